@@ -1,0 +1,145 @@
+"""ORACLE (test infrastructure, not product code): the reverse-diffusion loops on CPU.
+
+Restates, with every random draw passed in explicitly (CPU and GPU generators differ):
+  ResidualDiffusion.model_predictions / q_posterior / p_sample / p_sample_loop / ddim_sample / sample
+      /root/reference/src/DADiff.py:1120-1380  (objective 'pred_res', condition=True, eta=0)
+  GaussianDiffusion.model_predictions / p_sample / p_sample_loop / ddim_sample
+      /root/reference/src/denoising_diffusion_pytorch.py:523-652
+Pinned by tests/golden/e2e_*.npz captured from the reference with its torch.randn patched to
+replay the same tensors (tests/golden/make_golden.py).
+"""
+import math
+
+import torch
+
+from . import nets, schedule
+
+
+class ResidualOracle:
+    def __init__(self, sd, prefix="model.unet0.", timesteps=1000, sampling_timesteps=None,
+                 sum_scale=0.01, after_init=True, scan_fn=None, hoist_cond=True):
+        self.sd = nets.SD(sd, prefix)
+        self.T = timesteps
+        self.S = sampling_timesteps if sampling_timesteps is not None else timesteps
+        self.sum_scale = sum_scale
+        self.sch = schedule.residual_schedule(timesteps, after_init)
+        self.scan_fn = scan_fn
+        self.hoist_cond = hoist_cond  # the DA-CLIP branch is t-independent
+        self._cond = None
+
+    def unet(self, x_t, x_in, t_idx):
+        """t_idx (B,) long -> raw model output (B,1,H,W)."""
+        time = self.sch["alphas_cumsum"][t_idx] * self.T
+        x = torch.cat((x_t, x_in), dim=1)
+        if self.hoist_cond:
+            if self._cond is None:
+                self._cond = nets.da_unet_cond(self.sd, x_in)
+            cond = self._cond
+        else:
+            cond = None
+        return nets.da_unet(self.sd, x, time, cond, self.scan_fn)
+
+    def model_predictions(self, x_in, x_t, t_idx):
+        out = self.unet(x_t, x_in, t_idx)
+        pred_res = out.clamp(-1.0, 1.0)
+        a = self.sch["alphas_cumsum"][t_idx].view(-1, 1, 1, 1)
+        b = self.sch["betas_cumsum"][t_idx].view(-1, 1, 1, 1)
+        pred_noise = (x_t - x_in - (a - 1) * pred_res) / b
+        x_start = (x_in - pred_res).clamp(-1.0, 1.0)
+        return pred_res, pred_noise, x_start
+
+    def q_posterior(self, pred_res, x_start, x_t, t_idx):
+        e = lambda k: self.sch[k][t_idx].view(-1, 1, 1, 1)
+        mean = e("posterior_mean_coef1") * x_t + e("posterior_mean_coef2") * pred_res + \
+            e("posterior_mean_coef3") * x_start
+        return mean, e("posterior_variance"), e("posterior_log_variance_clipped")
+
+    def p_sample(self, x_in, x_t, t, noise):
+        t_idx = torch.full((x_t.shape[0],), t, dtype=torch.long)
+        pred_res, _, x_start = self.model_predictions(x_in, x_t, t_idx)
+        mean, _, logvar = self.q_posterior(pred_res, x_start, x_t, t_idx)
+        nz = noise if t > 0 else 0.0
+        return mean + (0.5 * logvar).exp() * nz, x_start
+
+    def sample(self, x_input01, noise0, step_noise=None, trace=None, t_stop=0):
+        """x_input01 (B,1,H,W) in [0,1]; noise0 the one randn(shape) draw; step_noise[t] for
+        the ancestral loop.  Returns [x_T01, out01] like sample(last=True)."""
+        self._cond = None
+        x_in = x_input01 * 2 - 1
+        img = x_in + math.sqrt(self.sum_scale) * noise0
+        start = img
+        if self.S < self.T:
+            for t, t_next in schedule.ddim_time_pairs(self.T, self.S):
+                t_idx = torch.full((img.shape[0],), t, dtype=torch.long)
+                pred_res, _, x_start = self.model_predictions(x_in, img, t_idx)
+                if trace is not None:
+                    trace.setdefault("pred_res", []).append(pred_res.clone())
+                if t_next < 0:
+                    img = x_start
+                else:
+                    alpha = self.sch["alphas_cumsum"][t] - self.sch["alphas_cumsum"][t_next]
+                    img = img - alpha * pred_res
+                if trace is not None:
+                    trace.setdefault("img", []).append(img.clone())
+        else:
+            for t in reversed(range(t_stop, self.T)):
+                img, _ = self.p_sample(x_in, img, t, None if t == 0 else step_noise[t])
+                if trace is not None:
+                    trace.setdefault("img", []).append(img.clone())
+        return [(start + 1) * 0.5, (img + 1) * 0.5]
+
+
+class GaussianOracle:
+    def __init__(self, sd, prefix="model.", timesteps=1000, sampling_timesteps=None,
+                 beta_schedule="cosine", objective="pred_noise", eta=0.0):
+        self.sd = nets.SD(sd, prefix)
+        self.T = timesteps
+        self.S = sampling_timesteps if sampling_timesteps is not None else timesteps
+        self.sch = schedule.gaussian_schedule(timesteps, beta_schedule)
+        self.objective = objective
+        self.eta = eta
+
+    def model_predictions(self, x, t_idx, clip_x_start=False):
+        out = nets.vanilla_unet(self.sd, x, t_idx)
+        e = lambda k: self.sch[k][t_idx].view(-1, 1, 1, 1)
+        clip = (lambda v: v.clamp(-1.0, 1.0)) if clip_x_start else (lambda v: v)
+        if self.objective == "pred_noise":
+            pred_noise = out
+            x_start = clip(e("sqrt_recip_alphas_cumprod") * x - e("sqrt_recipm1_alphas_cumprod") * out)
+        elif self.objective == "pred_x0":
+            x_start = clip(out)
+            pred_noise = (e("sqrt_recip_alphas_cumprod") * x - x_start) / e("sqrt_recipm1_alphas_cumprod")
+        else:  # pred_v
+            x_start = clip(e("sqrt_alphas_cumprod") * x - e("sqrt_one_minus_alphas_cumprod") * out)
+            pred_noise = (e("sqrt_recip_alphas_cumprod") * x - x_start) / e("sqrt_recipm1_alphas_cumprod")
+        return pred_noise, x_start
+
+    def p_sample(self, x, t, noise):
+        t_idx = torch.full((x.shape[0],), t, dtype=torch.long)
+        _, x_start = self.model_predictions(x, t_idx)
+        x_start = x_start.clamp(-1.0, 1.0)
+        e = lambda k: self.sch[k][t_idx].view(-1, 1, 1, 1)
+        mean = e("posterior_mean_coef1") * x_start + e("posterior_mean_coef2") * x
+        nz = noise if t > 0 else 0.0
+        return mean + (0.5 * e("posterior_log_variance_clipped")).exp() * nz, x_start
+
+    def sample(self, x_T, step_noise=None, t_stop=0):
+        """x_T the initial randn(shape); step_noise: list indexed by loop iteration for DDIM
+        (the reference draws randn_like every DDIM step even at eta=0) or dict t->noise."""
+        img = x_T
+        if self.S < self.T:
+            for i, (t, t_next) in enumerate(schedule.ddim_time_pairs(self.T, self.S)):
+                t_idx = torch.full((img.shape[0],), t, dtype=torch.long)
+                pred_noise, x_start = self.model_predictions(img, t_idx, clip_x_start=True)
+                if t_next < 0:
+                    img = x_start
+                    continue
+                a, an = self.sch["alphas_cumprod"][t], self.sch["alphas_cumprod"][t_next]
+                sigma = self.eta * ((1 - a / an) * (1 - an) / (1 - a)).sqrt()
+                c = (1 - an - sigma ** 2).sqrt()
+                nz = step_noise[i] if (step_noise is not None and self.eta != 0) else 0.0
+                img = x_start * an.sqrt() + c * pred_noise + sigma * nz
+        else:
+            for t in reversed(range(t_stop, self.T)):
+                img, _ = self.p_sample(img, t, None if t == 0 else step_noise[t])
+        return [(img + 1) * 0.5]

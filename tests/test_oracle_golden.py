@@ -1,0 +1,168 @@
+"""Pin the CPU oracle (oracle/) against golden vectors captured from the reference itself
+(tests/golden/make_golden.py).  CPU only."""
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import nets, sampler, schedule
+
+TOL = 2e-5   # fp32 re-association noise between two CPU implementations
+
+
+def test_residual_schedule(golden):
+    g = golden("schedule")
+    for tag, after in (("ctor", False), ("init", True)):
+        sch = schedule.residual_schedule(1000, after_init=after)
+        for k in schedule.RES_KEYS:
+            ref = g[f"{tag}.{k}"]
+            assert torch.equal(sch[k], ref), (tag, k, (sch[k] - ref).abs().max())
+
+
+def test_ddim_pairs(golden):
+    g = golden("schedule")
+    for S in (2, 10, 25, 50):
+        assert schedule.ddim_time_pairs(1000, S) == [tuple(p) for p in g[f"pairs.{S}"].tolist()]
+    assert schedule.ddim_time_pairs(1000, 50)[0] == (999, 979)
+
+
+def test_gaussian_schedule(golden):
+    g = golden("schedule")
+    for bs in ("linear", "cosine"):
+        sch = schedule.gaussian_schedule(1000, bs)
+        for k, v in sch.items():
+            assert torch.equal(v, g[f"vanilla.{bs}.{k}"]), (bs, k)
+
+
+def test_time_mlp(golden):
+    g = golden("modules")
+    sd = nets.SD(g.weights("time_mlp."), "time_mlp.")
+    assert rel_err(nets.time_mlp(sd, g["time_mlp.in"], 32), g["time_mlp.out"]) < TOL
+
+
+@pytest.mark.parametrize("name", ["rb_same", "rb_proj"])
+def test_resnet_block(golden, name):
+    g = golden("modules")
+    sd = nets.SD(g.weights(name + "."), name + ".")
+    assert rel_err(nets.block(sd.sub("block1."), g[name + ".in"]), g[name + ".block_out"]) < TOL
+    assert rel_err(nets.da_resnet_block(sd, g[name + ".in"]), g[name + ".out"]) < TOL
+
+
+def test_efficient_scan_merge(golden):
+    g = golden("modules")
+    for tag in ("even", "odd"):
+        x = g[f"escan_{tag}.in"]
+        xs = nets.efficient_scan(x)
+        assert torch.equal(xs, g[f"escan_{tag}.out"])
+        y = nets.efficient_merge(xs, x.shape[2], x.shape[3])
+        assert torch.equal(y, g[f"emerge_{tag}.out"])
+        assert torch.equal(y.view_as(x), x)      # merge inverts scan
+
+
+def test_scan_c_vs_torch():
+    torch.manual_seed(0)
+    b, K, Dg, N, L = 2, 4, 6, 5, 37
+    u, dl = torch.randn(b, K * Dg, L), torch.randn(b, K * Dg, L) * 0.5
+    A = -torch.exp(torch.randn(K * Dg, N) * 0.3)
+    B, C = torch.randn(b, K, N, L), torch.randn(b, K, N, L)
+    D, bias = torch.randn(K * Dg), torch.randn(K * Dg) * 0.1
+    y1 = nets.selective_scan(u, dl, A, B, C, D, bias, True)
+    y2 = nets.selective_scan_torch(u, dl, A, B, C, D, bias, True)
+    assert rel_err(y1, y2) < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["c32n4", "c64n32", "c32n16"])
+def test_ss2d(golden, tag):
+    g = golden("modules")
+    p = f"ss2d_{tag}."
+    sd = nets.SD(g.weights(p), p)
+    assert rel_err(nets.cross_selective_scan(sd, g[p + "core_in"]), g[p + "core_out"]) < TOL
+    assert rel_err(nets.ss2d(sd, g[p + "x"], g[p + "c"]), g[p + "out"]) < TOL
+
+
+def test_transposed_attention(golden):
+    g = golden("modules")
+    sd = nets.SD(g.weights("tattn."), "tattn.")
+    assert rel_err(nets.transposed_attention(sd, g["tattn.in"]), g["tattn.out"]) < TOL
+
+
+@pytest.mark.parametrize("tag", ["c32", "c64"])
+def test_mamba_block(golden, tag):
+    g = golden("modules")
+    p = f"mamba_{tag}."
+    sd = nets.SD(g.weights(p), p)
+    out = nets.mamba_block(sd, g[p + "x"], g[p + "c"], g[p + "t"])
+    assert rel_err(out, g[p + "out"]) < TOL
+
+
+def test_samplers_conv(golden):
+    g = golden("modules")
+    import torch.nn.functional as F
+    w = g.weights("down.")
+    assert rel_err(F.conv2d(g["down.in"], w["down.weight"], w["down.bias"], stride=2, padding=1), g["down.out"]) < TOL
+    w = g.weights("up.")
+    up = F.interpolate(g["up.in"], scale_factor=2, mode="nearest")
+    assert rel_err(F.conv2d(up, w["up.1.weight"], w["up.1.bias"], padding=1), g["up.out"]) < TOL
+
+
+def test_dose_encoder(golden):
+    g = golden("modules")
+    sd = nets.SD(g.weights("iqa."), "iqa.")
+    dose, ctx = nets.dose_encoder(sd, g["iqa.in"].repeat(1, 3, 1, 1))
+    assert rel_err(dose, g["iqa.dose"]) < TOL
+    assert rel_err(ctx, g["iqa.ctx"]) < TOL
+
+
+def test_vanilla_modules(golden):
+    g = golden("modules_vanilla")
+    sd = nets.SD(g.weights("vrb."), "vrb.")
+    assert rel_err(nets.v_resnet_block(sd, g["vrb.x"], g["vrb.t"]), g["vrb.out"]) < TOL
+    sd = nets.SD(g.weights("vlin."), "vlin.fn.")
+    assert rel_err(nets.v_linear_attention(sd, g["vlin.x"]), g["vlin.out"]) < TOL
+    sd = nets.SD(g.weights("vatt."), "vatt.fn.")
+    assert rel_err(nets.v_attention(sd, g["vatt.x"]), g["vatt.out"]) < TOL
+
+
+def test_e2e_da_tiny(golden):
+    g = golden("e2e_da_tiny")
+    w = g.weights()
+    orc = sampler.ResidualOracle(w, prefix="model.unet0.", sampling_timesteps=10)
+    x_in = g["x_input"]
+    xi = x_in * 2 - 1
+    xt = xi + 0.1 * g["ddim.noise0"]
+    tt = torch.full((2,), 979, dtype=torch.long)
+    assert rel_err(orc.unet(xt, xi, tt), g["unet.out"]) < 1e-4
+    pr, pn, xs = orc.model_predictions(xi, xt, tt)
+    assert rel_err(pr, g["mp.pred_res"]) < 1e-4
+    assert rel_err(pn, g["mp.pred_noise"]) < 1e-4
+    assert rel_err(xs, g["mp.x_start"]) < 1e-4
+    trace = {}
+    out = orc.sample(x_in, g["ddim.noise0"], trace=trace)
+    imgs = g["ddim.imgs"]
+    assert rel_err(out[0], imgs[0]) < 1e-6
+    for i, im in enumerate(trace["img"]):
+        assert rel_err((im + 1) * 0.5, imgs[i + 1]) < 2e-4, i
+    assert rel_err(out[1], g["ddim.out"]) < 2e-4
+    # ancestral steps
+    img = xt.clone()
+    for i, t in enumerate(range(999, 979, -1)):
+        img, _ = orc.p_sample(xi, img, t, g["anc.noise"][i])
+        assert rel_err(img, g["anc.imgs"][i]) < 2e-4, t
+    img0, xs0 = orc.p_sample(xi, xt, 0, None)
+    assert rel_err(img0, g["anc.t0_img"]) < 1e-4
+    assert rel_err(xs0, g["anc.t0_xstart"]) < 1e-4
+
+
+def test_e2e_vanilla_tiny(golden):
+    g = golden("e2e_vanilla_tiny")
+    w = g.weights()
+    sd = nets.SD(w, "model.")
+    assert rel_err(nets.vanilla_unet(sd, g["unet.x"], g["unet.t"]), g["unet.out"]) < 1e-4
+    for obj in ("pred_noise", "pred_x0", "pred_v"):
+        orc = sampler.GaussianOracle(w, sampling_timesteps=10, objective=obj)
+        out = orc.sample(g[f"ddim.{obj}.xT"])
+        assert rel_err(out[0], g[f"ddim.{obj}.out"]) < 5e-4, obj
+    orc = sampler.GaussianOracle(w, beta_schedule="linear")
+    img = g["ddim.pred_v.xT"]
+    for i, t in enumerate(range(999, 993, -1)):
+        img, _ = orc.p_sample(img, t, g["anc.noise"][i])
+        assert rel_err(img, g["anc.imgs"][i]) < 2e-4, t
