@@ -1,0 +1,105 @@
+"""ctypes binding of libfounddiff_hip.so (the C ABI declared in include/founddiff_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, we raise.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libfounddiff_hip.so")
+
+FD_F32, FD_BF16 = 0, 1
+EPI_NONE, EPI_SILU_SPLIT, EPI_RELU, EPI_GATE_RES, EPI_RES_RELU, EPI_GNSILU_ADD = range(6)
+ACT_NONE, ACT_SILU, ACT_GELU, ACT_RELU = range(4)
+
+vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+
+class ConvParams(C.Structure):
+    _fields_ = [
+        ("dtype", i32), ("out_f32", i32),
+        ("in0", vp), ("in1", vp),
+        ("c0", i32), ("ld0", i32), ("off0", i32),
+        ("c1", i32), ("ld1", i32), ("off1", i32),
+        ("B", i32), ("H", i32), ("W", i32),
+        ("upsample", i32),
+        ("KH", i32), ("KW", i32), ("stride", i32), ("pad_h", i32), ("pad_w", i32),
+        ("OH", i32), ("OW", i32),
+        ("ndir", i32),
+        ("weight", vp), ("w_batch_stride", i64), ("w_dir_stride", i64),
+        ("bias", vp),
+        ("Cout", i32),
+        ("out", vp), ("ldo", i32), ("offo", i32), ("out_dir_stride", i64),
+        ("epilogue", i32), ("epi_split", i32),
+        ("res", vp), ("ld_res", i32), ("off_res", i32),
+        ("gate", vp), ("gate_ld", i32),
+        ("h", vp), ("gn_mean_rstd", vp), ("gn_gamma", vp), ("gn_beta", vp), ("gn_groups", i32),
+        ("stats_partial", vp),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/founddiff_hip.h declares
+SIGNATURES = {
+    "fd_version": (i32, []),
+    "fd_last_error": (C.c_char_p, []),
+    "fd_conv_mtiles": (i32, [i32, i32]),
+    "fd_conv2d": (i32, [C.POINTER(ConvParams), vp]),
+    "fd_gn_finalize": (i32, [vp, i32, i32, i32, i32, i64, f32, vp, vp]),
+    "fd_gn_silu_apply": (i32, [i32, vp, vp, vp, vp, vp, vp, i32, i64, i32, i32, vp]),
+    "fd_ln_modulate": (i32, [i32, vp, vp, vp, f32, vp, vp, i32, vp, i32, i64, i32, vp]),
+    "fd_ln_gate": (i32, [i32, vp, vp, vp, f32, vp, i32, i32, vp, i32, vp, i32, i64, i32, vp]),
+    "fd_dwconv3x3": (i32, [i32, vp, i32, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "fd_scan_ws_floats": (i64, [i32, i32, i32, i32, i32]),
+    "fd_selective_scan": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "fd_chan_attn_nblk": (i32, [i64]),
+    "fd_chan_attn_gram": (i32, [i32, vp, i32, i64, i32, vp, vp]),
+    "fd_chan_attn_weff": (i32, [i32, vp, i32, vp, vp, vp, i32, i32, vp]),
+    "fd_linear": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "fd_sinusoidal": (i32, [vp, vp, i32, i32, vp]),
+    "fd_softmax_mul": (i32, [vp, vp, vp, i32, i32, vp]),
+    "fd_l2norm_rows": (i32, [vp, vp, i32, i32, f32, vp]),
+    "fd_add_f32": (i32, [vp, vp, vp, i64, vp]),
+    "fd_pack_planes": (i32, [i32, vp, vp, vp, i32, i64, i32, vp]),
+    "fd_final_conv1": (i32, [i32, vp, vp, vp, vp, i64, i32, vp]),
+    "fd_avgpool": (i32, [i32, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "fd_attnpool_tokens": (i32, [i32, vp, vp, i32, i64, i32, vp]),
+    "fd_attnpool_core": (i32, [vp, i32, vp, i32, i32, i32, vp, i32, i32, i32, i32, vp]),
+    "fd_res_predictions": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i64, vp]),
+    "fd_res_ddim_step": (i32, [vp, vp, vp, vp, f32, f32, i32, vp, i64, vp]),
+    "fd_res_posterior_step": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i64, vp]),
+    "fd_affine_f32": (i32, [vp, f32, f32, vp, i64, vp]),
+    "fd_axpy_f32": (i32, [vp, vp, f32, vp, i64, vp]),
+}
+
+_lib = None
+
+
+class FoundDiffHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the HIP library (once).  Raises if it has not been built: there is no CPU path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FoundDiffHipError(
+                f"{LIB_PATH} not found: build it with `python -m founddiff_amd.build` "
+                "(hipcc --offload-arch=gfx950).  founddiff_amd has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)       # AttributeError if the .so does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().fd_last_error().decode(errors="replace")
+        raise FoundDiffHipError(f"{what} failed (rc={rc}): {msg}")
+
+
+def call(name, *args):
+    check(getattr(lib(), name)(*args), name)

@@ -1,0 +1,455 @@
+// fd_conv.hip -- implicit-GEMM convolution / GEMM on MFMA for gfx950.
+//
+// One kernel serves every dense contraction of the denoiser (see include/founddiff_hip.h):
+// M = output pixels of one image, N = Cout, K = KH*KW*Cin with (kh,kw,c) ordering so that a
+// 16-byte chunk of the K axis is 8 (bf16) / 4 (f32) consecutive channels of ONE input pixel:
+// coalesced NHWC loads, no im2col buffer.  The A operand may come from two tensors (skip
+// concat), through a nearest x2 upsample, at stride 2 with a sub-grid origin (SS2D
+// directions), and with a pixel stride / channel offset (slices of wider tensors).
+//
+// Tile: 128 (pixels) x BN (64|128 channels) x 128 bytes of K per step, 256 threads = 4 waves
+// in 2x2, each wave 64 x BN/2 as 16x16 MFMA tiles (bf16: v_mfma_f32_16x16x32_bf16; f32 parity
+// mode: v_mfma_f32_16x16x4_f32, exact f32).  Global -> registers -> LDS double buffer, one
+// barrier per K step; LDS rows are 128 B with a 16-byte-chunk XOR swizzle
+// (chunk ^= (row>>1)&7) that makes the bf16 ds_read_b128 fragment reads conflict-free.
+// The accumulators are staged through LDS so the epilogue works on row-contiguous 8-channel
+// vectors: 16/32-byte stores, vector loads of the residual / GroupNorm operand, and
+// per-channel partial sums for the next GroupNorm.
+#include "fd_common.h"
+
+namespace {
+
+constexpr int BM = 128;
+constexpr int ROWB = 128;  // bytes of K per tile row
+
+template <typename T> struct Frag;
+template <> struct Frag<bf16> {
+    static constexpr int KSTEPS = 2;  // 64 bf16 per row = 2 x K32
+};
+template <> struct Frag<float> {
+    static constexpr int KSTEPS = 1;  // 32 f32 per row
+};
+
+__device__ __forceinline__ int swz(int row, int chunk) { return (chunk ^ ((row >> 1) & 7)) << 4; }
+
+template <typename T, int BN>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const fd_conv_params p) {
+    constexpr int CH = TT<T>::CH;
+    constexpr int BK = ROWB / (int)sizeof(T);
+    constexpr int NB = BN / 32;   // B rows per loading thread
+    constexpr int NT = BN / 32;   // 16-wide n tiles per wave
+    constexpr int AB_BYTES = 2 * (BM + BN) * ROWB;
+    constexpr int C_BYTES = BM * BN * 4;
+    constexpr int SM_BYTES = AB_BYTES > C_BYTES ? AB_BYTES : C_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SM_BYTES];
+    __shared__ float s_stat[4][BN][2];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int mt = blockIdx.x, nt = blockIdx.y;
+    const int b = blockIdx.z / p.ndir, dir = blockIdx.z % p.ndir;
+    const int Cin = p.c0 + p.c1;
+    const int K = p.KH * p.KW * Cin;
+    const int OHW = p.OH * p.OW;
+    const int pad_h = p.ndir > 1 ? -(dir & 1) : p.pad_h;
+    const int pad_w = p.ndir > 1 ? -(dir >> 1) : p.pad_w;
+    const T *__restrict__ in0 = (const T *)p.in0;
+    const T *__restrict__ in1 = (const T *)p.in1;
+    const T *__restrict__ wgt = (const T *)p.weight + (int64_t)b * p.w_batch_stride + (int64_t)dir * p.w_dir_stride;
+    const int Hs = p.upsample ? 2 * p.H : p.H, Ws = p.upsample ? 2 * p.W : p.W;
+
+    // ---- loader roles
+    const int chunk = tid & 7, rbase = tid >> 3;
+    int ihb[4], iwb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int m = mt * BM + rbase + 32 * i;
+        if (m < OHW) {
+            int oh = m / p.OW, ow = m - oh * p.OW;
+            ihb[i] = oh * p.stride - pad_h;
+            iwb[i] = ow * p.stride - pad_w;
+        } else {
+            ihb[i] = -(1 << 28);
+            iwb[i] = 0;
+        }
+    }
+    u32x4 ra[4], rb[NB];
+    const int nkt = (K + BK - 1) / BK;
+
+    auto gload = [&](int kt) {
+        const int k = kt * BK + chunk * CH;
+        const bool kv = k < K;
+        int tap = k / Cin;
+        int c = k - tap * Cin;
+        int kh = tap / p.KW, kw = tap - kh * p.KW;
+        const T *src;
+        int ld, coff;
+        if (c < p.c0) { src = in0; ld = p.ld0; coff = p.off0 + c; }
+        else { src = in1; ld = p.ld1; coff = p.off1 + c - p.c0; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int ih = ihb[i] + kh, iw = iwb[i] + kw;
+            bool ok = kv && ih >= 0 && ih < Hs && iw >= 0 && iw < Ws;
+            if (p.upsample) { ih >>= 1; iw >>= 1; }
+            u32x4 v = {0, 0, 0, 0};
+            if (ok) v = *(const u32x4 *)(src + ((int64_t)(b * p.H + ih) * p.W + iw) * ld + coff);
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            int n = nt * BN + rbase + 32 * i;
+            u32x4 v = {0, 0, 0, 0};
+            if (kv && n < p.Cout) v = *(const u32x4 *)(wgt + (int64_t)n * K + k);
+            rb[i] = v;
+        }
+    };
+    auto lstore = [&](int buf) {
+        unsigned char *sA = smem + buf * (BM + BN) * ROWB;
+        unsigned char *sB = sA + BM * ROWB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int r = rbase + 32 * i;
+            *(u32x4 *)(sA + r * ROWB + swz(r, chunk)) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            int r = rbase + 32 * i;
+            *(u32x4 *)(sB + r * ROWB + swz(r, chunk)) = rb[i];
+        }
+    };
+
+    // ---- compute roles
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fg = lane >> 4;
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nkt) gload(kt + 1);
+        const unsigned char *sA = smem + buf * (BM + BN) * ROWB;
+        const unsigned char *sB = sA + BM * ROWB;
+#pragma unroll
+        for (int ks = 0; ks < Frag<T>::KSTEPS; ++ks) {
+            if constexpr (sizeof(T) == 2) {
+                bf16x8 af[4], bfr[NT];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    int r = 64 * wm + 16 * i + fr;
+                    af[i] = *(const bf16x8 *)(sA + r * ROWB + swz(r, ks * 4 + fg));
+                }
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    int r = (BN / 2) * wn + 16 * j + fr;
+                    bfr[j] = *(const bf16x8 *)(sB + r * ROWB + swz(r, ks * 4 + fg));
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            } else {
+                // f32: lane group fg owns k = 8*fg .. 8*fg+7 of the 32-wide step; MFMA step e
+                // contracts the k-set {8g + e}: any consistent A/B k-permutation is a valid sum.
+                f32x4 a0[4], a1[4], b0[NT], b1[NT];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    int r = 64 * wm + 16 * i + fr;
+                    a0[i] = *(const f32x4 *)(sA + r * ROWB + swz(r, 2 * fg));
+                    a1[i] = *(const f32x4 *)(sA + r * ROWB + swz(r, 2 * fg + 1));
+                }
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    int r = (BN / 2) * wn + 16 * j + fr;
+                    b0[j] = *(const f32x4 *)(sB + r * ROWB + swz(r, 2 * fg));
+                    b1[j] = *(const f32x4 *)(sB + r * ROWB + swz(r, 2 * fg + 1));
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i][e], b0[j][e], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i][e], b1[j][e], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < nkt) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- stage accumulators: sC[row][col] f32, row-major BN floats per row
+    float *sC = (float *)smem;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int r = 64 * wm + 16 * i + fg * 4 + e;
+                int cc = (BN / 2) * wn + 16 * j + fr;
+                sC[r * BN + cc] = acc[i][j][e];
+            }
+    __syncthreads();
+
+    // ---- epilogue on 8-channel vectors
+    constexpr int VPR = BN / 8;          // vectors per row
+    constexpr int RPP = 256 / VPR;       // rows per pass
+    const int v = tid % VPR, r0 = tid / VPR;
+    const int n0 = nt * BN + v * 8;
+    const bool vec_ok = (p.Cout % 8 == 0) && (p.ldo % 8 == 0) && (p.offo % 8 == 0) &&
+                        (p.res == nullptr || (p.ld_res % 8 == 0 && p.off_res % 8 == 0));
+    float bias[8], gate[8], gam[8], bet[8], gmean[8], grstd[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        int n = n0 + e;
+        bool ok = n < p.Cout;
+        bias[e] = (p.bias && ok) ? p.bias[n] : 0.f;
+        gate[e] = (p.epilogue == FD_EPI_GATE_RES && ok) ? p.gate[(int64_t)b * p.gate_ld + n] : 0.f;
+        if (p.epilogue == FD_EPI_GNSILU_ADD && ok) {
+            int g = n / (p.Cout / p.gn_groups);
+            gam[e] = p.gn_gamma[n];
+            bet[e] = p.gn_beta[n];
+            gmean[e] = p.gn_mean_rstd[((int64_t)b * p.gn_groups + g) * 2];
+            grstd[e] = p.gn_mean_rstd[((int64_t)b * p.gn_groups + g) * 2 + 1];
+        } else {
+            gam[e] = bet[e] = gmean[e] = grstd[e] = 0.f;
+        }
+    }
+    float ssum[8], ssq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ssum[e] = ssq[e] = 0.f;
+
+    void *outp = p.out;
+    const int64_t obase = (int64_t)dir * p.out_dir_stride;
+    for (int r = r0; r < BM; r += RPP) {
+        const int m = mt * BM + r;
+        if (m >= OHW || n0 >= p.Cout) continue;
+        const int64_t pix = (int64_t)b * OHW + m;
+        float val[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) val[e] = sC[r * BN + v * 8 + e] + bias[e];
+        if (p.epilogue == FD_EPI_SILU_SPLIT) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (n0 + e >= p.epi_split) val[e] = fd_silu(val[e]);
+        } else if (p.epilogue == FD_EPI_RELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) val[e] = fmaxf(val[e], 0.f);
+        } else if (p.epilogue == FD_EPI_GATE_RES || p.epilogue == FD_EPI_RES_RELU) {
+            float rs[8];
+            const T *rp = (const T *)p.res + pix * p.ld_res + p.off_res + n0;
+            if (vec_ok) load8(rp, rs);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) rs[e] = (n0 + e < p.Cout) ? ld1(rp + e) : 0.f;
+            }
+            if (p.epilogue == FD_EPI_GATE_RES) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) val[e] = rs[e] + gate[e] * val[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) val[e] = fmaxf(val[e] + rs[e], 0.f);
+            }
+        } else if (p.epilogue == FD_EPI_GNSILU_ADD) {
+            float hv[8];
+            const T *hp = (const T *)p.h + pix * p.Cout + n0;
+            if (vec_ok) load8(hp, hv);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) hv[e] = (n0 + e < p.Cout) ? ld1(hp + e) : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                val[e] += fd_silu((hv[e] - gmean[e]) * grstd[e] * gam[e] + bet[e]);
+        }
+        if (p.stats_partial) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { ssum[e] += val[e]; ssq[e] += val[e] * val[e]; }
+        }
+        if (p.out_f32) {
+            float *op = (float *)outp + obase + pix * p.ldo + p.offo + n0;
+            if (vec_ok) store8(op, val);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (n0 + e < p.Cout) op[e] = val[e];
+            }
+        } else {
+            T *op = (T *)outp + obase + pix * p.ldo + p.offo + n0;
+            if (vec_ok) store8(op, val);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (n0 + e < p.Cout) st1(op + e, val[e]);
+            }
+        }
+    }
+
+    if (p.stats_partial) {
+        // lanes with equal (tid % VPR) hold the same 8 columns: reduce inside the wave, then
+        // across the 4 waves through LDS (fixed order -> deterministic).
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+#pragma unroll
+            for (int o = VPR; o < 64; o <<= 1) {
+                ssum[e] += __shfl_xor(ssum[e], o, 64);
+                ssq[e] += __shfl_xor(ssq[e], o, 64);
+            }
+        }
+        if (lane < VPR) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                s_stat[wave][lane * 8 + e][0] = ssum[e];
+                s_stat[wave][lane * 8 + e][1] = ssq[e];
+            }
+        }
+        __syncthreads();
+        if (tid < BN) {
+            int n = nt * BN + tid;
+            if (n < p.Cout) {
+                float s = 0.f, q = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) { s += s_stat[w][tid][0]; q += s_stat[w][tid][1]; }
+                float *sp = p.stats_partial + (((int64_t)b * gridDim.x + mt) * p.Cout + n) * 2;
+                sp[0] = s;
+                sp[1] = q;
+            }
+        }
+    }
+}
+
+__global__ void gn_finalize_kernel(const float *__restrict__ part, int mtiles, int C, int groups,
+                                   double inv_cnt, float eps, float *__restrict__ mean_rstd) {
+    const int b = blockIdx.x / groups, g = blockIdx.x % groups;
+    const int cpg = C / groups;
+    double s = 0.0, q = 0.0;
+    const int total = mtiles * cpg;
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+        int t = i / cpg, c = g * cpg + i % cpg;
+        const float *pp = part + (((int64_t)b * mtiles + t) * C + c) * 2;
+        s += pp[0];
+        q += pp[1];
+    }
+    __shared__ double sh[2][256];
+    sh[0][threadIdx.x] = s;
+    sh[1][threadIdx.x] = q;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
+            sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double mean = sh[0][0] * inv_cnt;
+        double var = sh[1][0] * inv_cnt - mean * mean;
+        if (var < 0) var = 0;
+        mean_rstd[blockIdx.x * 2] = (float)mean;
+        mean_rstd[blockIdx.x * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
+template <typename T>
+__global__ void gn_silu_apply_kernel(const T *__restrict__ h, const float *__restrict__ mean_rstd,
+                                     const float *__restrict__ gamma, const float *__restrict__ beta,
+                                     const T *__restrict__ res, T *__restrict__ out, int64_t hw, int C,
+                                     int groups, int64_t nvec_per_img) {
+    const int b = blockIdx.y;
+    const int cpg = C / groups;
+    const int vpr = C / 8;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvec_per_img;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        int c0 = (int)(i % vpr) * 8;
+        int64_t off = (int64_t)b * hw * C + i * 8;
+        float hv[8], rv[8], o[8];
+        load8(h + off, hv);
+        if (res) load8(res + off, rv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            int c = c0 + e, g = c / cpg;
+            float mean = mean_rstd[((int64_t)b * groups + g) * 2];
+            float rstd = mean_rstd[((int64_t)b * groups + g) * 2 + 1];
+            float y = fd_silu((hv[e] - mean) * rstd * gamma[c] + beta[c]);
+            o[e] = res ? y + rv[e] : y;
+        }
+        store8(out + off, o);
+    }
+}
+
+}  // namespace
+
+extern "C" int fd_conv_mtiles(int OH, int OW) { return cdiv((int64_t)OH * OW, BM); }
+
+extern "C" int fd_conv2d(const fd_conv_params *pp, void *stream) {
+    const fd_conv_params &p = *pp;
+    const int CH = p.dtype == FD_BF16 ? 8 : 4;
+    FD_REQUIRE(p.dtype == FD_F32 || p.dtype == FD_BF16, "fd_conv2d: bad dtype %d", p.dtype);
+    FD_REQUIRE(p.in0 && p.weight && p.out, "fd_conv2d: null pointer");
+    FD_REQUIRE(p.c0 > 0 && p.c0 % CH == 0 && p.ld0 % CH == 0 && p.off0 % CH == 0,
+               "fd_conv2d: source 0 channels/stride/offset (%d,%d,%d) must be multiples of %d", p.c0, p.ld0, p.off0, CH);
+    FD_REQUIRE(p.c1 == 0 || (p.in1 && p.c1 % CH == 0 && p.ld1 % CH == 0 && p.off1 % CH == 0),
+               "fd_conv2d: source 1 channels/stride/offset must be multiples of %d", CH);
+    FD_REQUIRE(p.B > 0 && p.H > 0 && p.W > 0 && p.OH > 0 && p.OW > 0 && p.Cout > 0, "fd_conv2d: bad sizes");
+    FD_REQUIRE(p.KH > 0 && p.KW > 0 && p.stride > 0, "fd_conv2d: bad kernel/stride");
+    FD_REQUIRE(p.ndir == 1 || p.ndir == 4, "fd_conv2d: ndir must be 1 or 4");
+    FD_REQUIRE(p.epilogue >= FD_EPI_NONE && p.epilogue <= FD_EPI_GNSILU_ADD, "fd_conv2d: bad epilogue %d", p.epilogue);
+    if (p.epilogue == FD_EPI_GATE_RES) FD_REQUIRE(p.res && p.gate, "fd_conv2d: GATE_RES needs res and gate");
+    if (p.epilogue == FD_EPI_RES_RELU) FD_REQUIRE(p.res, "fd_conv2d: RES_RELU needs res");
+    if (p.epilogue == FD_EPI_GNSILU_ADD)
+        FD_REQUIRE(p.h && p.gn_mean_rstd && p.gn_gamma && p.gn_beta && p.gn_groups > 0 && p.Cout % p.gn_groups == 0,
+                   "fd_conv2d: GNSILU_ADD needs h, statistics, affine and groups | Cout");
+    const int mt = fd_conv_mtiles(p.OH, p.OW);
+    const bool wide = p.Cout > 64;
+    dim3 grid(mt, cdiv(p.Cout, wide ? 128 : 64), p.B * p.ndir), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (p.dtype == FD_BF16) {
+        if (wide) hipLaunchKernelGGL((conv_igemm_kernel<bf16, 128>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((conv_igemm_kernel<bf16, 64>), grid, block, 0, s, p);
+    } else {
+        if (wide) hipLaunchKernelGGL((conv_igemm_kernel<float, 128>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((conv_igemm_kernel<float, 64>), grid, block, 0, s, p);
+    }
+    FD_LAUNCH_OK("fd_conv2d");
+    return FD_OK;
+}
+
+extern "C" int fd_gn_finalize(const float *stats_partial, int B, int mtiles, int C, int groups,
+                              int64_t hw, float eps, float *mean_rstd, void *stream) {
+    FD_REQUIRE(stats_partial && mean_rstd && groups > 0 && C % groups == 0, "fd_gn_finalize: bad args");
+    double inv = 1.0 / ((double)hw * (C / groups));
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(256), 0, (hipStream_t)stream,
+                       stats_partial, mtiles, C, groups, inv, eps, mean_rstd);
+    FD_LAUNCH_OK("fd_gn_finalize");
+    return FD_OK;
+}
+
+extern "C" int fd_gn_silu_apply(int dtype, const void *h, const float *mean_rstd, const float *gamma,
+                                const float *beta, const void *res, void *out, int B, int64_t hw,
+                                int C, int groups, void *stream) {
+    FD_REQUIRE(C % 8 == 0 && C % groups == 0, "fd_gn_silu_apply: C=%d must be a multiple of 8 and of groups", C);
+    int64_t nvec = hw * C / 8;
+    dim3 grid((unsigned)((nvec + 255) / 256 > 2048 ? 2048 : (nvec + 255) / 256), B), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == FD_BF16)
+        hipLaunchKernelGGL(gn_silu_apply_kernel<bf16>, grid, block, 0, s, (const bf16 *)h, mean_rstd, gamma, beta,
+                           (const bf16 *)res, (bf16 *)out, hw, C, groups, nvec);
+    else
+        hipLaunchKernelGGL(gn_silu_apply_kernel<float>, grid, block, 0, s, (const float *)h, mean_rstd, gamma, beta,
+                           (const float *)res, (float *)out, hw, C, groups, nvec);
+    FD_LAUNCH_OK("fd_gn_silu_apply");
+    return FD_OK;
+}

@@ -1,0 +1,306 @@
+// fd_rows.hip -- HBM-bound row kernels on NHWC activations: LayerNorm+adaLN modulate,
+// out_norm * z + local, depthwise 3x3, avg-pool, plane packing, final 1-channel conv.
+// All are one pass over their operands with 16-byte (bf16) / 32-byte (f32) per-lane vectors.
+#include "fd_common.h"
+
+namespace {
+
+// Row of C channels handled by LPR lanes x VPL 8-element vectors per lane (C = 8*VPL*LPR),
+// LPR a power of two <= 64 so the reduction is an xor-shuffle butterfly inside one wave.
+template <typename T, int VPL, bool GATE>
+__global__ __launch_bounds__(256) void ln_rows_kernel(
+    const T *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+    const float *__restrict__ shift, const float *__restrict__ scale, int mod_ld,
+    const T *__restrict__ z, int ldz, int offz, T *__restrict__ out, int64_t hw, int C, int lpr,
+    int64_t nrows) {
+    const int tid = threadIdx.x;
+    const int rpb = 256 / lpr;  // rows per block
+    const int sub = tid % lpr;
+    const int64_t row = (int64_t)blockIdx.x * rpb + tid / lpr;
+    const bool active = row < nrows;
+    const int64_t rr = active ? row : 0;
+    const int b = (int)(rr / hw);
+    float v[VPL][8];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        load8(x + rr * C + (j * lpr + sub) * 8, v[j]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[j][e];
+    }
+    for (int o = 1; o < lpr; o <<= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / C;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float d = v[j][e] - mean;
+            q += d * d;
+        }
+    for (int o = 1; o < lpr; o <<= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = rsqrtf(q / C + eps);
+    if (!active) return;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        const int c0 = (j * lpr + sub) * 8;
+        float o8[8], zz[8];
+        if (GATE) load8(z + rr * ldz + offz + c0, zz);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = c0 + e;
+            float y = (v[j][e] - mean) * rstd;
+            if (gamma) y = y * gamma[c] + beta[c];
+            if (GATE) y = y * zz[e] + shift[(int64_t)b * mod_ld + c];       // shift == local
+            else y = y * (1.f + scale[(int64_t)b * mod_ld + c]) + shift[(int64_t)b * mod_ld + c];
+            o8[e] = y;
+        }
+        store8(out + rr * C + c0, o8);
+    }
+}
+
+template <typename T, bool GATE>
+int launch_ln(const T *x, const float *gamma, const float *beta, float eps, const float *shift,
+              const float *scale, int mod_ld, const T *z, int ldz, int offz, T *out, int B, int64_t hw,
+              int C, hipStream_t s) {
+    int vpl = (C + 511) / 512;
+    int lpr = C / (8 * vpl);
+    if (lpr * 8 * vpl != C || (lpr & (lpr - 1)) || lpr > 64 || vpl > 2) {
+        fd_set_error("fd_ln_*: C=%d unsupported (need C = 8*v*2^k, v<=2, 2^k<=64)", C);
+        return FD_ERR_ARG;
+    }
+    int64_t nrows = (int64_t)B * hw;
+    int rpb = 256 / lpr;
+    dim3 grid((unsigned)((nrows + rpb - 1) / rpb)), block(256);
+    if (vpl == 1)
+        hipLaunchKernelGGL((ln_rows_kernel<T, 1, GATE>), grid, block, 0, s, x, gamma, beta, eps, shift, scale,
+                           mod_ld, z, ldz, offz, out, hw, C, lpr, nrows);
+    else
+        hipLaunchKernelGGL((ln_rows_kernel<T, 2, GATE>), grid, block, 0, s, x, gamma, beta, eps, shift, scale,
+                           mod_ld, z, ldz, offz, out, hw, C, lpr, nrows);
+    return FD_OK;
+}
+
+// depthwise 3x3, pad 1: a thread owns 8 channels of one pixel.
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv3x3_kernel(const T *__restrict__ in, int ld_in, int off_in,
+                                                       const float *__restrict__ w, const float *__restrict__ bias,
+                                                       int silu, T *__restrict__ out, int ld_out, int off_out,
+                                                       int H, int W, int C, int64_t total) {
+    const int vpp = C / 8;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % vpp);
+        const int64_t pix = i / vpp;
+        const int x = (int)(pix % W);
+        const int y = (int)((pix / W) % H);
+        const int64_t img = pix / ((int64_t)W * H);
+        const int c0 = cv * 8;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = bias ? bias[c0 + e] : 0.f;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int yy = y + dy;
+            if (yy < 0 || yy >= H) continue;
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int xx = x + dx;
+                if (xx < 0 || xx >= W) continue;
+                float v[8], ww[8];
+                load8(in + ((img * H + yy) * W + xx) * ld_in + off_in + c0, v);
+                load8(w + ((dy + 1) * 3 + (dx + 1)) * C + c0, ww);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += v[e] * ww[e];
+            }
+        }
+        if (silu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = fd_silu(acc[e]);
+        }
+        store8(out + pix * ld_out + off_out + c0, acc);
+    }
+}
+
+template <typename T>
+__global__ void avgpool_kernel(const T *__restrict__ in, T *__restrict__ out, int H, int W, int C, int k,
+                               int64_t total) {
+    const int OH = H / k, OW = W / k, vpp = C / 8;
+    const float inv = 1.f / (k * k);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % vpp);
+        const int64_t pix = i / vpp;
+        const int ox = (int)(pix % OW), oy = (int)((pix / OW) % OH);
+        const int64_t img = pix / ((int64_t)OW * OH);
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int dy = 0; dy < k; ++dy)
+            for (int dx = 0; dx < k; ++dx) {
+                float v[8];
+                load8(in + ((img * H + oy * k + dy) * W + ox * k + dx) * C + cv * 8, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += v[e];
+            }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] *= inv;
+        store8(out + pix * C + cv * 8, acc);
+    }
+}
+
+template <typename T>
+__global__ void pack_planes_kernel(const float *__restrict__ p0, const float *__restrict__ p1, T *__restrict__ out,
+                                   int64_t npix, int cpad) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < npix;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        float v[8] = {p0[i], p1 ? p1[i] : 0.f, 0, 0, 0, 0, 0, 0};
+        store8(out + i * cpad, v);
+        for (int c = 8; c < cpad; c += 8) {
+            float zz[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            store8(out + i * cpad + c, zz);
+        }
+    }
+}
+
+// out[p] = b + sum_c x[p,c] w[c]; C/8 lanes cooperate on one pixel.
+template <typename T>
+__global__ __launch_bounds__(256) void final_conv1_kernel(const T *__restrict__ x, const float *__restrict__ w,
+                                                         const float *__restrict__ bias, float *__restrict__ out,
+                                                         int64_t npix, int C, int lpp) {
+    const int ppb = 256 / lpp;
+    const int sub = threadIdx.x % lpp;
+    const int64_t pix = (int64_t)blockIdx.x * ppb + threadIdx.x / lpp;
+    const bool active = pix < npix;
+    float s = 0.f;
+    if (active)
+        for (int c0 = sub * 8; c0 < C; c0 += lpp * 8) {
+            float v[8], ww[8];
+            load8(x + pix * C + c0, v);
+            load8(w + c0, ww);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += v[e] * ww[e];
+        }
+    for (int o = 1; o < lpp; o <<= 1) s += __shfl_xor(s, o, 64);
+    if (active && sub == 0) out[pix] = s + bias[0];
+}
+
+// tokens[b,0,:] = mean over hw; tokens[b,1+p,:] = x[b,p,:]
+template <typename T>
+__global__ void attnpool_tokens_kernel(const T *__restrict__ x, T *__restrict__ tok, int64_t hw, int C) {
+    const int b = blockIdx.y;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int64_t p = 0; p < hw; ++p) {
+        float v = ld1(x + ((int64_t)b * hw + p) * C + c);
+        s += v;
+        st1(tok + ((int64_t)b * (hw + 1) + 1 + p) * C + c, v);
+    }
+    st1(tok + (int64_t)b * (hw + 1) * C + c, s / (float)hw);
+}
+
+unsigned grid1d(int64_t n, int block = 256, int cap = 4096) {
+    int64_t g = (n + block - 1) / block;
+    return (unsigned)(g > cap ? cap : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+extern "C" int fd_ln_modulate(int dtype, const void *x, const float *gamma, const float *beta, float eps,
+                              const float *shift, const float *scale, int mod_ld, void *out, int B,
+                              int64_t hw, int C, void *stream) {
+    FD_REQUIRE(x && out && shift && scale, "fd_ln_modulate: null pointer");
+    FD_REQUIRE((gamma == nullptr) == (beta == nullptr), "fd_ln_modulate: gamma/beta must both be set or NULL");
+    int rc = dtype == FD_BF16
+                 ? launch_ln<bf16, false>((const bf16 *)x, gamma, beta, eps, shift, scale, mod_ld, nullptr, 0, 0,
+                                          (bf16 *)out, B, hw, C, (hipStream_t)stream)
+                 : launch_ln<float, false>((const float *)x, gamma, beta, eps, shift, scale, mod_ld, nullptr, 0, 0,
+                                           (float *)out, B, hw, C, (hipStream_t)stream);
+    if (rc) return rc;
+    FD_LAUNCH_OK("fd_ln_modulate");
+    return FD_OK;
+}
+
+extern "C" int fd_ln_gate(int dtype, const void *y, const float *gamma, const float *beta, float eps,
+                          const void *z, int ldz, int offz, const float *local, int local_ld, void *out,
+                          int B, int64_t hw, int C, void *stream) {
+    FD_REQUIRE(y && z && local && out && gamma && beta, "fd_ln_gate: null pointer");
+    FD_REQUIRE(ldz % 8 == 0 && offz % 8 == 0, "fd_ln_gate: z stride/offset must be multiples of 8");
+    int rc = dtype == FD_BF16
+                 ? launch_ln<bf16, true>((const bf16 *)y, gamma, beta, eps, local, nullptr, local_ld, (const bf16 *)z,
+                                         ldz, offz, (bf16 *)out, B, hw, C, (hipStream_t)stream)
+                 : launch_ln<float, true>((const float *)y, gamma, beta, eps, local, nullptr, local_ld,
+                                          (const float *)z, ldz, offz, (float *)out, B, hw, C, (hipStream_t)stream);
+    if (rc) return rc;
+    FD_LAUNCH_OK("fd_ln_gate");
+    return FD_OK;
+}
+
+extern "C" int fd_dwconv3x3(int dtype, const void *in, int ld_in, int off_in, const float *weight,
+                            const float *bias, int silu, void *out, int ld_out, int off_out, int B, int H,
+                            int W, int C, void *stream) {
+    FD_REQUIRE(in && out && weight, "fd_dwconv3x3: null pointer");
+    FD_REQUIRE(C % 8 == 0 && ld_in % 8 == 0 && off_in % 8 == 0 && ld_out % 8 == 0 && off_out % 8 == 0,
+               "fd_dwconv3x3: channels/strides/offsets must be multiples of 8");
+    int64_t total = (int64_t)B * H * W * (C / 8);
+    dim3 grid(grid1d(total, 256, 1 << 20)), block(256);
+    if (dtype == FD_BF16)
+        hipLaunchKernelGGL(dwconv3x3_kernel<bf16>, grid, block, 0, (hipStream_t)stream, (const bf16 *)in, ld_in, off_in,
+                           weight, bias, silu, (bf16 *)out, ld_out, off_out, H, W, C, total);
+    else
+        hipLaunchKernelGGL(dwconv3x3_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float *)in, ld_in,
+                           off_in, weight, bias, silu, (float *)out, ld_out, off_out, H, W, C, total);
+    FD_LAUNCH_OK("fd_dwconv3x3");
+    return FD_OK;
+}
+
+extern "C" int fd_avgpool(int dtype, const void *in, void *out, int B, int H, int W, int C, int k, void *stream) {
+    FD_REQUIRE(C % 8 == 0 && k > 0 && H % k == 0 && W % k == 0, "fd_avgpool: C%%8, H%%k, W%%k must be 0");
+    int64_t total = (int64_t)B * (H / k) * (W / k) * (C / 8);
+    dim3 grid(grid1d(total)), block(256);
+    if (dtype == FD_BF16)
+        hipLaunchKernelGGL(avgpool_kernel<bf16>, grid, block, 0, (hipStream_t)stream, (const bf16 *)in, (bf16 *)out, H, W,
+                           C, k, total);
+    else
+        hipLaunchKernelGGL(avgpool_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float *)in, (float *)out, H,
+                           W, C, k, total);
+    FD_LAUNCH_OK("fd_avgpool");
+    return FD_OK;
+}
+
+extern "C" int fd_pack_planes(int dtype, const float *p0, const float *p1, void *out, int B, int64_t hw, int cpad,
+                              void *stream) {
+    FD_REQUIRE(p0 && out && cpad >= 8 && cpad % 8 == 0, "fd_pack_planes: bad args");
+    int64_t npix = (int64_t)B * hw;
+    dim3 grid(grid1d(npix)), block(256);
+    if (dtype == FD_BF16)
+        hipLaunchKernelGGL(pack_planes_kernel<bf16>, grid, block, 0, (hipStream_t)stream, p0, p1, (bf16 *)out, npix, cpad);
+    else
+        hipLaunchKernelGGL(pack_planes_kernel<float>, grid, block, 0, (hipStream_t)stream, p0, p1, (float *)out, npix, cpad);
+    FD_LAUNCH_OK("fd_pack_planes");
+    return FD_OK;
+}
+
+extern "C" int fd_final_conv1(int dtype, const void *x, const float *w, const float *b, float *out, int64_t npix,
+                              int C, void *stream) {
+    FD_REQUIRE(x && w && b && out && C % 8 == 0, "fd_final_conv1: bad args");
+    int lpp = 1;
+    while (lpp * 2 * 8 <= C && lpp < 64) lpp *= 2;
+    int ppb = 256 / lpp;
+    dim3 grid((unsigned)((npix + ppb - 1) / ppb)), block(256);
+    if (dtype == FD_BF16)
+        hipLaunchKernelGGL(final_conv1_kernel<bf16>, grid, block, 0, (hipStream_t)stream, (const bf16 *)x, w, b, out, npix, C, lpp);
+    else
+        hipLaunchKernelGGL(final_conv1_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float *)x, w, b, out, npix, C, lpp);
+    FD_LAUNCH_OK("fd_final_conv1");
+    return FD_OK;
+}
+
+extern "C" int fd_attnpool_tokens(int dtype, const void *x, void *tok, int B, int64_t hw, int C, void *stream) {
+    dim3 grid((C + 255) / 256, B), block(256);
+    if (dtype == FD_BF16)
+        hipLaunchKernelGGL(attnpool_tokens_kernel<bf16>, grid, block, 0, (hipStream_t)stream, (const bf16 *)x, (bf16 *)tok, hw, C);
+    else
+        hipLaunchKernelGGL(attnpool_tokens_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float *)x, (float *)tok, hw, C);
+    FD_LAUNCH_OK("fd_attnpool_tokens");
+    return FD_OK;
+}

@@ -1,0 +1,211 @@
+// fd_scan.hip -- SS2D selective scan for gfx950: chunked 3-phase parallel prefix over the
+// sequence, fp32 state, one lane per channel (coalesced NHWC loads), the per-position
+// (dt_r, B, C) row wave-uniform (scalar loads).
+//
+//   phase A  (parallel over chunks)  local scan from h=0:  H_c[n] and sum of dt -> P_c[n]=exp(A[n]*sum dt)
+//   phase B  (parallel over segments of chunks) carry-in of every chunk: h_in[c+1] = P_c h_in[c] + H_c
+//   phase C  (parallel over chunks)  re-run the recurrence from h_in, y = sum_n h C + D u
+//
+// The EfficientScan gather (4 stride-2 sub-grids, two of them column-major) and the
+// EfficientMerge scatter are index arithmetic on the NHWC tensors: neither the (B,4,D,L)
+// gathered tensor, nor delta (dt_proj + bias + softplus is recomputed per step from the
+// R-vector), nor dA/dBu ever exist in HBM.  Algorithmic HBM bytes per (pixel, channel):
+// u read twice + y written once (dtype), plus the x_dbl rows (fp32, shared by all channels).
+#include "fd_common.h"
+
+namespace {
+
+struct ScanGeom {
+    int B, H, W, D, N, R, CD;
+    int H2, W2, L, CL, nch;
+};
+
+// position l of direction k -> (row of xdbl, NHWC pixel index inside the image)
+__device__ __forceinline__ void scan_pos(const ScanGeom &g, int k, int l, int &lrow, int &pix) {
+    int h2, w2;
+    if (k & 1) { w2 = l / g.H2; h2 = l - w2 * g.H2; }
+    else { h2 = l / g.W2; w2 = l - h2 * g.W2; }
+    lrow = h2 * g.W2 + w2;
+    pix = (2 * h2 + (k & 1)) * g.W + 2 * w2 + (k >> 1);
+}
+
+template <typename T, int N, int R, bool FINAL>
+__global__ __launch_bounds__(256) void scan_chunk_kernel(const T *__restrict__ xc, const float *__restrict__ xdbl,
+                                                        const float *__restrict__ dtw, const float *__restrict__ dtb,
+                                                        const float *__restrict__ A, const float *__restrict__ Ds,
+                                                        T *__restrict__ y, float *__restrict__ wsH,
+                                                        float *__restrict__ wsP, const ScanGeom g) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int dblocks = g.D / 64;
+    const int unit = blockIdx.x * 4 + wave;          // (chunk, dblock)
+    if (unit >= g.nch * dblocks) return;
+    const int chunk = unit / dblocks, db = unit - chunk * dblocks;
+    const int bk = blockIdx.y, b = bk >> 2, k = bk & 3;
+    const int d = db * 64 + lane;
+    const int kd = k * g.D + d;
+
+    float w[R], a[N], h[N];
+#pragma unroll
+    for (int r = 0; r < R; ++r) w[r] = dtw[(int64_t)kd * R + r];
+#pragma unroll
+    for (int n = 0; n < N; ++n) a[n] = A[(int64_t)kd * N + n];
+    const float bias = dtb[kd];
+    const float Dd = FINAL ? Ds[kd] : 0.f;
+    const int64_t cbase = (((int64_t)bk * g.nch + chunk) * N) * g.D + d;   // [bk][chunk][n][d]
+    if (FINAL) {
+#pragma unroll
+        for (int n = 0; n < N; ++n) h[n] = wsH[cbase + (int64_t)n * g.D];
+    } else {
+#pragma unroll
+        for (int n = 0; n < N; ++n) h[n] = 0.f;
+    }
+    float sdt = 0.f;
+    const int l0 = chunk * g.CL;
+    const int l1 = min(l0 + g.CL, g.L);
+    const float *xb = xdbl + ((int64_t)k * g.B + b) * g.L * g.CD;   // [4][B][L][CD]
+    const T *ub = xc + (int64_t)b * g.H * g.W * g.D + d;
+    T *yb = FINAL ? y + (int64_t)b * g.H * g.W * g.D + d : nullptr;
+    for (int l = l0; l < l1; ++l) {
+        int lrow, pix;
+        scan_pos(g, k, l, lrow, pix);
+        const float *xr = xb + (int64_t)lrow * g.CD;      // wave-uniform row
+        const float u = ld1(ub + (int64_t)pix * g.D);
+        float dv = bias;
+#pragma unroll
+        for (int r = 0; r < R; ++r) dv += w[r] * xr[r];
+        const float dt = fd_softplus(dv);
+        const float dtu = dt * u;
+        if (!FINAL) sdt += dt;
+        float acc = 0.f;
+#pragma unroll
+        for (int n = 0; n < N; ++n) {
+            const float da = __expf(dt * a[n]);
+            h[n] = da * h[n] + dtu * xr[R + n];
+            if (FINAL) acc += h[n] * xr[R + N + n];
+        }
+        if (FINAL) st1(yb + (int64_t)pix * g.D, acc + Dd * u);
+    }
+    if (!FINAL) {
+#pragma unroll
+        for (int n = 0; n < N; ++n) {
+            wsH[cbase + (int64_t)n * g.D] = h[n];
+            wsP[cbase + (int64_t)n * g.D] = __expf(a[n] * sdt);
+        }
+    }
+}
+
+// Phase B: block = 64 channels x S segments.  Each segment composes its chunks, segments are
+// chained through LDS, then each segment rewrites H_c with the carry-in of chunk c.
+constexpr int SEG = 16;
+__global__ __launch_bounds__(64 * SEG) void scan_carry_kernel(float *__restrict__ wsH, const float *__restrict__ wsP,
+                                                             int nch, int N, int D) {
+    __shared__ float sP[SEG][64], sH[SEG][64];
+    const int lane = threadIdx.x & 63;
+    const int seg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int dblocks = D / 64;
+    const int db = blockIdx.x % dblocks, n = (blockIdx.x / dblocks) % N, bk = blockIdx.x / (dblocks * N);
+    const int d = db * 64 + lane;
+    const int per = (nch + SEG - 1) / SEG;
+    const int c0 = seg * per, c1 = min(c0 + per, nch);
+    const int64_t base = ((int64_t)bk * nch * N + n) * D + d;   // + c*N*D
+    const int64_t cs = (int64_t)N * D;
+    float P = 1.f, Hh = 0.f;
+    for (int c = c0; c < c1; ++c) {
+        const float p = wsP[base + c * cs], hh = wsH[base + c * cs];
+        Hh = p * Hh + hh;
+        P = p * P;
+    }
+    sP[seg][lane] = P;
+    sH[seg][lane] = Hh;
+    __syncthreads();
+    float carry = 0.f;
+    for (int s = 0; s < seg; ++s) carry = sP[s][lane] * carry + sH[s][lane];
+    for (int c = c0; c < c1; ++c) {
+        const float p = wsP[base + c * cs], hh = wsH[base + c * cs];
+        wsH[base + c * cs] = carry;
+        carry = p * carry + hh;
+    }
+}
+
+template <typename T, int N, int R>
+void launch_scan(const T *xc, const float *xdbl, const float *dtw, const float *dtb, const float *A,
+                 const float *Ds, T *y, float *ws, const ScanGeom &g, hipStream_t s) {
+    const int64_t half = (int64_t)g.B * 4 * g.nch * g.N * g.D;
+    float *wsH = ws, *wsP = ws + half;
+    const int units = g.nch * (g.D / 64);
+    dim3 grid((units + 3) / 4, g.B * 4), block(256);
+    hipLaunchKernelGGL((scan_chunk_kernel<T, N, R, false>), grid, block, 0, s, xc, xdbl, dtw, dtb, A, Ds, y, wsH, wsP, g);
+    if (g.nch > 1)
+        hipLaunchKernelGGL(scan_carry_kernel, dim3(g.B * 4 * g.N * (g.D / 64)), dim3(64 * SEG), 0, s, wsH, wsP,
+                           g.nch, g.N, g.D);
+    else
+        (void)hipMemsetAsync(wsH, 0, half * sizeof(float), s);
+    hipLaunchKernelGGL((scan_chunk_kernel<T, N, R, true>), grid, block, 0, s, xc, xdbl, dtw, dtb, A, Ds, y, wsH, wsP, g);
+}
+
+template <typename T, int N>
+int dispatch_r(const T *xc, const float *xdbl, const float *dtw, const float *dtb, const float *A,
+               const float *Ds, T *y, float *ws, const ScanGeom &g, hipStream_t s) {
+    switch (g.R) {
+    case 2: launch_scan<T, N, 2>(xc, xdbl, dtw, dtb, A, Ds, y, ws, g, s); return 0;
+    case 4: launch_scan<T, N, 4>(xc, xdbl, dtw, dtb, A, Ds, y, ws, g, s); return 0;
+    case 8: launch_scan<T, N, 8>(xc, xdbl, dtw, dtb, A, Ds, y, ws, g, s); return 0;
+    case 16: launch_scan<T, N, 16>(xc, xdbl, dtw, dtb, A, Ds, y, ws, g, s); return 0;
+    case 32: launch_scan<T, N, 32>(xc, xdbl, dtw, dtb, A, Ds, y, ws, g, s); return 0;
+    }
+    return -1;
+}
+
+template <typename T>
+int dispatch_n(const T *xc, const float *xdbl, const float *dtw, const float *dtb, const float *A,
+               const float *Ds, T *y, float *ws, const ScanGeom &g, hipStream_t s) {
+    switch (g.N) {
+    case 4: return dispatch_r<T, 4>(xc, xdbl, dtw, dtb, A, Ds, y, ws, g, s);
+    case 8: return dispatch_r<T, 8>(xc, xdbl, dtw, dtb, A, Ds, y, ws, g, s);
+    case 16: return dispatch_r<T, 16>(xc, xdbl, dtw, dtb, A, Ds, y, ws, g, s);
+    case 32: return dispatch_r<T, 32>(xc, xdbl, dtw, dtb, A, Ds, y, ws, g, s);
+    }
+    return -1;
+}
+
+int chunk_len(int L, int D) {
+    // aim for >= ~4096 waves per image (4 per SIMD), chunk length a power of two in [32, 256].
+    // Deliberately independent of the batch size: a slice's result must not depend on what
+    // else is in the batch (bitwise batch invariance -> sharding over GPUs changes nothing).
+    int64_t units = (int64_t)4 * (D / 64) * L;
+    int cl = 256;
+    while (cl > 32 && units / cl < 4096) cl >>= 1;
+    return cl;
+}
+
+ScanGeom make_geom(int B, int H, int W, int D, int N, int R) {
+    ScanGeom g;
+    g.B = B; g.H = H; g.W = W; g.D = D; g.N = N; g.R = R; g.CD = R + 2 * N;
+    g.H2 = H / 2; g.W2 = W / 2; g.L = g.H2 * g.W2;
+    g.CL = chunk_len(g.L, D);
+    g.nch = (g.L + g.CL - 1) / g.CL;
+    return g;
+}
+
+}  // namespace
+
+extern "C" int64_t fd_scan_ws_floats(int B, int H, int W, int D, int N) {
+    ScanGeom g = make_geom(B, H, W, D, N, 1);
+    return 2 * (int64_t)B * 4 * g.nch * N * D;
+}
+
+extern "C" int fd_selective_scan(int dtype, const void *xc, const float *xdbl, const float *dtw,
+                                 const float *dtb, const float *A, const float *Ds, void *y, float *ws,
+                                 int B, int H, int W, int D, int N, int R, void *stream) {
+    FD_REQUIRE(xc && xdbl && dtw && dtb && A && Ds && y && ws, "fd_selective_scan: null pointer");
+    FD_REQUIRE(H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "fd_selective_scan: H,W must be even (got %d,%d)", H, W);
+    FD_REQUIRE(D % 64 == 0, "fd_selective_scan: d_inner=%d must be a multiple of 64", D);
+    ScanGeom g = make_geom(B, H, W, D, N, R);
+    int rc = dtype == FD_BF16
+                 ? dispatch_n<bf16>((const bf16 *)xc, xdbl, dtw, dtb, A, Ds, (bf16 *)y, ws, g, (hipStream_t)stream)
+                 : dispatch_n<float>((const float *)xc, xdbl, dtw, dtb, A, Ds, (float *)y, ws, g, (hipStream_t)stream);
+    FD_REQUIRE(rc == 0, "fd_selective_scan: unsupported d_state=%d / dt_rank=%d (need N in {4,8,16,32}, R in {2,4,8,16,32})", N, R);
+    FD_LAUNCH_OK("fd_selective_scan");
+    return FD_OK;
+}

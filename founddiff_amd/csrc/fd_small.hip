@@ -1,0 +1,237 @@
+// fd_small.hip -- fp32 conditioning path (time MLP, adaLN vectors, prompt path, DA-CLIP heads),
+// scheduler math on fp32 images, and the library's error state.
+#include <stdarg.h>
+#include <stdio.h>
+#include "fd_common.h"
+
+static thread_local char g_err[512] = "";
+
+void fd_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *fd_last_error(void) { return g_err; }
+extern "C" int fd_version(void) { return 100; }
+
+namespace {
+
+__device__ __forceinline__ float act_fn(float v, int act) {
+    if (act == 1) return fd_silu(v);
+    if (act == 2) return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));   // nn.GELU() (erf form)
+    if (act == 3) return fmaxf(v, 0.f);
+    return v;
+}
+
+// one wave per output feature n, up to 8 rows of x at a time
+__global__ __launch_bounds__(256) void linear_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                    const float *__restrict__ bias, float *__restrict__ out, int M,
+                                                    int N, int K, int act, int pre_silu) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const float *wr = w + (int64_t)n * K;
+    for (int m0 = 0; m0 < M; m0 += 8) {
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int k = lane; k < K; k += 64) {
+            const float wv = wr[k];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (m0 + i < M) {
+                    float xv = x[(int64_t)(m0 + i) * K + k];
+                    if (pre_silu) xv = fd_silu(xv);
+                    acc[i] += wv * xv;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float s = wave_sum(acc[i]);
+            if (lane == 0 && m0 + i < M) out[(int64_t)(m0 + i) * N + n] = act_fn(s + (bias ? bias[n] : 0.f), act);
+        }
+    }
+}
+
+__global__ void sinusoidal_kernel(const float *__restrict__ time, float *__restrict__ out, int B, int dim) {
+    const int half = dim / 2;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * half) return;
+    const int b = i / half, j = i % half;
+    const float e = logf(10000.f) / (float)(half - 1);
+    const float f = expf((float)j * -e);
+    const float a = time[b] * f;
+    out[b * dim + j] = sinf(a);
+    out[b * dim + half + j] = cosf(a);
+}
+
+__global__ __launch_bounds__(256) void softmax_mul_kernel(const float *__restrict__ x, const float *__restrict__ p,
+                                                         float *__restrict__ out, int N) {
+    __shared__ float red[4];
+    const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float mx = -3.4e38f;
+    for (int n = tid; n < N; n += 256) mx = fmaxf(mx, x[(int64_t)m * N + n]);
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float den = 0.f;
+    for (int n = tid; n < N; n += 256) den += expf(x[(int64_t)m * N + n] - mx);
+    den = wave_sum(den);
+    if (lane == 0) red[wave] = den;
+    __syncthreads();
+    den = red[0] + red[1] + red[2] + red[3];
+    for (int n = tid; n < N; n += 256) out[(int64_t)m * N + n] = expf(x[(int64_t)m * N + n] - mx) / den * p[n];
+}
+
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(const float *__restrict__ x, float *__restrict__ out, int N,
+                                                         float eps) {
+    __shared__ float red[4];
+    const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float s = 0.f;
+    for (int n = tid; n < N; n += 256) { float v = x[(int64_t)m * N + n]; s += v * v; }
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const float nrm = fmaxf(sqrtf(red[0] + red[1] + red[2] + red[3]), eps);
+    for (int n = tid; n < N; n += 256) out[(int64_t)m * N + n] = x[(int64_t)m * N + n] / nrm;
+}
+
+__global__ void add_kernel(const float *a, const float *b, float *out, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = a[i] + b[i];
+}
+__global__ void affine_kernel(const float *x, float a, float b, float *out, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = x[i] * a + b;
+}
+__global__ void axpy_kernel(const float *x, const float *nz, float s, float *out, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = x[i] + s * nz[i];
+}
+
+__device__ __forceinline__ float clamp1(float v) { return fminf(fmaxf(v, -1.f), 1.f); }
+
+__global__ void res_predictions_kernel(const float *__restrict__ mo, const float *__restrict__ xt,
+                                       const float *__restrict__ xin, const float *__restrict__ ac,
+                                       const float *__restrict__ bc, float *pred_res, float *pred_noise,
+                                       float *x_start, int64_t npix) {
+    const int b = blockIdx.y;
+    const float a = ac[b], bb = bc[b];
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t j = (int64_t)b * npix + i;
+        const float pr = clamp1(mo[j]);
+        if (pred_res) pred_res[j] = pr;
+        if (pred_noise) pred_noise[j] = (xt[j] - xin[j] - (a - 1.f) * pr) / bb;
+        if (x_start) x_start[j] = clamp1(xin[j] - pr);
+    }
+}
+
+__global__ void res_ddim_kernel(const float *__restrict__ mo, const float *__restrict__ img,
+                                const float *__restrict__ xin, const float *__restrict__ noise, float alpha,
+                                float sigma, int last, float *__restrict__ out, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float pr = clamp1(mo[i]);
+        float v;
+        if (last) v = clamp1(xin[i] - pr);
+        else {
+            v = img[i] - alpha * pr;
+            if (noise) v += sigma * noise[i];
+        }
+        out[i] = v;
+    }
+}
+
+__global__ void res_posterior_kernel(const float *__restrict__ mo, const float *__restrict__ xt,
+                                     const float *__restrict__ xin, const float *__restrict__ noise,
+                                     const float *__restrict__ coef, float *__restrict__ out,
+                                     float *__restrict__ xs_out, int64_t npix) {
+    const int b = blockIdx.y;
+    const float c1 = coef[b * 4], c2 = coef[b * 4 + 1], c3 = coef[b * 4 + 2];
+    const float sd = expf(0.5f * coef[b * 4 + 3]);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t j = (int64_t)b * npix + i;
+        const float pr = clamp1(mo[j]);
+        const float xs = clamp1(xin[j] - pr);
+        float v = c1 * xt[j] + c2 * pr + c3 * xs;
+        if (noise) v += sd * noise[j];
+        out[j] = v;
+        if (xs_out) xs_out[j] = xs;
+    }
+}
+
+unsigned g1(int64_t n) {
+    int64_t g = (n + 255) / 256;
+    return (unsigned)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+extern "C" int fd_linear(const float *x, const float *w, const float *b, float *out, int M, int N, int K, int act,
+                         int pre_silu, void *stream) {
+    FD_REQUIRE(x && w && out && M > 0 && N > 0 && K > 0, "fd_linear: bad args");
+    hipLaunchKernelGGL(linear_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, w, b, out, M, N, K, act, pre_silu);
+    FD_LAUNCH_OK("fd_linear");
+    return FD_OK;
+}
+extern "C" int fd_sinusoidal(const float *time, float *out, int B, int dim, void *stream) {
+    FD_REQUIRE(time && out && dim >= 4 && dim % 2 == 0, "fd_sinusoidal: bad args");
+    hipLaunchKernelGGL(sinusoidal_kernel, dim3((B * dim / 2 + 255) / 256), dim3(256), 0, (hipStream_t)stream, time, out, B, dim);
+    FD_LAUNCH_OK("fd_sinusoidal");
+    return FD_OK;
+}
+extern "C" int fd_softmax_mul(const float *x, const float *p, float *out, int M, int N, void *stream) {
+    FD_REQUIRE(x && p && out, "fd_softmax_mul: null pointer");
+    hipLaunchKernelGGL(softmax_mul_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, x, p, out, N);
+    FD_LAUNCH_OK("fd_softmax_mul");
+    return FD_OK;
+}
+extern "C" int fd_l2norm_rows(const float *x, float *out, int M, int N, float eps, void *stream) {
+    FD_REQUIRE(x && out, "fd_l2norm_rows: null pointer");
+    hipLaunchKernelGGL(l2norm_rows_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, x, out, N, eps);
+    FD_LAUNCH_OK("fd_l2norm_rows");
+    return FD_OK;
+}
+extern "C" int fd_add_f32(const float *a, const float *b, float *out, int64_t n, void *stream) {
+    hipLaunchKernelGGL(add_kernel, dim3(g1(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+    FD_LAUNCH_OK("fd_add_f32");
+    return FD_OK;
+}
+extern "C" int fd_affine_f32(const float *x, float a, float b, float *out, int64_t n, void *stream) {
+    hipLaunchKernelGGL(affine_kernel, dim3(g1(n)), dim3(256), 0, (hipStream_t)stream, x, a, b, out, n);
+    FD_LAUNCH_OK("fd_affine_f32");
+    return FD_OK;
+}
+extern "C" int fd_axpy_f32(const float *x, const float *noise, float s, float *out, int64_t n, void *stream) {
+    hipLaunchKernelGGL(axpy_kernel, dim3(g1(n)), dim3(256), 0, (hipStream_t)stream, x, noise, s, out, n);
+    FD_LAUNCH_OK("fd_axpy_f32");
+    return FD_OK;
+}
+extern "C" int fd_res_predictions(const float *model_out, const float *x_t, const float *x_in, const float *ac,
+                                  const float *bc, float *pred_res, float *pred_noise, float *x_start, int B,
+                                  int64_t npix, void *stream) {
+    FD_REQUIRE(model_out && x_t && x_in && ac && bc, "fd_res_predictions: null pointer");
+    hipLaunchKernelGGL(res_predictions_kernel, dim3(g1(npix), B), dim3(256), 0, (hipStream_t)stream, model_out, x_t,
+                       x_in, ac, bc, pred_res, pred_noise, x_start, npix);
+    FD_LAUNCH_OK("fd_res_predictions");
+    return FD_OK;
+}
+extern "C" int fd_res_ddim_step(const float *model_out, const float *img, const float *x_in, const float *noise,
+                                float alpha, float sigma, int last, float *img_out, int64_t n, void *stream) {
+    FD_REQUIRE(model_out && img && x_in && img_out, "fd_res_ddim_step: null pointer");
+    hipLaunchKernelGGL(res_ddim_kernel, dim3(g1(n)), dim3(256), 0, (hipStream_t)stream, model_out, img, x_in, noise,
+                       alpha, sigma, last, img_out, n);
+    FD_LAUNCH_OK("fd_res_ddim_step");
+    return FD_OK;
+}
+extern "C" int fd_res_posterior_step(const float *model_out, const float *x_t, const float *x_in, const float *noise,
+                                     const float *coef, float *img_out, float *x_start_out, int B, int64_t npix,
+                                     void *stream) {
+    FD_REQUIRE(model_out && x_t && x_in && coef && img_out, "fd_res_posterior_step: null pointer");
+    hipLaunchKernelGGL(res_posterior_kernel, dim3(g1(npix), B), dim3(256), 0, (hipStream_t)stream, model_out, x_t, x_in,
+                       noise, coef, img_out, x_start_out, npix);
+    FD_LAUNCH_OK("fd_res_posterior_step");
+    return FD_OK;
+}

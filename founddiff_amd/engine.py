@@ -1,0 +1,491 @@
+"""Host side of the MI355X denoiser: weight packing, workspace planning and the launch
+sequence of one `Unet.forward` (src/DADiff.py:685-740 of the reference) over the C ABI in
+include/founddiff_hip.h.  PyTorch is used for device memory, streams and graph capture only;
+every FLOP of the forward runs in libfounddiff_hip.so.
+
+Layout: activations NHWC; `mode` 'fp32' (parity: fp32 storage, exact-f32 MFMA) or 'bf16'
+(bf16 storage + bf16 MFMA, fp32 accumulation/statistics/scan state).
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib as L
+
+_T = {"fp32": (L.FD_F32, torch.float32), "bf16": (L.FD_BF16, torch.bfloat16)}
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _po(t, off_elems):
+    """pointer to element offset inside tensor t"""
+    return C.c_void_p(t.data_ptr() + off_elems * t.element_size())
+
+
+class ConvW:
+    """Packed convolution / linear weight: [Cout][KH*KW*Cin] in the compute dtype, fp32 bias."""
+
+    def __init__(self, w_oihw, bias, dev, tdt, cin_pad=None):
+        w = w_oihw.detach().float()
+        if w.dim() == 2:
+            w = w[:, :, None, None]
+        o, i, kh, kw = w.shape
+        if cin_pad is not None and cin_pad > i:
+            w = torch.cat([w, w.new_zeros(o, cin_pad - i, kh, kw)], dim=1)
+            i = cin_pad
+        self.Cout, self.Cin, self.KH, self.KW = o, i, kh, kw
+        self.w = w.permute(0, 2, 3, 1).reshape(o, kh * kw * i).contiguous().to(dev, tdt)
+        self.b = bias.detach().float().contiguous().to(dev) if bias is not None else None
+
+
+def ws_standardize(w, eps=1e-5):
+    """Weight standardisation folded at pack time (src/DADiff.py:145-152, fp32 eps)."""
+    w = w.detach().float()
+    mean = w.mean(dim=(1, 2, 3), keepdim=True)
+    var = w.var(dim=(1, 2, 3), unbiased=False, keepdim=True)
+    return (w - mean) * torch.rsqrt(var + eps)
+
+
+def fold_bn(w, bn_w, bn_b, mean, var, eps=1e-5):
+    s = bn_w.float() / torch.sqrt(var.float() + eps)
+    return w.float() * s[:, None, None, None], bn_b.float() - mean.float() * s
+
+
+class _Sub:
+    def __init__(self, sd, prefix):
+        self.sd, self.prefix = sd, prefix
+
+    def __getitem__(self, k):
+        return self.sd[self.prefix + k]
+
+    def has(self, k):
+        return (self.prefix + k) in self.sd
+
+    def sub(self, p):
+        return _Sub(self.sd, self.prefix + p)
+
+
+class DAEngine:
+    """DA-conditioned U-Net denoiser (reference `Unet`, src/DADiff.py:530-740) on HIP kernels."""
+
+    def __init__(self, state_dict, prefix="", device="cuda", mode="bf16"):
+        L.lib()  # fail loudly if the HIP library is missing
+        if mode not in _T:
+            raise ValueError(f"mode must be 'fp32' or 'bf16', got {mode!r}")
+        self.mode = mode
+        self.dt, self.tdt = _T[mode]
+        self.dev = torch.device(device)
+        self.f32 = dict(device=self.dev, dtype=torch.float32)
+        sd = _Sub(state_dict, prefix)
+        self._pack(sd)
+        self._plan_key = None
+        self.buf = {}
+
+    # ------------------------------------------------------------------ packing
+    def _f(self, t):
+        return t.detach().float().contiguous().to(self.dev)
+
+    def _convw(self, w, b=None, cin_pad=None):
+        return ConvW(w, b, self.dev, self.tdt, cin_pad)
+
+    def _pack_res(self, s):
+        r = {"conv": self._convw(ws_standardize(s["block1.proj.weight"]), s["block1.proj.bias"]),
+             "gamma": self._f(s["block1.norm.weight"]), "beta": self._f(s["block1.norm.bias"]),
+             "res": None}
+        if s.has("res_conv.weight"):
+            r["res"] = self._convw(s["res_conv.weight"], s["res_conv.bias"])
+        return r
+
+    def _pack_mamba(self, s):
+        m = s.sub("mamba.")
+        C_ = s["norm1.weight"].shape[0]
+        xw = m["x_proj_weight"]            # (4, R+2N, 2C)
+        dtw = m["dt_projs_weight"]         # (4, 2C, R)
+        N = m["A_logs"].shape[1]
+        R = dtw.shape[2]
+        D = dtw.shape[1]
+        a = s.sub("attn_blk.")
+        d = dict(
+            C=C_, N=N, R=R, D=D, CD=R + 2 * N, heads=a["temperature"].shape[0],
+            n1w=self._f(s["norm1.weight"]), n1b=self._f(s["norm1.bias"]),
+            in_proj=self._convw(m["in_proj.weight"]),
+            dw_w=self._f(m["conv2d.weight"].reshape(D, 9).t()), dw_b=self._f(m["conv2d.bias"]),
+            x_proj=xw.detach().float().contiguous().to(self.dev, self.tdt),
+            dtw=self._f(dtw), dtb=self._f(m["dt_projs_bias"]),
+            A=self._f(-torch.exp(m["A_logs"].detach().float())), Ds=self._f(m["Ds"]),
+            onw=self._f(m["out_norm.weight"]), onb=self._f(m["out_norm.bias"]),
+            out_proj=self._convw(m["out_proj.weight"]),
+            qkv=self._convw(a["qkv.weight"]),
+            qdw_w=self._f(a["qkv_dwconv.weight"].reshape(3 * C_, 9).t()),
+            temp=self._f(a["temperature"].reshape(-1)),
+            wproj=self._f(a["project_out.weight"].reshape(C_, C_)),
+        )
+        assert d["heads"] * 32 == C_, "TransposedAttention heads must be C/32 (src/DADiff.py:468)"
+        d["adaln_w"] = s["adaLN_modulation.1.weight"].detach().float()
+        d["adaln_b"] = s["adaLN_modulation.1.bias"].detach().float()
+        d["local_w"] = m["attn.0.weight"].detach().float()
+        return d
+
+    def _pack(self, sd):
+        self.dim = sd["init_conv.weight"].shape[0]
+        self.time_dim = sd["time_mlp.1.weight"].shape[0]
+        self.init_conv = self._convw(sd["init_conv.weight"], sd["init_conv.bias"], cin_pad=8)
+        self.tm = dict(w1=self._f(sd["time_mlp.1.weight"]), b1=self._f(sd["time_mlp.1.bias"]),
+                       w2=self._f(sd["time_mlp.3.weight"]), b2=self._f(sd["time_mlp.3.bias"]))
+        self.prompt = dict(
+            w0=self._f(sd["text_mlp.0.weight"]), b0=self._f(sd["text_mlp.0.bias"]),
+            w2=self._f(sd["text_mlp.2.weight"]), b2=self._f(sd["text_mlp.2.bias"]),
+            p=self._f(sd["prompt"].reshape(-1)),
+            wp=self._f(sd["prompt_mlp.weight"]), bp=self._f(sd["prompt_mlp.bias"]))
+        self.downs, self.ups = [], []
+        i = 0
+        while sd.has(f"downs.{i}.0.block1.proj.weight"):
+            s = sd.sub(f"downs.{i}.")
+            w = s["2.weight"]
+            self.downs.append(dict(res=self._pack_res(s.sub("0.")), mamba=self._pack_mamba(s.sub("1.")),
+                                   samp=self._convw(w, s["2.bias"]), stride=2 if w.shape[-1] == 4 else 1))
+            i += 1
+        self.mid_res = self._pack_res(sd.sub("mid_block."))
+        self.mid_mamba = self._pack_mamba(sd.sub("mid_attn."))
+        i = 0
+        while sd.has(f"ups.{i}.0.block1.proj.weight"):
+            s = sd.sub(f"ups.{i}.")
+            up = s.has("2.1.weight")
+            w, b = (s["2.1.weight"], s["2.1.bias"]) if up else (s["2.weight"], s["2.bias"])
+            self.ups.append(dict(res=self._pack_res(s.sub("0.")), mamba=self._pack_mamba(s.sub("1.")),
+                                 samp=self._convw(w, b), up=up))
+            i += 1
+        self.final_res = self._pack_res(sd.sub("final_res_block."))
+        fw = sd["final_conv.weight"]
+        if fw.shape[0] != 1:
+            raise NotImplementedError("final_conv with out_dim != 1 (learned_variance) is not built")
+        self.final_w, self.final_b = self._f(fw.reshape(-1)), self._f(sd["final_conv.bias"])
+        # all adaLN / local projections concatenated: ONE matvec per step / per slice
+        mambas = [d["mamba"] for d in self.downs] + [self.mid_mamba] + [u["mamba"] for u in self.ups]
+        off_m = off_l = 0
+        for m in mambas:
+            m["mod_off"], m["loc_off"] = off_m, off_l
+            off_m += 6 * m["C"]
+            off_l += m["D"]
+        self.mod_total, self.loc_total = off_m, off_l
+        self.adaln_w = torch.cat([m.pop("adaln_w") for m in mambas]).contiguous().to(self.dev)
+        self.adaln_b = torch.cat([m.pop("adaln_b") for m in mambas]).contiguous().to(self.dev)
+        self.local_w = torch.cat([m.pop("local_w") for m in mambas]).contiguous().to(self.dev)
+        self.mambas = mambas
+        self._pack_clip(sd.sub("dose_encoder."))
+
+    def _pack_clip(self, sd):
+        v = sd.sub("clip_model.visual.")
+
+        def cbn(cw, bn, cin_pad=None, sum_in=False):
+            w = v[cw + ".weight"].detach().float()
+            if sum_in:   # 3 identical input channels (x.repeat(1,3,1,1), src/DADiff.py:692) -> 1
+                w = w.sum(dim=1, keepdim=True)
+            w, b = fold_bn(w, v[bn + ".weight"], v[bn + ".bias"], v[bn + ".running_mean"], v[bn + ".running_var"])
+            return self._convw(w, b, cin_pad)
+        stem = [cbn("conv1", "bn1", cin_pad=8, sum_in=True), cbn("conv2", "bn2"), cbn("conv3", "bn3")]
+        layers = []
+        for li in range(1, 5):
+            bi = 0
+            while v.has(f"layer{li}.{bi}.conv1.weight"):
+                p = f"layer{li}.{bi}."
+                blk = dict(c1=cbn(p + "conv1", p + "bn1"), c2=cbn(p + "conv2", p + "bn2"),
+                           c3=cbn(p + "conv3", p + "bn3"), stride=2 if (li > 1 and bi == 0) else 1, ds=None)
+                if v.has(p + "downsample.0.weight"):
+                    blk["ds"] = cbn(p + "downsample.0", p + "downsample.1")
+                layers.append(blk)
+                bi += 1
+        ap = v.sub("attnpool.")
+        Cf = ap["q_proj.weight"].shape[0]
+        qkv_w = torch.cat([ap["q_proj.weight"], ap["k_proj.weight"], ap["v_proj.weight"]]).detach().float()
+        qkv_b = torch.cat([ap["q_proj.bias"], ap["k_proj.bias"], ap["v_proj.bias"]]).detach().float()
+        self.clip = dict(
+            stem=stem, layers=layers, Cf=Cf, heads=Cf // 64,
+            qkv=self._convw(qkv_w, qkv_b),
+            cw=self._f(ap["c_proj.weight"]), cb=self._f(ap["c_proj.bias"]),
+            h1=[self._f(sd[k]) for k in ("head1.0.weight", "head1.0.bias", "head1.2.weight", "head1.2.bias")],
+            h2=[self._f(sd[k]) for k in ("head2.0.weight", "head2.0.bias", "head2.2.weight", "head2.2.bias")])
+
+    # ------------------------------------------------------------------ buffers
+    def _b(self, name, shape, dtype=None):
+        """named, shape-keyed workspace tensor (same role + shape => same memory)"""
+        dtype = dtype or self.tdt
+        key = (name, tuple(shape), dtype)
+        t = self.buf.get(key)
+        if t is None:
+            t = torch.empty(shape, device=self.dev, dtype=dtype)
+            self.buf[key] = t
+        return t
+
+    @property
+    def stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+
+    # ------------------------------------------------------------------ op wrappers
+    def conv(self, cw, in0, B, H, W, out, *, c0=None, ld0=None, off0=0, in1=None, c1=0, ld1=0, off1=0,
+             stride=1, pad=None, upsample=False, ndir=1, w_batch_stride=0, w_dir_stride=0, weight=None,
+             bias="auto", Cout=None, KH=None, KW=None, ldo=None, offo=0, out_dir_stride=0, out_f32=False,
+             epi=L.EPI_NONE, split=0, res=None, ld_res=0, off_res=0, gate=None, gate_ld=0, h=None,
+             gn=None, gamma=None, beta=None, groups=8, stats=None, OH=None, OW=None):
+        p = L.ConvParams()
+        KH = KH or cw.KH
+        KW = KW or cw.KW
+        Cout = Cout or cw.Cout
+        c0 = c0 if c0 is not None else (cw.Cin - c1)
+        p.dtype, p.out_f32 = self.dt, int(out_f32)
+        p.in0, p.in1 = in0.data_ptr(), (in1.data_ptr() if in1 is not None else None)
+        p.c0, p.ld0, p.off0 = c0, (ld0 if ld0 is not None else c0), off0
+        p.c1, p.ld1, p.off1 = c1, (ld1 or c1), off1
+        p.B, p.H, p.W, p.upsample = B, H, W, int(upsample)
+        if pad is None:
+            pad = (KH - 1) // 2
+        p.KH, p.KW, p.stride, p.pad_h, p.pad_w = KH, KW, stride, pad, pad
+        Hs, Ws = (2 * H, 2 * W) if upsample else (H, W)
+        p.OH = OH if OH is not None else (Hs + 2 * pad - KH) // stride + 1
+        p.OW = OW if OW is not None else (Ws + 2 * pad - KW) // stride + 1
+        p.ndir = ndir
+        wt = weight if weight is not None else cw.w
+        p.weight, p.w_batch_stride, p.w_dir_stride = wt.data_ptr(), w_batch_stride, w_dir_stride
+        bt = (cw.b if cw is not None else None) if isinstance(bias, str) else bias
+        p.bias = bt.data_ptr() if bt is not None else None
+        p.Cout = Cout
+        p.out, p.ldo, p.offo, p.out_dir_stride = out.data_ptr(), (ldo or Cout), offo, out_dir_stride
+        p.epilogue, p.epi_split = epi, split
+        p.res = res.data_ptr() if res is not None else None
+        p.ld_res, p.off_res = (ld_res or Cout), off_res
+        p.gate = gate.value if isinstance(gate, C.c_void_p) else (gate.data_ptr() if gate is not None else None)
+        p.gate_ld = gate_ld
+        p.h = h.data_ptr() if h is not None else None
+        p.gn_mean_rstd = gn.data_ptr() if gn is not None else None
+        p.gn_gamma = gamma.data_ptr() if gamma is not None else None
+        p.gn_beta = beta.data_ptr() if beta is not None else None
+        p.gn_groups = groups
+        p.stats_partial = stats.data_ptr() if stats is not None else None
+        L.call("fd_conv2d", C.byref(p), self.stream)
+        return p.OH, p.OW
+
+    def linear(self, x, w, b, out, act=L.ACT_NONE, pre_silu=False):
+        M, K = x.shape
+        N = w.shape[0]
+        L.call("fd_linear", _p(x), _p(w), _p(b), _p(out), M, N, K, act, int(pre_silu), self.stream)
+        return out
+
+    # ------------------------------------------------------------------ blocks
+    def res_block(self, r, in0, c0, in1, c1, B, H, W, tag):
+        """DADiff ResnetBlock: conv3x3(WS)+GN+SiLU, + res_conv(x) or x (src/DADiff.py:397-430)."""
+        cw = r["conv"]
+        Co = cw.Cout
+        hw = H * W
+        mt = L.lib().fd_conv_mtiles(H, W)
+        hraw = self._b("res_h", (B, H, W, Co))
+        part = self._b("gn_part", (B, mt, Co, 2), torch.float32)
+        mr = self._b("gn_mr", (B, 8, 2), torch.float32)
+        self.conv(cw, in0, B, H, W, hraw, c0=c0, in1=in1, c1=c1, stats=part)
+        L.call("fd_gn_finalize", _p(part), B, mt, Co, 8, hw, 1e-5, _p(mr), self.stream)
+        out = self._b(tag, (B, H, W, Co))
+        if r["res"] is not None:
+            self.conv(r["res"], in0, B, H, W, out, c0=c0, in1=in1, c1=c1, epi=L.EPI_GNSILU_ADD, h=hraw, gn=mr,
+                      gamma=r["gamma"], beta=r["beta"], groups=8)
+        else:
+            assert in1 is None
+            L.call("fd_gn_silu_apply", self.dt, _p(hraw), _p(mr), _p(r["gamma"]), _p(r["beta"]), _p(in0), _p(out),
+                   B, hw, Co, 8, self.stream)
+        return out
+
+    def mamba_block(self, m, x, B, H, W, tag):
+        """adaLN-gated SS2D + channel attention (src/DADiff.py:477-488)."""
+        Cc, D, N, R, CD = m["C"], m["D"], m["N"], m["R"], m["CD"]
+        hw = H * W
+        s = self.stream
+        mod = self.mod_all
+        ml = self.mod_total
+        mo = m["mod_off"]
+        f4 = 4  # bytes per float
+        mp = lambda k: C.c_void_p(mod.data_ptr() + (mo + k * Cc) * f4)
+        # --- SS2D branch
+        xm = self._b("xm", (B, H, W, Cc))
+        L.call("fd_ln_modulate", self.dt, _p(x), _p(m["n1w"]), _p(m["n1b"]), 1e-5, mp(0), mp(1), ml, _p(xm),
+               B, hw, Cc, s)
+        xz = self._b("xz", (B, H, W, 2 * D))
+        self.conv(m["in_proj"], xm, B, H, W, xz, epi=L.EPI_SILU_SPLIT, split=D)
+        xc = self._b("xc", (B, H, W, D))
+        L.call("fd_dwconv3x3", self.dt, _p(xz), 2 * D, 0, _p(m["dw_w"]), _p(m["dw_b"]), 1, _p(xc), D, 0,
+               B, H, W, D, s)
+        Lq = (H // 2) * (W // 2)
+        xdbl = self._b("xdbl", (4, B, Lq, CD), torch.float32)
+        self.conv(None, xc, B, H, W, xdbl, c0=D, weight=m["x_proj"], bias=None, Cout=CD, KH=1, KW=1, stride=2,
+                  pad=0, ndir=4, w_dir_stride=CD * D, out_dir_stride=B * Lq * CD, out_f32=True,
+                  OH=H // 2, OW=W // 2)
+        nws = L.lib().fd_scan_ws_floats(B, H, W, D, N)
+        ws = self._b("scan_ws", (nws,), torch.float32)
+        y = self._b("scan_y", (B, H, W, D))
+        L.call("fd_selective_scan", self.dt, _p(xc), _p(xdbl), _p(m["dtw"]), _p(m["dtb"]), _p(m["A"]),
+               _p(m["Ds"]), _p(y), _p(ws), B, H, W, D, N, R, s)
+        yz = self._b("yz", (B, H, W, D))
+        loc = C.c_void_p(self.local_all.data_ptr() + m["loc_off"] * f4)
+        L.call("fd_ln_gate", self.dt, _p(y), _p(m["onw"]), _p(m["onb"]), 1e-5, _p(xz), 2 * D, D, loc,
+               self.loc_total, _p(yz), B, hw, D, s)
+        x1 = self._b(tag + ".x1", (B, H, W, Cc))
+        self.conv(m["out_proj"], yz, B, H, W, x1, epi=L.EPI_GATE_RES, res=x, gate=mp(2), gate_ld=ml)
+        # --- channel attention branch
+        xm2 = self._b("xm", (B, H, W, Cc))
+        L.call("fd_ln_modulate", self.dt, _p(x1), None, None, 1e-6, mp(3), mp(4), ml, _p(xm2), B, hw, Cc, s)
+        qkv = self._b("qkv", (B, H, W, 3 * Cc))
+        self.conv(m["qkv"], xm2, B, H, W, qkv)
+        qkv2 = self._b("qkv2", (B, H, W, 3 * Cc))
+        L.call("fd_dwconv3x3", self.dt, _p(qkv), 3 * Cc, 0, _p(m["qdw_w"]), None, 0, _p(qkv2), 3 * Cc, 0,
+               B, H, W, 3 * Cc, s)
+        nblk = L.lib().fd_chan_attn_nblk(hw)
+        part = self._b("gram", (B, m["heads"], nblk, 1024 + 64), torch.float32)
+        L.call("fd_chan_attn_gram", self.dt, _p(qkv2), B, hw, Cc, _p(part), s)
+        weff = self._b("weff", (B, Cc, Cc))
+        L.call("fd_chan_attn_weff", self.dt, _p(part), nblk, _p(m["temp"]), _p(m["wproj"]), _p(weff), B, Cc, s)
+        x2 = self._b(tag + ".x2", (B, H, W, Cc))
+        self.conv(None, qkv2, B, H, W, x2, c0=Cc, ld0=3 * Cc, off0=2 * Cc, weight=weff, w_batch_stride=Cc * Cc,
+                  bias=None, Cout=Cc, KH=1, KW=1, epi=L.EPI_GATE_RES, res=x1, gate=mp(5), gate_ld=ml)
+        return x2
+
+    # ------------------------------------------------------------------ conditioning (once per slice)
+    def encode_condition(self, x_cond):
+        """DA-CLIP encoder + prompt path + per-block `local` vectors; t-independent,
+        so it runs once per slice instead of once per step.  x_cond (B,1,H,W) fp32 in [-1,1]."""
+        B, _, H, W = x_cond.shape
+        s = self.stream
+        cl = self.clip
+        x8 = self._b("clip_in", (B, H, W, 8))
+        L.call("fd_pack_planes", self.dt, _p(x_cond), None, _p(x8), B, H * W, 8, s)
+        st = cl["stem"]
+        h1, w1 = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+        a = self._b("clip_s1", (B, h1, w1, st[0].Cout))
+        self.conv(st[0], x8, B, H, W, a, stride=2, epi=L.EPI_RELU)
+        b_ = self._b("clip_s2", (B, h1, w1, st[1].Cout))
+        self.conv(st[1], a, B, h1, w1, b_, epi=L.EPI_RELU)
+        c_ = self._b("clip_s3", (B, h1, w1, st[2].Cout))
+        self.conv(st[2], b_, B, h1, w1, c_, epi=L.EPI_RELU)
+        h, w = h1 // 2, w1 // 2
+        x = self._b("clip_p0", (B, h, w, st[2].Cout))
+        L.call("fd_avgpool", self.dt, _p(c_), _p(x), B, h1, w1, st[2].Cout, 2, s)
+        Cx = st[2].Cout
+        for i, blk in enumerate(cl["layers"]):
+            stride = blk["stride"]
+            o1 = self._b(f"clip_{i}_1", (B, h, w, blk["c1"].Cout))
+            self.conv(blk["c1"], x, B, h, w, o1, epi=L.EPI_RELU)
+            o2 = self._b(f"clip_{i}_2", (B, h, w, blk["c2"].Cout))
+            self.conv(blk["c2"], o1, B, h, w, o2, epi=L.EPI_RELU)
+            ho, wo = h // stride, w // stride
+            if stride > 1:
+                o2p = self._b(f"clip_{i}_2p", (B, ho, wo, blk["c2"].Cout))
+                L.call("fd_avgpool", self.dt, _p(o2), _p(o2p), B, h, w, blk["c2"].Cout, stride, s)
+                o2 = o2p
+            idn = x
+            if blk["ds"] is not None:
+                xi = x
+                if stride > 1:
+                    xi = self._b(f"clip_{i}_xp", (B, ho, wo, Cx))
+                    L.call("fd_avgpool", self.dt, _p(x), _p(xi), B, h, w, Cx, stride, s)
+                idn = self._b(f"clip_{i}_id", (B, ho, wo, blk["ds"].Cout))
+                self.conv(blk["ds"], xi, B, ho, wo, idn)
+            o3 = self._b(f"clip_{i}_3", (B, ho, wo, blk["c3"].Cout))
+            self.conv(blk["c3"], o2, B, ho, wo, o3, epi=L.EPI_RES_RELU, res=idn)
+            x, Cx, h, w = o3, blk["c3"].Cout, ho, wo
+        Cf, T = cl["Cf"], h * w + 1
+        tok = self._b("clip_tok", (B, T, Cf))
+        L.call("fd_attnpool_tokens", self.dt, _p(x), _p(tok), B, h * w, Cf, s)
+        qkv = self._b("clip_qkv", (B, T, 3 * Cf), torch.float32)
+        self.conv(cl["qkv"], tok, B, 1, T, qkv, out_f32=True)
+        pooled = self._b("clip_pool", (B, Cf), torch.float32)
+        L.call("fd_attnpool_core", _p(qkv), T * 3 * Cf, _p(qkv), 3 * Cf, Cf, 2 * Cf, _p(pooled), B, T, Cf,
+               cl["heads"], s)
+        feat = self.linear(pooled, cl["cw"], cl["cb"], self._b("clip_feat", (B, cl["cw"].shape[0]), torch.float32))
+        t1 = self.linear(feat, cl["h1"][0], cl["h1"][1], self._b("h1a", (B, cl["h1"][0].shape[0]), torch.float32), L.ACT_RELU)
+        t2 = self.linear(t1, cl["h1"][2], cl["h1"][3], self._b("h1b", (B, cl["h1"][2].shape[0]), torch.float32))
+        dose = self._b("dose_emb", t2.shape, torch.float32)
+        L.call("fd_l2norm_rows", _p(t2), _p(dose), B, t2.shape[1], 0.0, s)
+        t1 = self.linear(feat, cl["h2"][0], cl["h2"][1], self._b("h2a", (B, cl["h2"][0].shape[0]), torch.float32), L.ACT_RELU)
+        t2 = self.linear(t1, cl["h2"][2], cl["h2"][3], self._b("h2b", (B, cl["h2"][2].shape[0]), torch.float32))
+        ctx = self._b("ctx_emb", t2.shape, torch.float32)
+        L.call("fd_l2norm_rows", _p(t2), _p(ctx), B, t2.shape[1], 1e-12, s)
+        # prompt path (src/DADiff.py:706-707)
+        pr = self.prompt
+        td = self.time_dim
+        a1 = self.linear(dose, pr["w0"], pr["b0"], self._b("pm_a", (B, td), torch.float32), L.ACT_SILU)
+        a2 = self.linear(a1, pr["w2"], pr["b2"], self._b("pm_b", (B, td), torch.float32))
+        a3 = self._b("pm_c", (B, td), torch.float32)
+        L.call("fd_softmax_mul", _p(a2), _p(pr["p"]), _p(a3), B, td, s)
+        self.prompt_emb = self.linear(a3, pr["wp"], pr["bp"], self._b("prompt_emb", (B, td), torch.float32))
+        # SS2D `local` vectors of every block (src/emamba2.py:715)
+        self.local_all = self.linear(ctx, self.local_w, None, self._b("local_all", (B, self.loc_total), torch.float32),
+                                     L.ACT_SILU)
+        self.dose_emb, self.ctx_emb = dose, ctx
+        return dose, ctx
+
+    # ------------------------------------------------------------------ one denoiser forward
+    def time_cond(self, time):
+        """time (B,) fp32 device -> adaLN vectors of all blocks (src/DADiff.py:703,709,484)."""
+        B = time.shape[0]
+        s = self.stream
+        emb = self._b("t_emb", (B, self.dim), torch.float32)
+        L.call("fd_sinusoidal", _p(time), _p(emb), B, self.dim, s)
+        tm = self.tm
+        h = self.linear(emb, tm["w1"], tm["b1"], self._b("t_h", (B, self.time_dim), torch.float32), L.ACT_GELU)
+        t = self.linear(h, tm["w2"], tm["b2"], self._b("t_t", (B, self.time_dim), torch.float32))
+        tt = self._b("t_sum", (B, self.time_dim), torch.float32)
+        L.call("fd_add_f32", _p(t), _p(self.prompt_emb), _p(tt), B * self.time_dim, s)
+        self.t_vec = tt
+        self.mod_all = self.linear(tt, self.adaln_w, self.adaln_b,
+                                   self._b("mod_all", (B, self.mod_total), torch.float32), pre_silu=True)
+
+    def forward(self, x_t, x_in, time, out=None):
+        """x_t, x_in: (B,1,H,W) fp32 device tensors in [-1,1]; time (B,) fp32.  Returns the raw
+        model output (B,1,H,W) fp32.  encode_condition(x_in) must have been called."""
+        B, _, H, W = x_t.shape
+        nd = len(self.downs)
+        div = 2 ** sum(1 for d in self.downs if d["stride"] == 2)
+        if H % (2 * div) or W % (2 * div):
+            raise ValueError(f"H,W must be multiples of {2 * div} (got {H}x{W})")
+        s = self.stream
+        self.time_cond(time)
+        xin8 = self._b("unet_in", (B, H, W, 8))
+        L.call("fd_pack_planes", self.dt, _p(x_t), _p(x_in), _p(xin8), B, H * W, 8, s)
+        r = self._b("r", (B, H, W, self.dim))
+        self.conv(self.init_conv, xin8, B, H, W, r)
+        x, h, w = r, H, W
+        skips = []
+        for i, d in enumerate(self.downs):
+            x = self.mamba_block(d["mamba"], x, B, h, w, f"d{i}m")
+            x = self.res_block(d["res"], x, x.shape[-1], None, 0, B, h, w, f"d{i}r")
+            skips.append((x, h, w))
+            cw = d["samp"]
+            if d["stride"] == 2:
+                o = self._b(f"d{i}s", (B, h // 2, w // 2, cw.Cout))
+                self.conv(cw, x, B, h, w, o, stride=2, pad=1)
+                h, w = h // 2, w // 2
+            else:
+                o = self._b(f"d{i}s", (B, h, w, cw.Cout))
+                self.conv(cw, x, B, h, w, o)
+            x = o
+        x = self.res_block(self.mid_res, x, x.shape[-1], None, 0, B, h, w, "midr")
+        x = self.mamba_block(self.mid_mamba, x, B, h, w, "midm")
+        for i, u in enumerate(self.ups):
+            sk, hs, ws_ = skips.pop()
+            assert (hs, ws_) == (h, w)
+            x = self.res_block(u["res"], x, x.shape[-1], sk, sk.shape[-1], B, h, w, f"u{i}r")
+            x = self.mamba_block(u["mamba"], x, B, h, w, f"u{i}m")
+            cw = u["samp"]
+            if u["up"]:
+                o = self._b(f"u{i}s", (B, 2 * h, 2 * w, cw.Cout))
+                self.conv(cw, x, B, h, w, o, upsample=True)
+                h, w = 2 * h, 2 * w
+            else:
+                o = self._b(f"u{i}s", (B, h, w, cw.Cout))
+                self.conv(cw, x, B, h, w, o)
+            x = o
+        x = self.res_block(self.final_res, x, x.shape[-1], r, r.shape[-1], B, h, w, "finr")
+        if out is None:
+            out = self._b("model_out", (B, 1, H, W), torch.float32)
+        L.call("fd_final_conv1", self.dt, _p(x), _p(self.final_w), _p(self.final_b), _p(out), B * H * W,
+               x.shape[-1], s)
+        return out

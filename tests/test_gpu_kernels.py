@@ -1,0 +1,309 @@
+"""GPU parity of the individual HIP kernels (called through the C ABI) against plain fp32
+PyTorch-CPU restatements of the same op.  fp32 mode must agree to ~1e-5 (exact-f32 MFMA);
+bf16 mode is compared with inputs pre-rounded to bf16 so only accumulation order and the
+output rounding differ."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+MODES = [("fp32", 2e-5), ("bf16", 1.2e-2)]
+
+
+@pytest.fixture(scope="module")
+def eng_factory():
+    from founddiff_amd import _lib as L
+    from founddiff_amd.engine import DAEngine
+    L.lib()
+
+    class Bare(DAEngine):
+        def __init__(self, mode):
+            from founddiff_amd.engine import _T
+            self.mode = mode
+            self.dt, self.tdt = _T[mode]
+            self.dev = torch.device("cuda")
+            self.buf = {}
+    return Bare
+
+
+def nhwc(x, tdt):
+    return x.permute(0, 2, 3, 1).contiguous().to("cuda", tdt)
+
+
+def nchw(x):
+    return x.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def rq(x, mode):
+    return x.to(torch.bfloat16).float() if mode == "bf16" else x
+
+
+@pytest.mark.parametrize("mode,tol", MODES)
+@pytest.mark.parametrize("cfg", [
+    dict(cin=64, cout=64, k=3, s=1, p=1, hw=(24, 20)),
+    dict(cin=64, cout=128, k=4, s=2, p=1, hw=(16, 24)),
+    dict(cin=8, cout=32, k=7, s=1, p=3, hw=(20, 20)),
+    dict(cin=96, cout=40, k=1, s=1, p=0, hw=(9, 13)),
+    dict(cin=128, cout=200, k=3, s=1, p=1, hw=(8, 8)),
+    dict(cin=32, cout=64, k=3, s=1, p=1, hw=(6, 10), up=True),
+])
+def test_conv(eng_factory, mode, tol, cfg):
+    from founddiff_amd.engine import ConvW
+    e = eng_factory(mode)
+    torch.manual_seed(0)
+    B = 2
+    H, W = cfg["hw"]
+    x = rq(torch.randn(B, cfg["cin"], H, W), mode)
+    w = rq(torch.randn(cfg["cout"], cfg["cin"], cfg["k"], cfg["k"]) / (cfg["cin"] * cfg["k"] ** 2) ** 0.5, mode)
+    b = torch.randn(cfg["cout"])
+    xin = F.interpolate(x, scale_factor=2, mode="nearest") if cfg.get("up") else x
+    ref = F.conv2d(xin, w, b, stride=cfg["s"], padding=cfg["p"])
+    cw = ConvW(w, b, e.dev, e.tdt)
+    out = torch.empty(B, ref.shape[2], ref.shape[3], cfg["cout"], device="cuda", dtype=e.tdt)
+    e.conv(cw, nhwc(x, e.tdt), B, H, W, out, stride=cfg["s"], pad=cfg["p"], upsample=cfg.get("up", False))
+    torch.cuda.synchronize()
+    assert rel_err(nchw(out), ref) < tol
+
+
+@pytest.mark.parametrize("mode,tol", MODES)
+def test_conv_concat_slices_epilogues(eng_factory, mode, tol):
+    from founddiff_amd import _lib as L
+    from founddiff_amd.engine import ConvW
+    e = eng_factory(mode)
+    torch.manual_seed(1)
+    B, H, W = 2, 12, 10
+    a, b2 = rq(torch.randn(B, 32, H, W), mode), rq(torch.randn(B, 16, H, W), mode)
+    w = rq(torch.randn(64, 48, 3, 3) / 20, mode)
+    bias = torch.randn(64)
+    ref = F.conv2d(torch.cat((a, b2), 1), w, bias, padding=1)
+    cw = ConvW(w, bias, e.dev, e.tdt)
+    out = torch.empty(B, H, W, 64, device="cuda", dtype=e.tdt)
+    mt = L.lib().fd_conv_mtiles(H, W)
+    part = torch.zeros(B, mt, 64, 2, device="cuda")
+    e.conv(cw, nhwc(a, e.tdt), B, H, W, out, c0=32, in1=nhwc(b2, e.tdt), c1=16, stats=part)
+    torch.cuda.synchronize()
+    assert rel_err(nchw(out), ref) < tol
+    s = part.sum(1).cpu()
+    assert rel_err(s[..., 0], ref.sum((2, 3))) < (5e-3 if mode == "bf16" else 1e-4)
+    assert rel_err(s[..., 1], (ref ** 2).sum((2, 3))) < (5e-3 if mode == "bf16" else 1e-4)
+    # silu split + strided / offset output + fp32 out
+    wide = torch.zeros(B, H, W, 96, device="cuda", dtype=torch.float32)
+    e.conv(cw, nhwc(a, e.tdt), B, H, W, wide, c0=32, in1=nhwc(b2, e.tdt), c1=16, ldo=96, offo=16, out_f32=True,
+           epi=L.EPI_SILU_SPLIT, split=32)
+    torch.cuda.synchronize()
+    r2 = ref.clone()
+    r2[:, 32:] = F.silu(r2[:, 32:])
+    assert rel_err(nchw(wide[..., 16:80]), r2) < (4e-3 if mode == "bf16" else 2e-5)
+    assert float(wide[..., :16].abs().max()) == 0 and float(wide[..., 80:].abs().max()) == 0
+    # gated residual with per-batch weights, A operand = channel slice of a wider tensor
+    big = rq(torch.randn(B, 96, H, W), mode)
+    wb = rq(torch.randn(B, 32, 32) / 6, mode)
+    res = rq(torch.randn(B, 32, H, W), mode)
+    gate = torch.randn(B, 50)
+    refg = torch.stack([F.conv2d(big[i:i + 1, 64:96], wb[i][:, :, None, None])[0] for i in range(B)])
+    refg = res + gate[:, 7:39, None, None] * refg
+    og = torch.empty(B, H, W, 32, device="cuda", dtype=e.tdt)
+    gd = gate.cuda()
+    e.conv(None, nhwc(big, e.tdt), B, H, W, og, c0=32, ld0=96, off0=64, weight=wb.to("cuda", e.tdt),
+           w_batch_stride=32 * 32, bias=None, Cout=32, KH=1, KW=1, epi=L.EPI_GATE_RES, res=nhwc(res, e.tdt),
+           gate=C.c_void_p(gd.data_ptr() + 7 * 4), gate_ld=50)
+    torch.cuda.synchronize()
+    assert rel_err(nchw(og), refg) < tol
+
+
+@pytest.mark.parametrize("mode,tol", MODES)
+def test_xproj_directions(eng_factory, mode, tol):
+    """x_proj as 4 stride-2 1x1 convs with sub-grid origins == einsum over EfficientScan output."""
+    e = eng_factory(mode)
+    torch.manual_seed(2)
+    B, D, H, W, CD = 2, 64, 8, 12, 12
+    x = rq(torch.randn(B, D, H, W), mode)
+    xw = rq(torch.randn(4, CD, D) / 8, mode)
+    out = torch.empty(4, B, (H // 2) * (W // 2), CD, device="cuda", dtype=torch.float32)
+    e.conv(None, nhwc(x, e.tdt), B, H, W, out, c0=D, weight=xw.to("cuda", e.tdt), bias=None, Cout=CD, KH=1, KW=1,
+           stride=2, pad=0, ndir=4, w_dir_stride=CD * D, out_dir_stride=B * (H // 2) * (W // 2) * CD,
+           out_f32=True, OH=H // 2, OW=W // 2)
+    torch.cuda.synchronize()
+    for k in range(4):
+        sub = x[:, :, (k & 1)::2, (k >> 1)::2]                      # (B,D,H/2,W/2)
+        ref = torch.einsum("bdhw,cd->bhwc", sub, xw[k]).reshape(B, -1, CD)
+        assert rel_err(out[k].cpu(), ref) < (1e-5 if mode == "fp32" else 1e-4), k
+
+
+@pytest.mark.parametrize("mode,tol", MODES)
+@pytest.mark.parametrize("C_", [32, 64, 256, 1024])
+def test_ln_kernels(eng_factory, mode, tol, C_):
+    from founddiff_amd import _lib as L
+    e = eng_factory(mode)
+    torch.manual_seed(3)
+    B, hw = 2, 37
+    x = rq(torch.randn(B, hw, C_) * 2 + 0.5, mode)
+    g, b = torch.randn(C_), torch.randn(C_)
+    mod = torch.randn(B, 3 * C_)
+    sh, sc = mod[:, :C_], mod[:, C_:2 * C_]
+    ref = F.layer_norm(x, (C_,), g, b, 1e-5) * (1 + sc[:, None]) + sh[:, None]
+    xd, out = x.to("cuda", e.tdt), torch.empty(B, hw, C_, device="cuda", dtype=e.tdt)
+    md = mod.cuda()
+    L.call("fd_ln_modulate", e.dt, xd.data_ptr(), g.cuda().data_ptr(), b.cuda().data_ptr(), 1e-5, md.data_ptr(),
+           md.data_ptr() + 4 * C_, 3 * C_, out.data_ptr(), B, hw, C_, e.stream)
+    torch.cuda.synchronize()
+    assert rel_err(out.float().cpu(), ref) < tol
+    ref2 = F.layer_norm(x, (C_,), None, None, 1e-6) * (1 + sc[:, None]) + sh[:, None]
+    L.call("fd_ln_modulate", e.dt, xd.data_ptr(), None, None, 1e-6, md.data_ptr(), md.data_ptr() + 4 * C_, 3 * C_,
+           out.data_ptr(), B, hw, C_, e.stream)
+    torch.cuda.synchronize()
+    assert rel_err(out.float().cpu(), ref2) < tol
+    z = rq(torch.randn(B, hw, 2 * C_), mode)
+    loc = torch.randn(B, C_ + 5)
+    ref3 = F.layer_norm(x, (C_,), g, b, 1e-5) * z[..., C_:] + loc[:, None, 5:]
+    ld = loc.cuda()
+    zd = z.to("cuda", e.tdt)
+    L.call("fd_ln_gate", e.dt, xd.data_ptr(), g.cuda().data_ptr(), b.cuda().data_ptr(), 1e-5, zd.data_ptr(), 2 * C_,
+           C_, ld.data_ptr() + 20, C_ + 5, out.data_ptr(), B, hw, C_, e.stream)
+    torch.cuda.synchronize()
+    assert rel_err(out.float().cpu(), ref3) < tol
+
+
+@pytest.mark.parametrize("mode,tol", MODES)
+def test_dwconv_avgpool_gn(eng_factory, mode, tol):
+    from founddiff_amd import _lib as L
+    e = eng_factory(mode)
+    torch.manual_seed(4)
+    B, Cc, H, W = 2, 48, 9, 14
+    x = rq(torch.randn(B, Cc, H, W), mode)
+    w, b = torch.randn(Cc, 1, 3, 3) / 3, torch.randn(Cc)
+    ref = F.silu(F.conv2d(x, w, b, padding=1, groups=Cc))
+    out = torch.empty(B, H, W, Cc, device="cuda", dtype=e.tdt)
+    wd = w.reshape(Cc, 9).t().contiguous().cuda()
+    L.call("fd_dwconv3x3", e.dt, nhwc(x, e.tdt).data_ptr(), Cc, 0, wd.data_ptr(), b.cuda().data_ptr(), 1,
+           out.data_ptr(), Cc, 0, B, H, W, Cc, e.stream)
+    torch.cuda.synchronize()
+    assert rel_err(nchw(out), ref) < tol
+    x2 = rq(torch.randn(B, 16, 8, 12), mode)
+    o2 = torch.empty(B, 4, 6, 16, device="cuda", dtype=e.tdt)
+    L.call("fd_avgpool", e.dt, nhwc(x2, e.tdt).data_ptr(), o2.data_ptr(), B, 8, 12, 16, 2, e.stream)
+    torch.cuda.synchronize()
+    assert rel_err(nchw(o2), F.avg_pool2d(x2, 2)) < tol
+    # GroupNorm + SiLU (+ residual) from mean/rstd
+    h = rq(torch.randn(B, 32, 6, 5) * 3 + 1, mode)
+    res = rq(torch.randn(B, 32, 6, 5), mode)
+    g, bb = torch.randn(32), torch.randn(32)
+    ref = F.silu(F.group_norm(h, 8, g, bb, 1e-5)) + res
+    hv = h.reshape(B, 8, -1)
+    mr = torch.stack([hv.mean(-1), torch.rsqrt(hv.var(-1, unbiased=False) + 1e-5)], -1).contiguous().cuda()
+    o3 = torch.empty(B, 6, 5, 32, device="cuda", dtype=e.tdt)
+    L.call("fd_gn_silu_apply", e.dt, nhwc(h, e.tdt).data_ptr(), mr.data_ptr(), g.cuda().data_ptr(),
+           bb.cuda().data_ptr(), nhwc(res, e.tdt).data_ptr(), o3.data_ptr(), B, 30, 32, 8, e.stream)
+    torch.cuda.synchronize()
+    assert rel_err(nchw(o3), ref) < tol
+
+
+@pytest.mark.parametrize("mode,tol", MODES)
+@pytest.mark.parametrize("cfg", [(64, 4, 4, 16, 24), (64, 8, 2, 8, 8), (128, 32, 8, 12, 10), (256, 16, 16, 64, 64)])
+def test_selective_scan(eng_factory, mode, tol, cfg):
+    """HIP chunked scan (fused gather/dt_proj/softplus/merge) vs the sequential CPU oracle."""
+    from founddiff_amd import _lib as L
+    from oracle import nets
+    e = eng_factory(mode)
+    D, N, R, H, W = cfg
+    torch.manual_seed(5)
+    B, CD = 2, R + 2 * N
+    Lq = (H // 2) * (W // 2)
+    xc = rq(torch.randn(B, D, H, W) * 0.5, mode)
+    xdbl = torch.randn(4, B, Lq, CD)
+    dtw = (torch.rand(4, D, R) * 2 - 1) * R ** -0.5
+    dtb = torch.randn(4, D) * 0.5 - 3
+    A = -torch.exp(torch.log(torch.arange(1, N + 1).float())[None].repeat(4 * D, 1) + 0.1 * torch.randn(4 * D, N))
+    Ds = 1 + 0.1 * torch.randn(4 * D)
+    # oracle on the explicitly gathered tensors
+    xs = nets.efficient_scan(xc)                                                    # (B,4,D,L) in scan order
+    xd = xdbl.permute(1, 0, 2, 3).reshape(B, 4, H // 2, W // 2, CD)
+    xd_scan = torch.stack([xd[:, 0].reshape(B, Lq, CD), xd[:, 1].transpose(1, 2).reshape(B, Lq, CD),
+                           xd[:, 2].reshape(B, Lq, CD), xd[:, 3].transpose(1, 2).reshape(B, Lq, CD)], 1)
+    dts = torch.einsum("bklr,kdr->bkdl", xd_scan[..., :R], dtw)
+    Bs = xd_scan[..., R:R + N].permute(0, 1, 3, 2).contiguous()
+    Cs = xd_scan[..., R + N:].permute(0, 1, 3, 2).contiguous()
+    ys = nets.selective_scan(xs.reshape(B, 4 * D, Lq), dts.reshape(B, 4 * D, Lq), A, Bs, Cs, Ds, dtb.reshape(-1))
+    ref = nets.efficient_merge(ys.view(B, 4, D, Lq), H, W).view(B, D, H, W)
+    nws = L.lib().fd_scan_ws_floats(B, H, W, D, N)
+    ws = torch.empty(nws, device="cuda")
+    y = torch.empty(B, H, W, D, device="cuda", dtype=e.tdt)
+    t = [v.contiguous().cuda() for v in (xdbl, dtw, dtb, A, Ds)]
+    L.call("fd_selective_scan", e.dt, nhwc(xc, e.tdt).data_ptr(), t[0].data_ptr(), t[1].data_ptr(),
+           t[2].data_ptr(), t[3].data_ptr(), t[4].data_ptr(), y.data_ptr(), ws.data_ptr(), B, H, W, D, N, R, e.stream)
+    torch.cuda.synchronize()
+    assert rel_err(nchw(y), ref) < (1e-4 if mode == "fp32" else 1e-2)
+
+
+@pytest.mark.parametrize("mode,tol", MODES)
+def test_channel_attention(eng_factory, mode, tol):
+    from founddiff_amd import _lib as L
+    from oracle import nets
+    e = eng_factory(mode)
+    torch.manual_seed(6)
+    B, Cc, H, W = 2, 64, 40, 30          # hw = 1200 -> 2 pixel blocks, ragged tail
+    qkv = rq(torch.randn(B, 3 * Cc, H, W), mode)
+    temp = 1 + 0.3 * torch.randn(2)
+    wp = torch.randn(Cc, Cc) / 8
+    res = rq(torch.randn(B, Cc, H, W), mode)
+    gate = torch.randn(B, Cc)
+    q, k, v = qkv.chunk(3, 1)
+    qh = F.normalize(q.reshape(B, 2, 32, -1), dim=-1)
+    kh = F.normalize(k.reshape(B, 2, 32, -1), dim=-1)
+    attn = ((qh @ kh.transpose(-2, -1)) * temp[None, :, None, None]).softmax(-1)
+    o = (attn @ v.reshape(B, 2, 32, -1)).reshape(B, Cc, H, W)
+    ref = res + gate[:, :, None, None] * F.conv2d(o, wp[:, :, None, None])
+    qd = nhwc(qkv, e.tdt)
+    nblk = L.lib().fd_chan_attn_nblk(H * W)
+    part = torch.empty(B, 2, nblk, 1024 + 64, device="cuda")
+    L.call("fd_chan_attn_gram", e.dt, qd.data_ptr(), B, H * W, Cc, part.data_ptr(), e.stream)
+    weff = torch.empty(B, Cc, Cc, device="cuda", dtype=e.tdt)
+    L.call("fd_chan_attn_weff", e.dt, part.data_ptr(), nblk, temp.cuda().data_ptr(), wp.cuda().data_ptr(),
+           weff.data_ptr(), B, Cc, e.stream)
+    out = torch.empty(B, H, W, Cc, device="cuda", dtype=e.tdt)
+    e.conv(None, qd, B, H, W, out, c0=Cc, ld0=3 * Cc, off0=2 * Cc, weight=weff, w_batch_stride=Cc * Cc, bias=None,
+           Cout=Cc, KH=1, KW=1, epi=L.EPI_GATE_RES, res=nhwc(res, e.tdt), gate=gate.cuda(), gate_ld=Cc)
+    torch.cuda.synchronize()
+    assert rel_err(nchw(out), ref) < tol
+
+
+def test_small_fp32_ops(eng_factory):
+    from founddiff_amd import _lib as L
+    from oracle import nets
+    e = eng_factory("fp32")
+    torch.manual_seed(7)
+    x, w, b = torch.randn(3, 200), torch.randn(77, 200) / 14, torch.randn(77)
+    for act, fn in ((0, lambda v: v), (1, F.silu), (2, F.gelu), (3, F.relu)):
+        out = torch.empty(3, 77, device="cuda")
+        e.linear(x.cuda(), w.cuda(), b.cuda(), out, act)
+        assert rel_err(out.cpu(), fn(F.linear(x, w, b))) < 1e-5
+    out = torch.empty(3, 77, device="cuda")
+    e.linear(x.cuda(), w.cuda(), None, out, 0, pre_silu=True)
+    assert rel_err(out.cpu(), F.linear(F.silu(x), w)) < 1e-5
+    t = torch.tensor([998.5, 3.25, 0.0])
+    emb = torch.empty(3, 64, device="cuda")
+    L.call("fd_sinusoidal", t.cuda().data_ptr(), emb.data_ptr(), 3, 64, e.stream)
+    assert rel_err(emb.cpu(), nets.sinusoidal_emb(t, 64)) < 2e-4     # sin/cos of ~1e3 rad in fp32
+    p = torch.rand(77)
+    o = torch.empty(3, 77, device="cuda")
+    L.call("fd_softmax_mul", out.data_ptr(), p.cuda().data_ptr(), o.data_ptr(), 3, 77, e.stream)
+    assert rel_err(o.cpu(), torch.softmax(out.cpu(), 1) * p) < 1e-5
+    L.call("fd_l2norm_rows", out.data_ptr(), o.data_ptr(), 3, 77, 1e-12, e.stream)
+    assert rel_err(o.cpu(), F.normalize(out.cpu(), dim=1)) < 1e-5
+    # attention pool core
+    B, T, Cf, heads = 2, 17, 128, 2
+    qkv = torch.randn(B, T, 3 * Cf)
+    q = qkv[:, 0, :Cf].reshape(B, heads, 1, 64) * 64 ** -0.5
+    k = qkv[:, :, Cf:2 * Cf].reshape(B, T, heads, 64).permute(0, 2, 1, 3)
+    v = qkv[:, :, 2 * Cf:].reshape(B, T, heads, 64).permute(0, 2, 1, 3)
+    ref = ((q @ k.transpose(-2, -1)).softmax(-1) @ v).reshape(B, Cf)
+    qd = qkv.cuda()
+    po = torch.empty(B, Cf, device="cuda")
+    L.call("fd_attnpool_core", qd.data_ptr(), T * 3 * Cf, qd.data_ptr(), 3 * Cf, Cf, 2 * Cf, po.data_ptr(), B, T, Cf,
+           heads, e.stream)
+    assert rel_err(po.cpu(), ref) < 1e-5

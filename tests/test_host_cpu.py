@@ -1,0 +1,93 @@
+"""CPU-side checks of the host layer: parameter layout vs the reference's, product schedule vs
+golden, C-ABI library loads and exports every declared symbol (no compute without a GPU)."""
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+def _norm(spec):
+    return {k: (tuple(v[0]), v[1]) if (len(v) == 2 and isinstance(v[1], str)) else (tuple(v), "float32")
+            for k, v in spec.items()}
+
+
+@pytest.mark.parametrize("fixture,kw", [
+    ("e2e_da_tiny", dict(dim=32, dim_mults=(1, 2), clip=dict(layers=(2, 1, 1, 1), width=16, embed_dim=1024))),
+    ("full_arch_64", dict(dim=64, dim_mults=(1, 2, 4, 8))),
+])
+def test_arch_spec_matches_reference_layout(golden, fixture, kw):
+    from founddiff_amd import arch
+    g = golden(fixture)
+    ref = _norm(g.spec)
+    mine = _norm(arch.da_unet_spec(prefix="model.unet0.", **kw))
+    assert not [k for k in mine if k not in ref]
+    assert not [k for k in mine if ref[k] != mine[k]]
+    sched = {"alphas", "alphas_cumsum", "one_minus_alphas_cumsum", "betas2", "betas", "betas2_cumsum",
+             "betas_cumsum", "posterior_mean_coef1", "posterior_mean_coef2", "posterior_mean_coef3",
+             "posterior_variance", "posterior_log_variance_clipped"}
+    extra = [k for k in ref if k not in mine and not arch.is_dead_key(k) and k not in sched]
+    assert not extra, extra[:10]
+
+
+def test_module_state_dict_layout(golden):
+    from founddiff_amd.DADiff import ResidualDiffusion, UnetRes
+    g = golden("e2e_da_tiny")
+    net = UnetRes(dim=32, dim_mults=(1, 2), num_unet=1, condition=True, objective="pred_res",
+                  test_res_or_noise="res", clip_cfg=dict(layers=(2, 1, 1, 1), width=16, embed_dim=1024))
+    dif = ResidualDiffusion(net, image_size=64, timesteps=1000, sampling_timesteps=10, objective="pred_res",
+                            loss_type="l2", condition=True, sum_scale=0.01)
+    sd = dif.state_dict()
+    ref = _norm(g.spec)
+    for k, v in sd.items():
+        assert k in ref and tuple(v.shape) == ref[k][0], k
+    # a checkpoint with the reference's dead weight (second CLIP, text tower, LPIPS) loads
+    w = g.weights()
+    w["model.unet0.clip_model.visual.conv1.weight"] = torch.zeros(1)
+    w["perceploss.net.slice1.0.weight"] = torch.zeros(1)
+    w["model.unet0.dose_encoder.prompt_learner.ctx"] = torch.zeros(1)
+    missing, unexpected = dif.load_state_dict(w, strict=False)
+    assert not unexpected and not missing
+    dif.load_state_dict(w, strict=True)
+
+
+def test_product_schedule_matches_reference(golden):
+    from founddiff_amd.DADiff import residual_schedule
+    g = golden("schedule")
+    for tag, after in (("ctor", False), ("init", True)):
+        s = residual_schedule(1000, after)
+        for k, v in s.items():
+            assert torch.equal(v, g[f"{tag}.{k}"]), (tag, k)
+
+
+def test_cabi_exports_every_declared_symbol():
+    from founddiff_amd import _lib as L
+    hdr = open(os.path.join(ROOT, "include", "founddiff_hip.h")).read()
+    declared = set(re.findall(r"\b(fd_[a-z0-9_]+)\s*\(", hdr)) - {"fd_conv_params"}
+    assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
+    lib = L.lib()          # raises if the .so is missing or lacks a symbol
+    assert lib.fd_version() >= 100
+    assert lib.fd_conv_mtiles(512, 512) == 2048
+    assert lib.fd_chan_attn_nblk(512 * 512) == 256
+    assert lib.fd_scan_ws_floats(1, 512, 512, 128, 4) > 0
+
+
+def test_no_cpu_fallback():
+    """The product path must fail loudly without a GPU, never fall back to torch/oracle."""
+    from founddiff_amd import _lib as L
+    from founddiff_amd.DADiff import Unet
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    u = Unet(32, dim_mults=(1, 2), clip_cfg=dict(layers=(1, 1, 1, 1), width=16, embed_dim=1024))
+    with pytest.raises(L.FoundDiffHipError):
+        u(torch.zeros(1, 2, 16, 16), torch.zeros(1))
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "founddiff_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "oracle" not in src.replace("CPU oracle", ""), fn

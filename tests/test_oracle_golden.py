@@ -166,3 +166,16 @@ def test_e2e_vanilla_tiny(golden):
     for i, t in enumerate(range(999, 993, -1)):
         img, _ = orc.p_sample(img, t, g["anc.noise"][i])
         assert rel_err(img, g["anc.imgs"][i]) < 2e-4, t
+
+
+def test_full_arch_64(golden):
+    """Shipped architecture (dim 64, mults 1-2-4-8, RN50-sized DA-CLIP) at 64x64."""
+    g = golden("full_arch_64")
+    w = g.weights("model.")
+    orc = sampler.ResidualOracle(w, prefix="model.unet0.", sampling_timesteps=2)
+    xi = g["x_input"] * 2 - 1
+    xt = xi + 0.1 * g["noise0"]
+    tt = torch.full((1,), 999, dtype=torch.long)
+    assert rel_err(orc.unet(xt, xi, tt), g["unet.out"]) < 1e-4
+    out = orc.sample(g["x_input"], g["noise0"])
+    assert rel_err(out[-1], g["ddim2.out"]) < 2e-4
