@@ -148,8 +148,8 @@ def test_ln_kernels(eng_factory, mode, tol, C_):
     sh, sc = mod[:, :C_], mod[:, C_:2 * C_]
     ref = F.layer_norm(x, (C_,), g, b, 1e-5) * (1 + sc[:, None]) + sh[:, None]
     xd, out = x.to("cuda", e.tdt), torch.empty(B, hw, C_, device="cuda", dtype=e.tdt)
-    md = mod.cuda()
-    L.call("fd_ln_modulate", e.dt, xd.data_ptr(), g.cuda().data_ptr(), b.cuda().data_ptr(), 1e-5, md.data_ptr(),
+    md, gd, bd = mod.cuda(), g.cuda(), b.cuda()     # keep device tensors alive across the launches
+    L.call("fd_ln_modulate", e.dt, xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), 1e-5, md.data_ptr(),
            md.data_ptr() + 4 * C_, 3 * C_, out.data_ptr(), B, hw, C_, e.stream)
     torch.cuda.synchronize()
     assert rel_err(out.float().cpu(), ref) < tol
@@ -163,7 +163,7 @@ def test_ln_kernels(eng_factory, mode, tol, C_):
     ref3 = F.layer_norm(x, (C_,), g, b, 1e-5) * z[..., C_:] + loc[:, None, 5:]
     ld = loc.cuda()
     zd = z.to("cuda", e.tdt)
-    L.call("fd_ln_gate", e.dt, xd.data_ptr(), g.cuda().data_ptr(), b.cuda().data_ptr(), 1e-5, zd.data_ptr(), 2 * C_,
+    L.call("fd_ln_gate", e.dt, xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), 1e-5, zd.data_ptr(), 2 * C_,
            C_, ld.data_ptr() + 20, C_ + 5, out.data_ptr(), B, hw, C_, e.stream)
     torch.cuda.synchronize()
     assert rel_err(out.float().cpu(), ref3) < tol
@@ -179,14 +179,15 @@ def test_dwconv_avgpool_gn(eng_factory, mode, tol):
     w, b = torch.randn(Cc, 1, 3, 3) / 3, torch.randn(Cc)
     ref = F.silu(F.conv2d(x, w, b, padding=1, groups=Cc))
     out = torch.empty(B, H, W, Cc, device="cuda", dtype=e.tdt)
-    wd = w.reshape(Cc, 9).t().contiguous().cuda()
-    L.call("fd_dwconv3x3", e.dt, nhwc(x, e.tdt).data_ptr(), Cc, 0, wd.data_ptr(), b.cuda().data_ptr(), 1,
+    wd, bd, xd = w.reshape(Cc, 9).t().contiguous().cuda(), b.cuda(), nhwc(x, e.tdt)
+    L.call("fd_dwconv3x3", e.dt, xd.data_ptr(), Cc, 0, wd.data_ptr(), bd.data_ptr(), 1,
            out.data_ptr(), Cc, 0, B, H, W, Cc, e.stream)
     torch.cuda.synchronize()
     assert rel_err(nchw(out), ref) < tol
     x2 = rq(torch.randn(B, 16, 8, 12), mode)
     o2 = torch.empty(B, 4, 6, 16, device="cuda", dtype=e.tdt)
-    L.call("fd_avgpool", e.dt, nhwc(x2, e.tdt).data_ptr(), o2.data_ptr(), B, 8, 12, 16, 2, e.stream)
+    x2d = nhwc(x2, e.tdt)
+    L.call("fd_avgpool", e.dt, x2d.data_ptr(), o2.data_ptr(), B, 8, 12, 16, 2, e.stream)
     torch.cuda.synchronize()
     assert rel_err(nchw(o2), F.avg_pool2d(x2, 2)) < tol
     # GroupNorm + SiLU (+ residual) from mean/rstd
@@ -197,8 +198,9 @@ def test_dwconv_avgpool_gn(eng_factory, mode, tol):
     hv = h.reshape(B, 8, -1)
     mr = torch.stack([hv.mean(-1), torch.rsqrt(hv.var(-1, unbiased=False) + 1e-5)], -1).contiguous().cuda()
     o3 = torch.empty(B, 6, 5, 32, device="cuda", dtype=e.tdt)
-    L.call("fd_gn_silu_apply", e.dt, nhwc(h, e.tdt).data_ptr(), mr.data_ptr(), g.cuda().data_ptr(),
-           bb.cuda().data_ptr(), nhwc(res, e.tdt).data_ptr(), o3.data_ptr(), B, 30, 32, 8, e.stream)
+    hd, gd, bbd, rd = nhwc(h, e.tdt), g.cuda(), bb.cuda(), nhwc(res, e.tdt)
+    L.call("fd_gn_silu_apply", e.dt, hd.data_ptr(), mr.data_ptr(), gd.data_ptr(),
+           bbd.data_ptr(), rd.data_ptr(), o3.data_ptr(), B, 30, 32, 8, e.stream)
     torch.cuda.synchronize()
     assert rel_err(nchw(o3), ref) < tol
 
@@ -234,7 +236,8 @@ def test_selective_scan(eng_factory, mode, tol, cfg):
     ws = torch.empty(nws, device="cuda")
     y = torch.empty(B, H, W, D, device="cuda", dtype=e.tdt)
     t = [v.contiguous().cuda() for v in (xdbl, dtw, dtb, A, Ds)]
-    L.call("fd_selective_scan", e.dt, nhwc(xc, e.tdt).data_ptr(), t[0].data_ptr(), t[1].data_ptr(),
+    xcd = nhwc(xc, e.tdt)
+    L.call("fd_selective_scan", e.dt, xcd.data_ptr(), t[0].data_ptr(), t[1].data_ptr(),
            t[2].data_ptr(), t[3].data_ptr(), t[4].data_ptr(), y.data_ptr(), ws.data_ptr(), B, H, W, D, N, R, e.stream)
     torch.cuda.synchronize()
     assert rel_err(nchw(y), ref) < (1e-4 if mode == "fp32" else 1e-2)
@@ -263,7 +266,8 @@ def test_channel_attention(eng_factory, mode, tol):
     part = torch.empty(B, 2, nblk, 1024 + 64, device="cuda")
     L.call("fd_chan_attn_gram", e.dt, qd.data_ptr(), B, H * W, Cc, part.data_ptr(), e.stream)
     weff = torch.empty(B, Cc, Cc, device="cuda", dtype=e.tdt)
-    L.call("fd_chan_attn_weff", e.dt, part.data_ptr(), nblk, temp.cuda().data_ptr(), wp.cuda().data_ptr(),
+    td, wpd = temp.cuda(), wp.cuda()
+    L.call("fd_chan_attn_weff", e.dt, part.data_ptr(), nblk, td.data_ptr(), wpd.data_ptr(),
            weff.data_ptr(), B, Cc, e.stream)
     out = torch.empty(B, H, W, Cc, device="cuda", dtype=e.tdt)
     e.conv(None, qd, B, H, W, out, c0=Cc, ld0=3 * Cc, off0=2 * Cc, weight=weff, w_batch_stride=Cc * Cc, bias=None,
@@ -287,11 +291,13 @@ def test_small_fp32_ops(eng_factory):
     assert rel_err(out.cpu(), F.linear(F.silu(x), w)) < 1e-5
     t = torch.tensor([998.5, 3.25, 0.0])
     emb = torch.empty(3, 64, device="cuda")
-    L.call("fd_sinusoidal", t.cuda().data_ptr(), emb.data_ptr(), 3, 64, e.stream)
+    td = t.cuda()
+    L.call("fd_sinusoidal", td.data_ptr(), emb.data_ptr(), 3, 64, e.stream)
     assert rel_err(emb.cpu(), nets.sinusoidal_emb(t, 64)) < 2e-4     # sin/cos of ~1e3 rad in fp32
     p = torch.rand(77)
     o = torch.empty(3, 77, device="cuda")
-    L.call("fd_softmax_mul", out.data_ptr(), p.cuda().data_ptr(), o.data_ptr(), 3, 77, e.stream)
+    pd = p.cuda()
+    L.call("fd_softmax_mul", out.data_ptr(), pd.data_ptr(), o.data_ptr(), 3, 77, e.stream)
     assert rel_err(o.cpu(), torch.softmax(out.cpu(), 1) * p) < 1e-5
     L.call("fd_l2norm_rows", out.data_ptr(), o.data_ptr(), 3, 77, 1e-12, e.stream)
     assert rel_err(o.cpu(), F.normalize(out.cpu(), dim=1)) < 1e-5
