@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Headline benchmark: denoised CT slices / second, 512x512, 50 DDIM steps, full FoundDiff
+architecture (dim 64, mults 1-2-4-8, DA-CLIP RN50 conditioning), bf16 kernels, synthetic
+weights + phantoms (BASELINE.json configs[2]; no checkpoints / Mayo data offline).
+
+    python bench.py --gpus N --steps K --warmup W         (N>1: launched by torch.distributed.run)
+
+A "step" = one complete sample() of a batch of `--batch` slices per GPU (DA-CLIP encode once,
+50 UNet forwards + DDIM updates).  Slices are independent, so GPUs shard the slice range with
+no data-path collective (weak scaling); one RCCL all-gather reassembles the output volume at
+the end of the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+SIZE, S_DDIM = 512, 50
+DIM, MULTS = 64, (1, 2, 4, 8)
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, MI355X_MICROARCH.md
+ALG_GFLOP_PER_FORWARD = 575.5  # SURVEY.md section 8(d), 512x512, B=1
+
+
+def build_model(device, size=SIZE, steps=S_DDIM, precision="bf16", seed=0):
+    from founddiff_amd import arch, synth
+    from founddiff_amd.DADiff import ResidualDiffusion, UnetRes
+    spec = arch.da_unet_spec(DIM, MULTS, prefix="model.unet0.")
+    w = synth.synth_state_dict(spec, seed=seed)
+    net = UnetRes(dim=DIM, dim_mults=MULTS, num_unet=1, condition=True, objective="pred_res",
+                  test_res_or_noise="res", precision=precision)
+    dif = ResidualDiffusion(net, image_size=size, timesteps=1000, sampling_timesteps=steps, objective="pred_res",
+                            loss_type="l2", condition=True, sum_scale=0.01, test_res_or_noise="res")
+    dif.load_state_dict(w, strict=False)
+    dif = dif.to(device)
+    dif.init()
+    return dif, w
+
+
+def conv_flops(p):
+    cin = p.c0 + p.c1
+    if p.KH == 7 and cin == 8:
+        cin = 2       # init_conv: channels 2..7 are zero padding, not algorithmic work
+    return 2.0 * p.B * p.OH * p.OW * p.Cout * p.KH * p.KW * cin * p.ndir
+
+
+def roofline_leg(dif, x, noise, reps=5):
+    """Dominant kernel family = conv_igemm_kernel (all dense contractions).  Replays exactly the
+    fd_conv2d launches of one UNet forward between HIP events on the launch stream."""
+    from founddiff_amd import _lib as L
+    eng = dif._eng()
+    B = x.shape[0]
+    x_in = (x * 2 - 1).contiguous()
+    img = (x_in + 0.1 * noise).contiguous()
+    tb = torch.full((B,), 500.0, device=x.device)
+    eng.encode_condition(x_in)
+    eng.forward(img, x_in, tb)
+    L.TRACE = []
+    eng.forward(img, x_in, tb)
+    trace, L.TRACE = L.TRACE, None
+    convs = [(n, a) for n, a in trace if n == "fd_conv2d"]
+    flops = sum(conv_flops(a[0]._obj) for _, a in convs)
+    lib = L.lib()
+    # HIP events recorded on the stream the kernels are launched on: every launch of this library
+    # goes to torch's CURRENT stream (engine.stream), which is the stream torch.cuda.Event records on.
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    best = None
+    for _ in range(reps):
+        ev0.record()
+        for n, a in convs:
+            lib.fd_conv2d(*a)
+        ev1.record()
+        ev1.synchronize()
+        ms = ev0.elapsed_time(ev1)
+        best = ms if best is None else min(best, ms)
+    # whole-forward time with the same events, for the share of the dominant kernel
+    ev0.record()
+    for n, a in trace:
+        getattr(lib, n)(*a)
+    ev1.record()
+    ev1.synchronize()
+    all_ms = ev0.elapsed_time(ev1)
+    achieved = flops / (best * 1e-3) / 1e12
+    traffic = None
+    tp = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tp):
+        traffic = json.load(open(tp)).get("conv_igemm_hbm_bytes_per_launch")
+    return {"bound": "mfma", "kernel": "conv_igemm_kernel<bf16,*> (implicit-GEMM conv/GEMM family)",
+            "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+            "launches_per_forward": len(convs), "avg_launch_us": round(best * 1e3 / len(convs), 2),
+            "alg_gflop_per_forward_in_kernel": round(flops / 1e9 / B, 1),
+            "kernel_ms_per_forward": round(best, 3), "all_kernels_ms_per_forward": round(all_ms, 3)}
+
+
+def cpu_baseline_leg(w, x_in01, noise):
+    """CPU oracle (PyTorch-CPU + C/OpenMP scan) on the host cores: DA-CLIP encode + ONE of the 50
+    UNet forwards of one 512x512 slice, extrapolated x50."""
+    from oracle import nets, sampler
+    torch.set_num_threads(os.cpu_count())
+    orc = sampler.ResidualOracle(w, prefix="model.unet0.", sampling_timesteps=S_DDIM)
+    xi = x_in01[:1].cpu() * 2 - 1
+    xt = xi + 0.1 * noise[:1].cpu()
+    t0 = time.time()
+    orc._cond = nets.da_unet_cond(orc.sd, xi)
+    t1 = time.time()
+    orc.unet(xt, xi, torch.full((1,), 999, dtype=torch.long))
+    t2 = time.time()
+    per_slice = (t1 - t0) + S_DDIM * (t2 - t1)
+    return {"value": round(1.0 / per_slice, 6), "unit": "slices/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"1 slice: DA-CLIP encode ({t1 - t0:.1f}s) + 1 of {S_DDIM} UNet forwards ({t2 - t1:.1f}s) "
+                      f"at 512x512 fp32, extrapolated x{S_DDIM}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=2, help="slices per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from founddiff_amd import parallel, synth
+    dif, w = build_model(dev)
+    B = a.batch
+    # global slice range sharded contiguously over ranks; per-slice noise keyed by GLOBAL index
+    lo, hi = parallel.shard_range(world * B, world, rank)
+    _, ld = synth.ct_phantom(world * B, SIZE, seed=10)
+    x = torch.from_numpy(ld[lo:hi]).to(dev)
+    noise = torch.stack([torch.randn(1, SIZE, SIZE, generator=torch.Generator().manual_seed(1000 + i))
+                         for i in range(lo, hi)]).to(dev)
+
+    def step():
+        out = dif.sample([x], batch_size=B, noise=noise)[-1]
+        return parallel.gather_volume(out, world)
+
+    for _ in range(a.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        vol = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert vol.shape[0] == world * B and torch.isfinite(vol).all()
+
+    if rank == 0:
+        slices = world * B * a.steps
+        res = {
+            "metric": "denoised CT slices/sec (512x512, 50 DDIM steps)",
+            "value": round(slices / dt, 4), "unit": "slices/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: 512x512 slice, 50-step DDIM, full FoundDiff UNet "
+                                   "(dim 64, mults 1-2-4-8) + DA-CLIP RN50 cond, bf16",
+                       "slices_per_gpu_per_step": B, "sharding": f"slices over {world} rank(s), no data-path "
+                       "collective; 1 all-gather of the output volume"},
+            "ms_per_unet_forward_per_slice": round(dt / a.steps / S_DDIM / B * 1e3, 3),
+            "alg_tflops_sustained": round(ALG_GFLOP_PER_FORWARD * S_DDIM * slices / dt / 1e3, 1),
+        }
+        if not a.no_roofline:
+            res["roofline"] = roofline_leg(dif, x, noise)
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline_leg(w, x, noise)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

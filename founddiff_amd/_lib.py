@@ -101,5 +101,10 @@ def check(rc, what=""):
         raise FoundDiffHipError(f"{what} failed (rc={rc}): {msg}")
 
 
+TRACE = None   # set to a list to record (name, args) of every launch (bench.py roofline leg)
+
+
 def call(name, *args):
+    if TRACE is not None:
+        TRACE.append((name, args))
     check(getattr(lib(), name)(*args), name)
