@@ -81,6 +81,27 @@ __global__ __launch_bounds__(256) void gram_kernel(const T *__restrict__ qkv, in
     if (tid < 64) out[1024 + tid] = sN[0][tid] + sN[1][tid] + sN[2][tid] + sN[3][tid];
 }
 
+// Sum the pixel-block partials of one (batch, head) in place into block 0's slot: a workgroup
+// owns 64 of the 1088 entries, 4 thread groups split the blocks, fixed order -> deterministic.
+__global__ __launch_bounds__(256) void gram_reduce_kernel(float *__restrict__ partial, int nblk) {
+    __shared__ float sh[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+    float *pp = partial + (int64_t)blockIdx.y * nblk * (1024 + 64);
+    float s = 0.f;
+    if (col < 1024 + 64) {
+        int k = grp;
+        for (; k + 12 < nblk; k += 16) {       // 4 independent loads in flight per thread
+            const float a0 = pp[(int64_t)k * 1088 + col], a1 = pp[(int64_t)(k + 4) * 1088 + col];
+            const float a2 = pp[(int64_t)(k + 8) * 1088 + col], a3 = pp[(int64_t)(k + 12) * 1088 + col];
+            s += (a0 + a1) + (a2 + a3);
+        }
+        for (; k < nblk; k += 4) s += pp[(int64_t)k * 1088 + col];
+    }
+    sh[grp][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (grp == 0 && col < 1024 + 64) pp[col] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void weff_kernel(const float *__restrict__ partial, int nblk,
                                                   const float *__restrict__ temperature,
@@ -89,10 +110,9 @@ __global__ __launch_bounds__(256) void weff_kernel(const float *__restrict__ par
     __shared__ float sNrm[64];
     const int tid = threadIdx.x;
     const int head = blockIdx.x, b = blockIdx.y, heads = gridDim.x;
-    const float *pp = partial + ((int64_t)b * heads + head) * nblk * (1024 + 64);
+    const float *pp = partial + ((int64_t)b * heads + head) * nblk * (1024 + 64);   // slot 0 = reduced
     for (int i = tid; i < 1024 + 64; i += 256) {
-        float s = 0.f;
-        for (int k = 0; k < nblk; ++k) s += pp[(int64_t)k * (1024 + 64) + i];
+        const float s = pp[i];
         if (i < 1024) sG[(i >> 5) * 33 + (i & 31)] = s;
         else sNrm[i - 1024] = fmaxf(sqrtf(s), 1e-12f);     // F.normalize eps
     }
@@ -180,10 +200,12 @@ extern "C" int fd_chan_attn_gram(int dtype, const void *qkv, int B, int64_t hw, 
     return FD_OK;
 }
 
-extern "C" int fd_chan_attn_weff(int dtype, const float *partial, int nblk, const float *temperature,
+extern "C" int fd_chan_attn_weff(int dtype, float *partial, int nblk, const float *temperature,
                                  const float *wproj, void *weff, int B, int C, void *stream) {
     FD_REQUIRE(partial && temperature && wproj && weff && C % 32 == 0, "fd_chan_attn_weff: bad args");
     dim3 grid(C / 32, B), block(256);
+    if (nblk > 1)
+        hipLaunchKernelGGL(gram_reduce_kernel, dim3(17, B * (C / 32)), dim3(256), 0, (hipStream_t)stream, partial, nblk);
     if (dtype == FD_BF16)
         hipLaunchKernelGGL(weff_kernel<bf16>, grid, block, 0, (hipStream_t)stream, partial, nblk, temperature, wproj, (bf16 *)weff, C);
     else

@@ -34,6 +34,16 @@ template <> struct TT<bf16> { static constexpr int CH = 8; };
 
 __device__ __forceinline__ float fd_silu(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float fd_softplus(float x) { return x > 20.0f ? x : log1pf(__expf(x)); }
+// softplus without libm: for x < -4 the series e - e^2/2 + e^3/3 of log1p(e), e = exp(x) < 0.0184
+// (truncation < 3e-8 absolute, ~1.5e-6 relative); else log(1 + e) with 1 + e >= 1.018 so the
+// rounding of the sum costs <= 3e-6 relative.  v_exp_f32 / v_log_f32 are the base-2 forms.
+__device__ __forceinline__ float fd_softplus_fast(float x) {
+    if (x > 20.0f) return x;
+    const float e = __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
+    const float series = e * (1.0f + e * (-0.5f + e * 0.33333334f));
+    const float lg = __builtin_amdgcn_logf(1.0f + e) * 0.6931471805599453f;
+    return x < -4.0f ? series : lg;
+}
 
 // 8 consecutive elements <-> 8 floats (16-byte aligned for bf16, 32-byte span for f32)
 __device__ __forceinline__ void load8(const float *p, float v[8]) {

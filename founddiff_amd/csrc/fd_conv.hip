@@ -19,8 +19,11 @@
 
 namespace {
 
-constexpr int BM = 128;
 constexpr int ROWB = 128;  // bytes of K per tile row
+// pixel-tile height: 128 rows for big images, 64 when an image has few pixels (low-resolution
+// levels at B=1 would otherwise launch fewer workgroups than there are CUs).  Depends on the
+// image size ONLY, so workspaces sized with fd_conv_mtiles() and results are batch-invariant.
+static inline int conv_bm(int64_t ohw) { return ohw <= 16384 ? 64 : 128; }
 
 template <typename T> struct Frag;
 template <> struct Frag<bf16> {
@@ -32,8 +35,9 @@ template <> struct Frag<float> {
 
 __device__ __forceinline__ int swz(int row, int chunk) { return (chunk ^ ((row >> 1) & 7)) << 4; }
 
-template <typename T, int BN>
+template <typename T, int BM, int BN>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const fd_conv_params p) {
+    constexpr int MT = BM / 32;   // 16-row m tiles per wave == A rows per loading thread
     constexpr int CH = TT<T>::CH;
     constexpr int BK = ROWB / (int)sizeof(T);
     constexpr int NB = BN / 32;   // B rows per loading thread
@@ -60,9 +64,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const fd_conv_params p)
 
     // ---- loader roles
     const int chunk = tid & 7, rbase = tid >> 3;
-    int ihb[4], iwb[4];
+    int ihb[MT], iwb[MT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MT; ++i) {
         int m = mt * BM + rbase + 32 * i;
         if (m < OHW) {
             int oh = m / p.OW, ow = m - oh * p.OW;
@@ -73,26 +77,42 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const fd_conv_params p)
             iwb[i] = 0;
         }
     }
-    u32x4 ra[4], rb[NB];
+    u32x4 ra[MT], rb[NB];
     const int nkt = (K + BK - 1) / BK;
 
-    auto gload = [&](int kt) {
-        const int k = kt * BK + chunk * CH;
-        const bool kv = k < K;
-        int tap = k / Cin;
-        int c = k - tap * Cin;
-        int kh = tap / p.KW, kw = tap - kh * p.KW;
+    // (kh, kw, channel base) of the next K tile, kept as wave-uniform counters: when the tile
+    // lies inside one filter tap (Cin % BK == 0: every large layer) the per-tile address math
+    // has no integer division; tiles that straddle taps (tiny Cin) take the general decode.
+    int t_kh = 0, t_kw = 0, t_cb = 0;
+    const int64_t img_px = (int64_t)p.H * p.W;
+    const T *in0b = in0 + (int64_t)b * img_px * p.ld0;
+    const T *in1b = in1 ? in1 + (int64_t)b * img_px * p.ld1 : nullptr;
+    auto gload = [&](int) {
+        int kh, kw, c;
+        bool kv;
+        if (t_cb + BK <= Cin) {
+            kh = t_kh; kw = t_kw; c = t_cb + chunk * CH;
+            kv = t_kh < p.KH;
+        } else {
+            const int k = (t_kh * p.KW + t_kw) * Cin + t_cb + chunk * CH;
+            kv = k < K;
+            const int tap = k / Cin;
+            c = k - tap * Cin;
+            kh = tap / p.KW;
+            kw = tap - kh * p.KW;
+        }
+        const int k = (kh * p.KW + kw) * Cin + c;
         const T *src;
         int ld, coff;
-        if (c < p.c0) { src = in0; ld = p.ld0; coff = p.off0 + c; }
-        else { src = in1; ld = p.ld1; coff = p.off1 + c - p.c0; }
+        if (c < p.c0) { src = in0b; ld = p.ld0; coff = p.off0 + c; }
+        else { src = in1b; ld = p.ld1; coff = p.off1 + c - p.c0; }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < MT; ++i) {
             int ih = ihb[i] + kh, iw = iwb[i] + kw;
             bool ok = kv && ih >= 0 && ih < Hs && iw >= 0 && iw < Ws;
             if (p.upsample) { ih >>= 1; iw >>= 1; }
             u32x4 v = {0, 0, 0, 0};
-            if (ok) v = *(const u32x4 *)(src + ((int64_t)(b * p.H + ih) * p.W + iw) * ld + coff);
+            if (ok) v = *(const u32x4 *)(src + ((ih * p.W + iw) * ld + coff));
             ra[i] = v;
         }
 #pragma unroll
@@ -102,12 +122,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const fd_conv_params p)
             if (kv && n < p.Cout) v = *(const u32x4 *)(wgt + (int64_t)n * K + k);
             rb[i] = v;
         }
+        t_cb += BK;
+        while (t_cb >= Cin) {
+            t_cb -= Cin;
+            if (++t_kw == p.KW) { t_kw = 0; ++t_kh; }
+        }
     };
     auto lstore = [&](int buf) {
         unsigned char *sA = smem + buf * (BM + BN) * ROWB;
         unsigned char *sB = sA + BM * ROWB;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < MT; ++i) {
             int r = rbase + 32 * i;
             *(u32x4 *)(sA + r * ROWB + swz(r, chunk)) = ra[i];
         }
@@ -121,9 +146,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const fd_conv_params p)
     // ---- compute roles
     const int wm = wave >> 1, wn = wave & 1;
     const int fr = lane & 15, fg = lane >> 4;
-    f32x4 acc[4][NT];
+    f32x4 acc[MT][NT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -140,8 +165,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const fd_conv_params p)
             if constexpr (sizeof(T) == 2) {
                 bf16x8 af[4], bfr[NT];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    int r = 64 * wm + 16 * i + fr;
+                for (int i = 0; i < MT; ++i) {
+                    int r = (BM / 2) * wm + 16 * i + fr;
                     af[i] = *(const bf16x8 *)(sA + r * ROWB + swz(r, ks * 4 + fg));
                 }
 #pragma unroll
@@ -150,7 +175,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const fd_conv_params p)
                     bfr[j] = *(const bf16x8 *)(sB + r * ROWB + swz(r, ks * 4 + fg));
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
@@ -159,8 +184,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const fd_conv_params p)
                 // contracts the k-set {8g + e}: any consistent A/B k-permutation is a valid sum.
                 f32x4 a0[4], a1[4], b0[NT], b1[NT];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    int r = 64 * wm + 16 * i + fr;
+                for (int i = 0; i < MT; ++i) {
+                    int r = (BM / 2) * wm + 16 * i + fr;
                     a0[i] = *(const f32x4 *)(sA + r * ROWB + swz(r, 2 * fg));
                     a1[i] = *(const f32x4 *)(sA + r * ROWB + swz(r, 2 * fg + 1));
                 }
@@ -173,14 +198,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const fd_conv_params p)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < MT; ++i)
 #pragma unroll
                         for (int j = 0; j < NT; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i][e], b0[j][e], acc[i][j], 0, 0, 0);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < MT; ++i)
 #pragma unroll
                         for (int j = 0; j < NT; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i][e], b1[j][e], acc[i][j], 0, 0, 0);
@@ -193,12 +218,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const fd_conv_params p)
     // ---- stage accumulators: sC[row][col] f32, row-major BN floats per row
     float *sC = (float *)smem;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                int r = 64 * wm + 16 * i + fg * 4 + e;
+                int r = (BM / 2) * wm + 16 * i + fg * 4 + e;
                 int cc = (BN / 2) * wn + 16 * j + fr;
                 sC[r * BN + cc] = acc[i][j][e];
             }
@@ -392,7 +417,7 @@ __global__ void gn_silu_apply_kernel(const T *__restrict__ h, const float *__res
 
 }  // namespace
 
-extern "C" int fd_conv_mtiles(int OH, int OW) { return cdiv((int64_t)OH * OW, BM); }
+extern "C" int fd_conv_mtiles(int OH, int OW) { return cdiv((int64_t)OH * OW, conv_bm((int64_t)OH * OW)); }
 
 extern "C" int fd_conv2d(const fd_conv_params *pp, void *stream) {
     const fd_conv_params &p = *pp;
@@ -412,17 +437,21 @@ extern "C" int fd_conv2d(const fd_conv_params *pp, void *stream) {
     if (p.epilogue == FD_EPI_GNSILU_ADD)
         FD_REQUIRE(p.h && p.gn_mean_rstd && p.gn_gamma && p.gn_beta && p.gn_groups > 0 && p.Cout % p.gn_groups == 0,
                    "fd_conv2d: GNSILU_ADD needs h, statistics, affine and groups | Cout");
+    FD_REQUIRE((int64_t)p.H * p.W * (p.ld0 > p.ld1 ? p.ld0 : p.ld1) < (1ll << 31),
+               "fd_conv2d: one image of a source must hold < 2^31 elements");
     const int mt = fd_conv_mtiles(p.OH, p.OW);
-    const bool wide = p.Cout > 64;
+    const bool wide = p.Cout > 64, tall = conv_bm((int64_t)p.OH * p.OW) == 128;
     dim3 grid(mt, cdiv(p.Cout, wide ? 128 : 64), p.B * p.ndir), block(256);
     hipStream_t s = (hipStream_t)stream;
+#define FD_CONV_LAUNCH(T_, BM_, BN_) hipLaunchKernelGGL((conv_igemm_kernel<T_, BM_, BN_>), grid, block, 0, s, p)
     if (p.dtype == FD_BF16) {
-        if (wide) hipLaunchKernelGGL((conv_igemm_kernel<bf16, 128>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((conv_igemm_kernel<bf16, 64>), grid, block, 0, s, p);
+        if (tall) { if (wide) FD_CONV_LAUNCH(bf16, 128, 128); else FD_CONV_LAUNCH(bf16, 128, 64); }
+        else { if (wide) FD_CONV_LAUNCH(bf16, 64, 128); else FD_CONV_LAUNCH(bf16, 64, 64); }
     } else {
-        if (wide) hipLaunchKernelGGL((conv_igemm_kernel<float, 128>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((conv_igemm_kernel<float, 64>), grid, block, 0, s, p);
+        if (tall) { if (wide) FD_CONV_LAUNCH(float, 128, 128); else FD_CONV_LAUNCH(float, 128, 64); }
+        else { if (wide) FD_CONV_LAUNCH(float, 64, 128); else FD_CONV_LAUNCH(float, 64, 64); }
     }
+#undef FD_CONV_LAUNCH
     FD_LAUNCH_OK("fd_conv2d");
     return FD_OK;
 }

@@ -7,7 +7,7 @@ namespace {
 
 // Row of C channels handled by LPR lanes x VPL 8-element vectors per lane (C = 8*VPL*LPR),
 // LPR a power of two <= 64 so the reduction is an xor-shuffle butterfly inside one wave.
-template <typename T, int VPL, bool GATE>
+template <typename T, int VPL, bool GATE, bool VEC>
 __global__ __launch_bounds__(256) void ln_rows_kernel(
     const T *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
     const float *__restrict__ shift, const float *__restrict__ scale, int mod_ld,
@@ -44,15 +44,26 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(
 #pragma unroll
     for (int j = 0; j < VPL; ++j) {
         const int c0 = (j * lpr + sub) * 8;
-        float o8[8], zz[8];
+        float o8[8], zz[8], gg[8], bb[8], sh[8], sc[8];
         if (GATE) load8(z + rr * ldz + offz + c0, zz);
+        if (VEC) {   // all per-channel vectors 16-byte aligned: 2 x dwordx4 each instead of 8 dword loads
+            if (gamma) { load8(gamma + c0, gg); load8(beta + c0, bb); }
+            load8(shift + (int64_t)b * mod_ld + c0, sh);
+            if (!GATE) load8(scale + (int64_t)b * mod_ld + c0, sc);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (gamma) { gg[e] = gamma[c0 + e]; bb[e] = beta[c0 + e]; }
+                sh[e] = shift[(int64_t)b * mod_ld + c0 + e];
+                if (!GATE) sc[e] = scale[(int64_t)b * mod_ld + c0 + e];
+            }
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int c = c0 + e;
             float y = (v[j][e] - mean) * rstd;
-            if (gamma) y = y * gamma[c] + beta[c];
-            if (GATE) y = y * zz[e] + shift[(int64_t)b * mod_ld + c];       // shift == local
-            else y = y * (1.f + scale[(int64_t)b * mod_ld + c]) + shift[(int64_t)b * mod_ld + c];
+            if (gamma) y = y * gg[e] + bb[e];
+            if (GATE) y = y * zz[e] + sh[e];       // shift == local
+            else y = y * (1.f + sc[e]) + sh[e];
             o8[e] = y;
         }
         store8(out + rr * C + c0, o8);
@@ -72,53 +83,96 @@ int launch_ln(const T *x, const float *gamma, const float *beta, float eps, cons
     int64_t nrows = (int64_t)B * hw;
     int rpb = 256 / lpr;
     dim3 grid((unsigned)((nrows + rpb - 1) / rpb)), block(256);
-    if (vpl == 1)
-        hipLaunchKernelGGL((ln_rows_kernel<T, 1, GATE>), grid, block, 0, s, x, gamma, beta, eps, shift, scale,
-                           mod_ld, z, ldz, offz, out, hw, C, lpr, nrows);
-    else
-        hipLaunchKernelGGL((ln_rows_kernel<T, 2, GATE>), grid, block, 0, s, x, gamma, beta, eps, shift, scale,
-                           mod_ld, z, ldz, offz, out, hw, C, lpr, nrows);
+    auto al16 = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
+    const bool vec = al16(gamma) && al16(beta) && al16(shift) && al16(scale) && (mod_ld % 4 == 0);
+#define FD_LN_LAUNCH(V, VEC_)                                                                              \
+    hipLaunchKernelGGL((ln_rows_kernel<T, V, GATE, VEC_>), grid, block, 0, s, x, gamma, beta, eps, shift, \
+                       scale, mod_ld, z, ldz, offz, out, hw, C, lpr, nrows)
+    if (vpl == 1) { if (vec) FD_LN_LAUNCH(1, true); else FD_LN_LAUNCH(1, false); }
+    else { if (vec) FD_LN_LAUNCH(2, true); else FD_LN_LAUNCH(2, false); }
+#undef FD_LN_LAUNCH
     return FD_OK;
 }
 
-// depthwise 3x3, pad 1: a thread owns 8 channels of one pixel.
+// depthwise 3x3, pad 1, LDS-tiled: a workgroup owns an 8 x 32 pixel tile x 64 channels.  The
+// (8+2) x (32+2) halo tile is read from HBM once (coalesced 128-byte pixel rows) into LDS; a
+// thread owns one 8-channel vector of one tile column, keeps its 9 tap vectors in registers and
+// walks down the 8 rows reading 9 LDS vectors per output (a wave reads 1 KiB contiguous: no
+// bank conflicts).  HBM traffic = 1.33x input (halo) + output instead of relying on L1/L2 for
+// the 9x tap reuse.
+constexpr int DW_TY = 8, DW_TX = 32, DW_CB = 64;
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(const T *__restrict__ in, int ld_in, int off_in,
                                                        const float *__restrict__ w, const float *__restrict__ bias,
                                                        int silu, T *__restrict__ out, int ld_out, int off_out,
-                                                       int H, int W, int C, int64_t total) {
-    const int vpp = C / 8;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const int cv = (int)(i % vpp);
-        const int64_t pix = i / vpp;
-        const int x = (int)(pix % W);
-        const int y = (int)((pix / W) % H);
-        const int64_t img = pix / ((int64_t)W * H);
-        const int c0 = cv * 8;
+                                                       int H, int W, int C, int cblocks) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dw_smem[];
+    T *tile = (T *)dw_smem;                          // [(TY+2)][(TX+2)][CB]
+    const int tid = threadIdx.x;
+    const int cb = blockIdx.z % cblocks;
+    const int64_t img = blockIdx.z / cblocks;
+    const int x0 = blockIdx.x * DW_TX, y0 = blockIdx.y * DW_TY;
+    const int cbase = cb * DW_CB;
+    constexpr int HX = DW_TX + 2, HY = DW_TY + 2;
+    for (int idx = tid; idx < HY * HX * 8; idx += 256) {
+        const int v = idx & 7, pxl = idx >> 3;
+        const int hy = pxl / HX, hx = pxl - hy * HX;
+        const int yy = y0 + hy - 1, xx = x0 + hx - 1, c0 = cbase + v * 8;
+        u32x4 val = {0, 0, 0, 0};
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W && c0 < C) {
+            const T *src = in + ((img * H + yy) * W + xx) * ld_in + off_in + c0;
+            if constexpr (sizeof(T) == 2) val = *(const u32x4 *)src;
+            else {
+                *(u32x4 *)(tile + (int64_t)pxl * DW_CB + v * 8) = *(const u32x4 *)src;
+                val = *(const u32x4 *)(src + 4);
+                *(u32x4 *)(tile + (int64_t)pxl * DW_CB + v * 8 + 4) = val;
+                continue;
+            }
+        } else if constexpr (sizeof(T) == 4) {
+            *(u32x4 *)(tile + (int64_t)pxl * DW_CB + v * 8) = val;
+            *(u32x4 *)(tile + (int64_t)pxl * DW_CB + v * 8 + 4) = val;
+            continue;
+        }
+        *(u32x4 *)(tile + (int64_t)pxl * DW_CB + v * 8) = val;
+    }
+    const int cv = tid & 7, px = tid >> 3;
+    const int c0 = cbase + cv * 8;
+    float wt[9][8], bs[8];
+    const bool cok = c0 < C;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        if (cok) load8(w + t * C + c0, wt[t]);
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) wt[t][e] = 0.f;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bs[e] = (bias && cok) ? bias[c0 + e] : 0.f;
+    __syncthreads();
+    const int x = x0 + px;
+    if (x >= W || !cok) return;
+#pragma unroll
+    for (int r = 0; r < DW_TY; ++r) {
+        const int y = y0 + r;
+        if (y >= H) break;
         float acc[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = bias ? bias[c0 + e] : 0.f;
+        for (int e = 0; e < 8; ++e) acc[e] = bs[e];
 #pragma unroll
-        for (int dy = -1; dy <= 1; ++dy) {
-            const int yy = y + dy;
-            if (yy < 0 || yy >= H) continue;
+        for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-            for (int dx = -1; dx <= 1; ++dx) {
-                const int xx = x + dx;
-                if (xx < 0 || xx >= W) continue;
-                float v[8], ww[8];
-                load8(in + ((img * H + yy) * W + xx) * ld_in + off_in + c0, v);
-                load8(w + ((dy + 1) * 3 + (dx + 1)) * C + c0, ww);
+            for (int dx = 0; dx < 3; ++dx) {
+                float v[8];
+                load8(tile + ((r + dy) * HX + px + dx) * DW_CB + cv * 8, v);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] += v[e] * ww[e];
+                for (int e = 0; e < 8; ++e) acc[e] += v[e] * wt[dy * 3 + dx][e];
             }
-        }
         if (silu) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[e] = fd_silu(acc[e]);
         }
-        store8(out + pix * ld_out + off_out + c0, acc);
+        store8(out + ((img * H + y) * W + x) * ld_out + off_out + c0, acc);
     }
 }
 
@@ -241,14 +295,21 @@ extern "C" int fd_dwconv3x3(int dtype, const void *in, int ld_in, int off_in, co
     FD_REQUIRE(in && out && weight, "fd_dwconv3x3: null pointer");
     FD_REQUIRE(C % 8 == 0 && ld_in % 8 == 0 && off_in % 8 == 0 && ld_out % 8 == 0 && off_out % 8 == 0,
                "fd_dwconv3x3: channels/strides/offsets must be multiples of 8");
-    int64_t total = (int64_t)B * H * W * (C / 8);
-    dim3 grid(grid1d(total, 256, 1 << 20)), block(256);
+    const int cblocks = (C + DW_CB - 1) / DW_CB;
+    dim3 grid((W + DW_TX - 1) / DW_TX, (H + DW_TY - 1) / DW_TY, (unsigned)(B * cblocks)), block(256);
+    const size_t lds = (size_t)(DW_TY + 2) * (DW_TX + 2) * DW_CB * (dtype == FD_BF16 ? 2 : 4);
     if (dtype == FD_BF16)
-        hipLaunchKernelGGL(dwconv3x3_kernel<bf16>, grid, block, 0, (hipStream_t)stream, (const bf16 *)in, ld_in, off_in,
-                           weight, bias, silu, (bf16 *)out, ld_out, off_out, H, W, C, total);
-    else
-        hipLaunchKernelGGL(dwconv3x3_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float *)in, ld_in,
-                           off_in, weight, bias, silu, (float *)out, ld_out, off_out, H, W, C, total);
+        hipLaunchKernelGGL(dwconv3x3_kernel<bf16>, grid, block, lds, (hipStream_t)stream, (const bf16 *)in, ld_in, off_in,
+                           weight, bias, silu, (bf16 *)out, ld_out, off_out, H, W, C, cblocks);
+    else {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void *)dwconv3x3_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(dwconv3x3_kernel<float>, grid, block, lds, (hipStream_t)stream, (const float *)in, ld_in,
+                           off_in, weight, bias, silu, (float *)out, ld_out, off_out, H, W, C, cblocks);
+    }
     FD_LAUNCH_OK("fd_dwconv3x3");
     return FD_OK;
 }

@@ -29,27 +29,48 @@ __device__ __forceinline__ void scan_pos(const ScanGeom &g, int k, int l, int &l
     pix = (2 * h2 + (k & 1)) * g.W + 2 * w2 + (k >> 1);
 }
 
+// One workgroup = one chunk of one (batch, direction) x up to 4 waves of 64 channels.  The
+// chunk's x_dbl rows (dt_r | B | C, shared by every channel) are staged once in LDS and read
+// back as wave-uniform broadcasts; each lane prefetches U of its u values per group so U
+// global loads are in flight per wave while the recurrence of the previous group runs.
 template <typename T, int N, int R, bool FINAL>
 __global__ __launch_bounds__(256) void scan_chunk_kernel(const T *__restrict__ xc, const float *__restrict__ xdbl,
                                                         const float *__restrict__ dtw, const float *__restrict__ dtb,
                                                         const float *__restrict__ A, const float *__restrict__ Ds,
                                                         T *__restrict__ y, float *__restrict__ wsH,
                                                         float *__restrict__ wsP, const ScanGeom g) {
+    constexpr int CD = R + 2 * N;
+    constexpr int CDP = (CD + 3) & ~3;
+    extern __shared__ __attribute__((aligned(16))) float sx[];      // [CL][CDP]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int dblocks = g.D / 64;
-    const int unit = blockIdx.x * 4 + wave;          // (chunk, dblock)
-    if (unit >= g.nch * dblocks) return;
-    const int chunk = unit / dblocks, db = unit - chunk * dblocks;
+    const int nw = blockDim.x >> 6;
+    const int dgroups = g.D / (64 * nw);
+    const int chunk = blockIdx.x / dgroups, dg = blockIdx.x - chunk * dgroups;
     const int bk = blockIdx.y, b = bk >> 2, k = bk & 3;
-    const int d = db * 64 + lane;
+    const int d = (dg * nw + wave) * 64 + lane;
     const int kd = k * g.D + d;
+    const int l0 = chunk * g.CL;
+    const int l1 = min(l0 + g.CL, g.L);
+    const int odd = k & 1, ph = k & 1, pw = k >> 1;
+    const float *xb = xdbl + ((int64_t)k * g.B + b) * g.L * g.CD;   // [4][B][L][CD]
 
-    float w[R], a[N], h[N];
+    // ---- stage the chunk's rows
+    for (int idx = threadIdx.x; idx < (l1 - l0) * CD; idx += blockDim.x) {
+        const int row = idx / CD, e = idx - row * CD;
+        const int l = l0 + row;
+        int h2, w2;
+        if (odd) { w2 = l / g.H2; h2 = l - w2 * g.H2; }
+        else { h2 = l / g.W2; w2 = l - h2 * g.W2; }
+        sx[row * CDP + e] = xb[(int64_t)(h2 * g.W2 + w2) * CD + e];
+    }
+
+    float w[R], a2[N], h[N];
 #pragma unroll
     for (int r = 0; r < R; ++r) w[r] = dtw[(int64_t)kd * R + r];
+    // exp(dt*A) = exp2(dt * A*log2(e)): fold the constant into A once (v_exp_f32 is exp2)
 #pragma unroll
-    for (int n = 0; n < N; ++n) a[n] = A[(int64_t)kd * N + n];
+    for (int n = 0; n < N; ++n) a2[n] = A[(int64_t)kd * N + n] * 1.4426950408889634f;
     const float bias = dtb[kd];
     const float Dd = FINAL ? Ds[kd] : 0.f;
     const int64_t cbase = (((int64_t)bk * g.nch + chunk) * N) * g.D + d;   // [bk][chunk][n][d]
@@ -61,36 +82,57 @@ __global__ __launch_bounds__(256) void scan_chunk_kernel(const T *__restrict__ x
         for (int n = 0; n < N; ++n) h[n] = 0.f;
     }
     float sdt = 0.f;
-    const int l0 = chunk * g.CL;
-    const int l1 = min(l0 + g.CL, g.L);
-    const float *xb = xdbl + ((int64_t)k * g.B + b) * g.L * g.CD;   // [4][B][L][CD]
     const T *ub = xc + (int64_t)b * g.H * g.W * g.D + d;
     T *yb = FINAL ? y + (int64_t)b * g.H * g.W * g.D + d : nullptr;
-    for (int l = l0; l < l1; ++l) {
-        int lrow, pix;
-        scan_pos(g, k, l, lrow, pix);
-        const float *xr = xb + (int64_t)lrow * g.CD;      // wave-uniform row
-        const float u = ld1(ub + (int64_t)pix * g.D);
+    // scan position -> (h2, w2) kept as scalar counters: no division in the loop
+    int h2, w2;
+    if (odd) { w2 = l0 / g.H2; h2 = l0 - w2 * g.H2; }
+    else { h2 = l0 / g.W2; w2 = l0 - h2 * g.W2; }
+    __syncthreads();
+
+    auto step = [&](const float *xr, float u, int pix) {
         float dv = bias;
 #pragma unroll
         for (int r = 0; r < R; ++r) dv += w[r] * xr[r];
-        const float dt = fd_softplus(dv);
+        const float dt = fd_softplus_fast(dv);
         const float dtu = dt * u;
         if (!FINAL) sdt += dt;
         float acc = 0.f;
 #pragma unroll
         for (int n = 0; n < N; ++n) {
-            const float da = __expf(dt * a[n]);
+            const float da = __builtin_amdgcn_exp2f(dt * a2[n]);
             h[n] = da * h[n] + dtu * xr[R + n];
             if (FINAL) acc += h[n] * xr[R + N + n];
         }
         if (FINAL) st1(yb + (int64_t)pix * g.D, acc + Dd * u);
+    };
+    auto advance = [&](int &pix) {
+        pix = (2 * h2 + ph) * g.W + 2 * w2 + pw;
+        if (odd) { if (++h2 == g.H2) { h2 = 0; ++w2; } }
+        else { if (++w2 == g.W2) { w2 = 0; ++h2; } }
+    };
+    constexpr int U = (N >= 16) ? 4 : 8;   // u values in flight per lane
+    int l = l0;
+    for (; l + U <= l1; l += U) {
+        int pix[U];
+        float u[U];
+#pragma unroll
+        for (int s = 0; s < U; ++s) advance(pix[s]);
+#pragma unroll
+        for (int s = 0; s < U; ++s) u[s] = ld1(ub + (int64_t)pix[s] * g.D);
+#pragma unroll
+        for (int s = 0; s < U; ++s) step(sx + (l - l0 + s) * CDP, u[s], pix[s]);
+    }
+    for (; l < l1; ++l) {
+        int pix;
+        advance(pix);
+        step(sx + (l - l0) * CDP, ld1(ub + (int64_t)pix * g.D), pix);
     }
     if (!FINAL) {
 #pragma unroll
         for (int n = 0; n < N; ++n) {
             wsH[cbase + (int64_t)n * g.D] = h[n];
-            wsP[cbase + (int64_t)n * g.D] = __expf(a[n] * sdt);
+            wsP[cbase + (int64_t)n * g.D] = __builtin_amdgcn_exp2f(a2[n] * sdt);
         }
     }
 }
@@ -133,15 +175,16 @@ void launch_scan(const T *xc, const float *xdbl, const float *dtw, const float *
                  const float *Ds, T *y, float *ws, const ScanGeom &g, hipStream_t s) {
     const int64_t half = (int64_t)g.B * 4 * g.nch * g.N * g.D;
     float *wsH = ws, *wsP = ws + half;
-    const int units = g.nch * (g.D / 64);
-    dim3 grid((units + 3) / 4, g.B * 4), block(256);
-    hipLaunchKernelGGL((scan_chunk_kernel<T, N, R, false>), grid, block, 0, s, xc, xdbl, dtw, dtb, A, Ds, y, wsH, wsP, g);
+    const int nw = g.D >= 256 ? 4 : g.D / 64;          // waves (64-channel groups) per workgroup
+    dim3 grid(g.nch * (g.D / (64 * nw)), g.B * 4), block(64 * nw);
+    const size_t lds = (size_t)g.CL * ((g.CD + 3) & ~3) * sizeof(float);
+    hipLaunchKernelGGL((scan_chunk_kernel<T, N, R, false>), grid, block, lds, s, xc, xdbl, dtw, dtb, A, Ds, y, wsH, wsP, g);
     if (g.nch > 1)
         hipLaunchKernelGGL(scan_carry_kernel, dim3(g.B * 4 * g.N * (g.D / 64)), dim3(64 * SEG), 0, s, wsH, wsP,
                            g.nch, g.N, g.D);
     else
         (void)hipMemsetAsync(wsH, 0, half * sizeof(float), s);
-    hipLaunchKernelGGL((scan_chunk_kernel<T, N, R, true>), grid, block, 0, s, xc, xdbl, dtw, dtb, A, Ds, y, wsH, wsP, g);
+    hipLaunchKernelGGL((scan_chunk_kernel<T, N, R, true>), grid, block, lds, s, xc, xdbl, dtw, dtb, A, Ds, y, wsH, wsP, g);
 }
 
 template <typename T, int N>

@@ -140,7 +140,8 @@ int fd_selective_scan(int dtype, const void *xc, const float *xdbl, const float 
 int fd_chan_attn_nblk(int64_t hw);
 int fd_chan_attn_gram(int dtype, const void *qkv, int B, int64_t hw, int C, float *partial,
                       void *stream);
-int fd_chan_attn_weff(int dtype, const float *partial, int nblk, const float *temperature,
+/* (`partial` is reduced IN PLACE over the pixel blocks: slot 0 of each (b, head) holds the sums) */
+int fd_chan_attn_weff(int dtype, float *partial, int nblk, const float *temperature,
                       const float *wproj /* [C][C] fp32 */, void *weff /* [B][C][C] dtype */,
                       int B, int C, void *stream);
 

@@ -60,7 +60,7 @@ def main():
     tot = sum(r[2] for r in rows)
     print(f"{'#':>3} {'op':58s} {'us':>8s} {'GFLOP':>8s} {'TF/s':>7s} {'MB':>7s} {'GB/s':>7s}")
     for i, d, us, gf, mb in rows:
-        print(f"{i:3d} {d:58s} {us:8.1f} {gf:8.2f} {gf / us * 1e-3 if gf else 0:7.1f} {mb:7.1f} {mb / us * 1e3 if mb else 0:7.0f}")
+        print(f"{i:3d} {d:58s} {us:8.1f} {gf:8.2f} {gf / us * 1e3 if gf else 0:7.1f} {mb:7.1f} {mb / us * 1e3 if mb else 0:7.0f}")
     print(f"total {tot / 1e3:.3f} ms over {len(rows)} launches")
     agg = {}
     for i, d, us, gf, mb in rows:
