@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libfounddiff_hip.so")
 FD_F32, FD_BF16 = 0, 1
 EPI_NONE, EPI_SILU_SPLIT, EPI_RELU, EPI_GATE_RES, EPI_RES_RELU, EPI_GNSILU_ADD = range(6)
 ACT_NONE, ACT_SILU, ACT_GELU, ACT_RELU = range(4)
+PRO_NONE, PRO_LN_MOD, PRO_LN_GATE = range(3)
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -35,6 +36,9 @@ class ConvParams(C.Structure):
         ("gate", vp), ("gate_ld", i32),
         ("h", vp), ("gn_mean_rstd", vp), ("gn_gamma", vp), ("gn_beta", vp), ("gn_groups", i32),
         ("stats_partial", vp),
+        ("prologue", i32), ("ln_eps", f32),
+        ("ln_gamma", vp), ("ln_beta", vp), ("ln_shift", vp), ("ln_scale", vp), ("ln_ld", i32),
+        ("ln_z", vp), ("ln_ldz", i32), ("ln_offz", i32),
     ]
 
 
@@ -44,6 +48,7 @@ SIGNATURES = {
     "fd_last_error": (C.c_char_p, []),
     "fd_conv_mtiles": (i32, [i32, i32]),
     "fd_conv2d": (i32, [C.POINTER(ConvParams), vp]),
+    "fd_conv_prologue_ok": (i32, [C.POINTER(ConvParams)]),
     "fd_gn_finalize": (i32, [vp, i32, i32, i32, i32, i64, f32, vp, vp]),
     "fd_gn_silu_apply": (i32, [i32, vp, vp, vp, vp, vp, vp, i32, i64, i32, i32, vp]),
     "fd_ln_modulate": (i32, [i32, vp, vp, vp, f32, vp, vp, i32, vp, i32, i64, i32, vp]),

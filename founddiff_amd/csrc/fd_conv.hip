@@ -419,6 +419,8 @@ __global__ void gn_silu_apply_kernel(const T *__restrict__ h, const float *__res
 
 extern "C" int fd_conv_mtiles(int OH, int OW) { return cdiv((int64_t)OH * OW, conv_bm((int64_t)OH * OW)); }
 
+int fd_gemm_rows_launch(const fd_conv_params &p, hipStream_t s);
+
 extern "C" int fd_conv2d(const fd_conv_params *pp, void *stream) {
     const fd_conv_params &p = *pp;
     const int CH = p.dtype == FD_BF16 ? 8 : 4;
@@ -437,6 +439,13 @@ extern "C" int fd_conv2d(const fd_conv_params *pp, void *stream) {
     if (p.epilogue == FD_EPI_GNSILU_ADD)
         FD_REQUIRE(p.h && p.gn_mean_rstd && p.gn_gamma && p.gn_beta && p.gn_groups > 0 && p.Cout % p.gn_groups == 0,
                    "fd_conv2d: GNSILU_ADD needs h, statistics, affine and groups | Cout");
+    if (fd_conv_prologue_ok(pp)) {
+        FD_REQUIRE(fd_gemm_rows_launch(p, (hipStream_t)stream) == 0, "fd_conv2d: row-GEMM dispatch failed");
+        FD_LAUNCH_OK("fd_conv2d(row-gemm)");
+        return FD_OK;
+    }
+    FD_REQUIRE(p.prologue == FD_PRO_NONE, "fd_conv2d: fused LN prologue requested for a conv the row-GEMM path "
+                                          "cannot run (check fd_conv_prologue_ok first)");
     FD_REQUIRE((int64_t)p.H * p.W * (p.ld0 > p.ld1 ? p.ld0 : p.ld1) < (1ll << 31),
                "fd_conv2d: one image of a source must hold < 2^31 elements");
     const int mt = fd_conv_mtiles(p.OH, p.OW);

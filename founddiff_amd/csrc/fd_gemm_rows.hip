@@ -1,0 +1,288 @@
+// fd_gemm_rows.hip -- streaming row-GEMM for the 1x1 convolutions / linears of the high-resolution
+// levels (bf16): out[m, :] = epi( W . pro(x[m, :]) ), M = B*H*W huge, K = Cin <= 256, weights tiny.
+//
+// These layers are HBM-bound (arithmetic intensity < 100 FLOP/B), so the kernel is organised
+// around the byte stream, not around a C tile:
+//   * the whole weight matrix lives in LDS for the lifetime of a (persistent) workgroup;
+//   * there is NO LDS staging of activations and NO barrier in the pixel loop: the MFMA is issued
+//     transposed (D^T = W . X^T), whose B operand is "8 consecutive channels of one pixel per
+//     lane" -- exactly a 16-byte global load of the NHWC row -- and whose D layout gives every
+//     lane 4 consecutive output channels of one pixel; two 16-row weight tiles are row-permuted
+//     so that a lane ends up with 8 CONSECUTIVE channels: one 16-byte store, with the residual /
+//     GroupNorm operand fetched by the matching 16-byte load;
+//   * a pixel's K channels sit in 4 lanes (l, l^16, l^32, l^48): LayerNorm statistics for the
+//     fused prologues are two xor-shuffles, so LN+adaLN-modulate (in_proj, qkv) and
+//     out_norm*z+local (out_proj) never round-trip through HBM.
+#include "fd_common.h"
+
+namespace {
+
+__device__ __forceinline__ void unpack8(const bf16x8 &v, float f[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
+}
+__device__ __forceinline__ bf16x8 pack8(const float f[8]) {
+    bf16x8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (bf16)f[i];
+    return v;
+}
+
+// LDS image of W: row n at n*RS bytes, 16-byte chunks XOR-swizzled so that the 16 rows a wave
+// reads per fragment ({8a+b} or {8a+4+b}, a,b in 0..3) fall on distinct bank groups.
+__device__ __forceinline__ int w_off(int row, int chunk, int RS) {
+    const int sw = RS == 128 ? (((row >> 1) & 1) | (((row >> 3) & 3) << 1))
+                             : ((row & 3) | (((row >> 3) & 3) << 2));
+    return row * RS + ((chunk ^ sw) << 4);
+}
+
+template <int KS, int PRO>
+__global__ __launch_bounds__(256) void gemm_rows_kernel(const fd_conv_params p, int wtiles, int RS) {
+    constexpr int K = 32 * KS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int N = p.Cout;
+    unsigned char *sW = smem;
+    float *sV = (float *)(smem + (size_t)N * RS);          // prologue vectors: [3][K]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int b = blockIdx.y;
+    const int64_t hw = (int64_t)p.H * p.W;
+    const bf16 *wg = (const bf16 *)p.weight + (int64_t)b * p.w_batch_stride;
+    // ---- stage W (and the per-channel prologue vectors) once per workgroup
+    for (int idx = tid; idx < N * (K / 8); idx += 256) {
+        const int row = idx / (K / 8), ch = idx - row * (K / 8);
+        *(u32x4 *)(sW + w_off(row, ch, RS)) = *(const u32x4 *)(wg + (int64_t)row * K + ch * 8);
+    }
+    if (PRO == 1) {          // G = gamma (1+scale), Bc = beta (1+scale) + shift
+        for (int c = tid; c < K; c += 256) {
+            const float g = p.ln_gamma ? p.ln_gamma[c] : 1.f, be = p.ln_beta ? p.ln_beta[c] : 0.f;
+            const float sc = 1.f + p.ln_scale[(int64_t)b * p.ln_ld + c], sh = p.ln_shift[(int64_t)b * p.ln_ld + c];
+            sV[c] = g * sc;
+            sV[K + c] = be * sc + sh;
+        }
+    } else if (PRO == 2) {   // gamma, beta, local
+        for (int c = tid; c < K; c += 256) {
+            sV[c] = p.ln_gamma[c];
+            sV[K + c] = p.ln_beta[c];
+            sV[2 * K + c] = p.ln_shift[(int64_t)b * p.ln_ld + c];
+        }
+    }
+    __syncthreads();
+
+    const bf16 *in0 = (const bf16 *)p.in0 + (int64_t)b * hw * p.ld0 + p.off0;
+    const bf16 *in1 = p.in1 ? (const bf16 *)p.in1 + (int64_t)b * hw * p.ld1 + p.off1 : nullptr;
+    const bf16 *zin = PRO == 2 ? (const bf16 *)p.ln_z + (int64_t)b * hw * p.ln_ldz + p.ln_offz : nullptr;
+    bf16 *outp = (bf16 *)p.out + (int64_t)b * hw * p.ldo + p.offo;
+    const bf16 *resp = p.res ? (const bf16 *)p.res + (int64_t)b * hw * p.ld_res + p.off_res : nullptr;
+    const bf16 *hp = p.h ? (const bf16 *)p.h + (int64_t)b * hw * N : nullptr;
+    const int cpg = p.gn_groups > 0 ? N / p.gn_groups : 1;
+
+    auto load_tile = [&](int wt, bf16x8 (&xb)[2][KS], bf16x8 (&zb)[2][KS]) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int64_t m = (int64_t)wt * 32 + 16 * s + fr;
+            const bool ok = m < hw;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int c = ks * 32 + fg * 8;
+                bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (ok) v = c < p.c0 ? *(const bf16x8 *)(in0 + m * p.ld0 + c)
+                                     : *(const bf16x8 *)(in1 + m * p.ld1 + (c - p.c0));
+                xb[s][ks] = v;
+                if (PRO == 2) {
+                    bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (ok) z = *(const bf16x8 *)(zin + m * p.ln_ldz + c);
+                    zb[s][ks] = z;
+                }
+            }
+        }
+    };
+
+    // No software prefetch: the kernel keeps its register footprint small enough for 3-4 waves
+    // per SIMD and lets the other waves' MFMA/store phases cover this wave's load latency.
+    const int wstride = gridDim.x * 4;
+    for (int wt = blockIdx.x * 4 + wave; wt < wtiles; wt += wstride) {
+        bf16x8 xb[2][KS], zb[2][KS];
+        load_tile(wt, xb, zb);
+        if (PRO != 0) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float f[KS][8];
+                float sum = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    unpack8(xb[s][ks], f[ks]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) sum += f[ks][e];
+                }
+                sum += __shfl_xor(sum, 16, 64);
+                sum += __shfl_xor(sum, 32, 64);
+                const float mean = sum * (1.f / K);
+                float q = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const float d = f[ks][e] - mean; q += d * d; }
+                q += __shfl_xor(q, 16, 64);
+                q += __shfl_xor(q, 32, 64);
+                const float rstd = rsqrtf(q * (1.f / K) + p.ln_eps);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int c = ks * 32 + fg * 8;
+                    float g8[8], b8[8];
+                    load8(sV + c, g8);
+                    load8(sV + K + c, b8);
+                    if (PRO == 1) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[ks][e] = (f[ks][e] - mean) * rstd * g8[e] + b8[e];
+                    } else {
+                        float z8[8], l8[8];
+                        unpack8(zb[s][ks], z8);
+                        load8(sV + 2 * K + c, l8);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            f[ks][e] = ((f[ks][e] - mean) * rstd * g8[e] + b8[e]) * z8[e] + l8[e];
+                    }
+                    xb[s][ks] = pack8(f[ks]);
+                }
+            }
+        }
+        const int64_t m0 = (int64_t)wt * 32 + fr, m1 = m0 + 16;
+#pragma unroll 1
+        for (int ng = 0; ng < N / 32; ++ng) {
+            f32x4 acc[2][2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) acc[t][s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int rowa = 32 * ng + 8 * (fr >> 2) + (fr & 3);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 wa = *(const bf16x8 *)(sW + w_off(rowa, ks * 4 + fg, RS));
+                const bf16x8 wb = *(const bf16x8 *)(sW + w_off(rowa + 4, ks * 4 + fg, RS));
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    acc[0][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb[s][ks], acc[0][s], 0, 0, 0);
+                    acc[1][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, xb[s][ks], acc[1][s], 0, 0, 0);
+                }
+            }
+            // lane (pixel fr of subtile s, group fg) holds channels n0 .. n0+7
+            const int n0 = 32 * ng + 8 * fg;
+            float bias[8], ev0[8], ev1[8], ev2[8], ev3[8];
+            if (p.bias) load8(p.bias + n0, bias);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bias[e] = 0.f;
+            }
+            if (p.epilogue == FD_EPI_GATE_RES) load8(p.gate + (int64_t)b * p.gate_ld + n0, ev0);
+            if (p.epilogue == FD_EPI_GNSILU_ADD) {
+                load8(p.gn_gamma + n0, ev0);
+                load8(p.gn_beta + n0, ev1);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int g = (n0 + e) / cpg;
+                    ev2[e] = p.gn_mean_rstd[((int64_t)b * p.gn_groups + g) * 2];
+                    ev3[e] = p.gn_mean_rstd[((int64_t)b * p.gn_groups + g) * 2 + 1];
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int64_t m = s ? m1 : m0;
+                if (m >= hw) continue;
+                float val[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { val[e] = acc[0][s][e] + bias[e]; val[4 + e] = acc[1][s][e] + bias[4 + e]; }
+                if (p.epilogue == FD_EPI_SILU_SPLIT) {
+                    if (n0 >= p.epi_split) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) val[e] = fd_silu(val[e]);
+                    }
+                } else if (p.epilogue == FD_EPI_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) val[e] = fmaxf(val[e], 0.f);
+                } else if (p.epilogue == FD_EPI_GATE_RES || p.epilogue == FD_EPI_RES_RELU) {
+                    float rs[8];
+                    load8(resp + m * p.ld_res + n0, rs);
+                    if (p.epilogue == FD_EPI_GATE_RES) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) val[e] = rs[e] + ev0[e] * val[e];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) val[e] = fmaxf(val[e] + rs[e], 0.f);
+                    }
+                } else if (p.epilogue == FD_EPI_GNSILU_ADD) {
+                    float hv[8];
+                    load8(hp + m * N + n0, hv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) val[e] += fd_silu((hv[e] - ev2[e]) * ev3[e] * ev0[e] + ev1[e]);
+                }
+                store8(outp + m * p.ldo + n0, val);
+            }
+        }
+    }
+}
+
+int row_stride(int K) { return K <= 64 ? 128 : (K <= 128 ? 256 : 512); }
+
+}  // namespace
+
+// 1 if `p` can run on the streaming row-GEMM (and therefore may carry a fused LN prologue).
+extern "C" int fd_conv_prologue_ok(const fd_conv_params *pp) {
+    const fd_conv_params &p = *pp;
+    const int K = p.c0 + p.c1;
+    if (p.dtype != FD_BF16 || p.out_f32) return 0;
+    if (p.KH != 1 || p.KW != 1 || p.stride != 1 || p.pad_h != 0 || p.pad_w != 0 || p.upsample || p.ndir != 1) return 0;
+    if (p.OH != p.H || p.OW != p.W) return 0;
+    if (K % 32 || K > 256 || K == 160 || K == 224 || p.c0 % 8 || p.c1 % 8) return 0;
+    if (p.Cout % 32 || (size_t)p.Cout * row_stride(K) > 128 * 1024) return 0;
+    if (p.stats_partial) return 0;
+    if (p.ldo % 8 || p.offo % 8 || p.ld0 % 8 || p.off0 % 8 || (p.in1 && (p.ld1 % 8 || p.off1 % 8))) return 0;
+    if (p.res && (p.ld_res % 8 || p.off_res % 8)) return 0;
+    if (p.epilogue == FD_EPI_GATE_RES && (p.gate_ld % 4 || ((uintptr_t)p.gate & 15))) return 0;
+    if (p.epilogue == FD_EPI_SILU_SPLIT && p.epi_split % 8) return 0;
+    if (p.bias && ((uintptr_t)p.bias & 15)) return 0;
+    if (p.prologue != FD_PRO_NONE) {
+        if (p.c1 != 0) return 0;
+        if (p.prologue == FD_PRO_LN_GATE && (!p.ln_z || p.ln_ldz % 8 || p.ln_offz % 8 || !p.ln_gamma || !p.ln_beta)) return 0;
+        if (!p.ln_shift || (p.prologue == FD_PRO_LN_MOD && !p.ln_scale)) return 0;
+    }
+    if ((int64_t)p.H * p.W < 32768) return 0;     // few pixels: the tiled kernel parallelises better
+    return 1;
+}
+
+int fd_gemm_rows_launch(const fd_conv_params &p, hipStream_t s) {
+    const int K = p.c0 + p.c1, KS = K / 32, RS = row_stride(K);
+    const int64_t hw = (int64_t)p.H * p.W;
+    const int wtiles = (int)((hw + 31) / 32);
+    const size_t lds = (size_t)p.Cout * RS + 3 * (size_t)K * sizeof(float);
+    int per_cu = (int)(150 * 1024 / lds);
+    if (per_cu > 4) per_cu = 4;
+    if (per_cu < 1) per_cu = 1;
+    int gx = (256 * per_cu + p.B - 1) / p.B;
+    const int need = (wtiles + 3) / 4;
+    if (gx > need) gx = need;
+    dim3 grid(gx, p.B), block(256);
+#define FD_GR(KS_, PRO_)                                                                                           \
+    do {                                                                                                           \
+        if (lds > 64 * 1024)                                                                                       \
+            (void)hipFuncSetAttribute((const void *)gemm_rows_kernel<KS_, PRO_>,                                   \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
+        hipLaunchKernelGGL((gemm_rows_kernel<KS_, PRO_>), grid, block, lds, s, p, wtiles, RS);                     \
+    } while (0)
+#define FD_GR_K(PRO_)                                  \
+    switch (KS) {                                      \
+    case 1: FD_GR(1, PRO_); break;                     \
+    case 2: FD_GR(2, PRO_); break;                     \
+    case 3: FD_GR(3, PRO_); break;                     \
+    case 4: FD_GR(4, PRO_); break;                     \
+    case 6: FD_GR(6, PRO_); break;                     \
+    case 8: FD_GR(8, PRO_); break;                     \
+    default: return -1;                                \
+    }
+    if (p.prologue == FD_PRO_LN_MOD) { FD_GR_K(1) }
+    else if (p.prologue == FD_PRO_LN_GATE) { FD_GR_K(2) }
+    else { FD_GR_K(0) }
+#undef FD_GR_K
+#undef FD_GR
+    return 0;
+}

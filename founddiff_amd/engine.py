@@ -229,7 +229,15 @@ class DAEngine:
              stride=1, pad=None, upsample=False, ndir=1, w_batch_stride=0, w_dir_stride=0, weight=None,
              bias="auto", Cout=None, KH=None, KW=None, ldo=None, offo=0, out_dir_stride=0, out_f32=False,
              epi=L.EPI_NONE, split=0, res=None, ld_res=0, off_res=0, gate=None, gate_ld=0, h=None,
-             gn=None, gamma=None, beta=None, groups=8, stats=None, OH=None, OW=None):
+             gn=None, gamma=None, beta=None, groups=8, stats=None, OH=None, OW=None,
+             prologue=L.PRO_NONE, ln_gamma=None, ln_beta=None, ln_eps=1e-5, ln_shift=None, ln_scale=None,
+             ln_ld=0, ln_z=None, ln_ldz=0, ln_offz=0, probe=False):
+        """One fd_conv2d launch.  `probe=True` only asks the library whether this conv can take the
+        fused LayerNorm prologue (bf16 streaming row-GEMM path) and launches nothing."""
+        def ptr(v):
+            if v is None:
+                return None
+            return v.value if isinstance(v, C.c_void_p) else v.data_ptr()
         p = L.ConvParams()
         KH = KH or cw.KH
         KW = KW or cw.KW
@@ -264,6 +272,12 @@ class DAEngine:
         p.gn_beta = beta.data_ptr() if beta is not None else None
         p.gn_groups = groups
         p.stats_partial = stats.data_ptr() if stats is not None else None
+        p.prologue, p.ln_eps = prologue, ln_eps
+        p.ln_gamma, p.ln_beta = ptr(ln_gamma), ptr(ln_beta)
+        p.ln_shift, p.ln_scale, p.ln_ld = ptr(ln_shift), ptr(ln_scale), ln_ld
+        p.ln_z, p.ln_ldz, p.ln_offz = ptr(ln_z), ln_ldz, ln_offz
+        if probe:
+            return bool(L.lib().fd_conv_prologue_ok(C.byref(p)))
         L.call("fd_conv2d", C.byref(p), self.stream)
         return p.OH, p.OW
 
@@ -305,12 +319,19 @@ class DAEngine:
         mo = m["mod_off"]
         f4 = 4  # bytes per float
         mp = lambda k: C.c_void_p(mod.data_ptr() + (mo + k * Cc) * f4)
-        # --- SS2D branch
-        xm = self._b("xm", (B, H, W, Cc))
-        L.call("fd_ln_modulate", self.dt, _p(x), _p(m["n1w"]), _p(m["n1b"]), 1e-5, mp(0), mp(1), ml, _p(xm),
-               B, hw, Cc, s)
+        # --- SS2D branch.  Where the library's streaming row-GEMM can run the projection (bf16,
+        # high-resolution levels) the LayerNorm+modulate / out_norm*z+local producers are fused into
+        # its operand load; otherwise they run as separate row kernels.
         xz = self._b("xz", (B, H, W, 2 * D))
-        self.conv(m["in_proj"], xm, B, H, W, xz, epi=L.EPI_SILU_SPLIT, split=D)
+        ln1 = dict(prologue=L.PRO_LN_MOD, ln_gamma=m["n1w"], ln_beta=m["n1b"], ln_eps=1e-5, ln_shift=mp(0),
+                   ln_scale=mp(1), ln_ld=ml)
+        if self.conv(m["in_proj"], x, B, H, W, xz, epi=L.EPI_SILU_SPLIT, split=D, probe=True, **ln1):
+            self.conv(m["in_proj"], x, B, H, W, xz, epi=L.EPI_SILU_SPLIT, split=D, **ln1)
+        else:
+            xm = self._b("xm", (B, H, W, Cc))
+            L.call("fd_ln_modulate", self.dt, _p(x), _p(m["n1w"]), _p(m["n1b"]), 1e-5, mp(0), mp(1), ml, _p(xm),
+                   B, hw, Cc, s)
+            self.conv(m["in_proj"], xm, B, H, W, xz, epi=L.EPI_SILU_SPLIT, split=D)
         xc = self._b("xc", (B, H, W, D))
         L.call("fd_dwconv3x3", self.dt, _p(xz), 2 * D, 0, _p(m["dw_w"]), _p(m["dw_b"]), 1, _p(xc), D, 0,
                B, H, W, D, s)
@@ -324,17 +345,27 @@ class DAEngine:
         y = self._b("scan_y", (B, H, W, D))
         L.call("fd_selective_scan", self.dt, _p(xc), _p(xdbl), _p(m["dtw"]), _p(m["dtb"]), _p(m["A"]),
                _p(m["Ds"]), _p(y), _p(ws), B, H, W, D, N, R, s)
-        yz = self._b("yz", (B, H, W, D))
         loc = C.c_void_p(self.local_all.data_ptr() + m["loc_off"] * f4)
-        L.call("fd_ln_gate", self.dt, _p(y), _p(m["onw"]), _p(m["onb"]), 1e-5, _p(xz), 2 * D, D, loc,
-               self.loc_total, _p(yz), B, hw, D, s)
         x1 = self._b(tag + ".x1", (B, H, W, Cc))
-        self.conv(m["out_proj"], yz, B, H, W, x1, epi=L.EPI_GATE_RES, res=x, gate=mp(2), gate_ld=ml)
+        lng = dict(prologue=L.PRO_LN_GATE, ln_gamma=m["onw"], ln_beta=m["onb"], ln_eps=1e-5, ln_shift=loc,
+                   ln_ld=self.loc_total, ln_z=xz, ln_ldz=2 * D, ln_offz=D)
+        ep1 = dict(epi=L.EPI_GATE_RES, res=x, gate=mp(2), gate_ld=ml)
+        if self.conv(m["out_proj"], y, B, H, W, x1, probe=True, **ep1, **lng):
+            self.conv(m["out_proj"], y, B, H, W, x1, **ep1, **lng)
+        else:
+            yz = self._b("yz", (B, H, W, D))
+            L.call("fd_ln_gate", self.dt, _p(y), _p(m["onw"]), _p(m["onb"]), 1e-5, _p(xz), 2 * D, D, loc,
+                   self.loc_total, _p(yz), B, hw, D, s)
+            self.conv(m["out_proj"], yz, B, H, W, x1, **ep1)
         # --- channel attention branch
-        xm2 = self._b("xm", (B, H, W, Cc))
-        L.call("fd_ln_modulate", self.dt, _p(x1), None, None, 1e-6, mp(3), mp(4), ml, _p(xm2), B, hw, Cc, s)
         qkv = self._b("qkv", (B, H, W, 3 * Cc))
-        self.conv(m["qkv"], xm2, B, H, W, qkv)
+        ln2 = dict(prologue=L.PRO_LN_MOD, ln_eps=1e-6, ln_shift=mp(3), ln_scale=mp(4), ln_ld=ml)
+        if self.conv(m["qkv"], x1, B, H, W, qkv, probe=True, **ln2):
+            self.conv(m["qkv"], x1, B, H, W, qkv, **ln2)
+        else:
+            xm2 = self._b("xm", (B, H, W, Cc))
+            L.call("fd_ln_modulate", self.dt, _p(x1), None, None, 1e-6, mp(3), mp(4), ml, _p(xm2), B, hw, Cc, s)
+            self.conv(m["qkv"], xm2, B, H, W, qkv)
         qkv2 = self._b("qkv2", (B, H, W, 3 * Cc))
         L.call("fd_dwconv3x3", self.dt, _p(qkv), 3 * Cc, 0, _p(m["qdw_w"]), None, 0, _p(qkv2), 3 * Cc, 0,
                B, H, W, 3 * Cc, s)

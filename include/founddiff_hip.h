@@ -85,7 +85,25 @@ typedef struct fd_conv_params {
     int32_t gn_groups;
     float *stats_partial;       /* optional: per-(b, m-tile, channel) sum & sumsq of the
                                    stored values, [B][mtiles][Cout][2]; see fd_conv_mtiles    */
+    /* LayerNorm over the Cin channels of in0 fused into the operand load.  Only the bf16
+     * streaming row-GEMM path implements it: ask fd_conv_prologue_ok() first.
+     *   LN_MOD : x' = LN(x)*(1+scale[b]) + shift[b]           src/DADiff.py:450-451,486-487
+     *   LN_GATE: x' = LN(x)*z[m] + local[b]  (shift = local)  src/emamba2.py:365,747-748     */
+    int32_t prologue;
+    float ln_eps;
+    const float *ln_gamma, *ln_beta;   /* [Cin] or NULL (LN_MOD without affine)              */
+    const float *ln_shift, *ln_scale;  /* entries [b*ln_ld + c]                               */
+    int32_t ln_ld;
+    const void *ln_z;                  /* LN_GATE: [B,H,W,ln_ldz], channels [ln_offz, +Cin)   */
+    int32_t ln_ldz, ln_offz;
 } fd_conv_params;
+
+#define FD_PRO_NONE 0
+#define FD_PRO_LN_MOD 1
+#define FD_PRO_LN_GATE 2
+/* 1 if this conv runs on the streaming row-GEMM kernel (1x1, bf16, Cin <= 256, >= 32768 pixels
+ * per image, weights fit LDS) and may therefore carry a fused LN prologue.                    */
+int fd_conv_prologue_ok(const fd_conv_params *p);
 
 int fd_conv_mtiles(int OH, int OW);         /* number of m-tiles per image (for workspaces)  */
 int fd_conv2d(const fd_conv_params *p, void *stream);

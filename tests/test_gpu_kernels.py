@@ -313,3 +313,76 @@ def test_small_fp32_ops(eng_factory):
     L.call("fd_attnpool_core", qd.data_ptr(), T * 3 * Cf, qd.data_ptr(), 3 * Cf, Cf, 2 * Cf, po.data_ptr(), B, T, Cf,
            heads, e.stream)
     assert rel_err(po.cpu(), ref) < 1e-5
+
+
+def test_row_gemm_fused_prologues(eng_factory):
+    """bf16 streaming row-GEMM (1x1 convs of the high-resolution levels) incl. fused LayerNorm
+    prologues, two-source A operand, per-batch weights and every epilogue it serves."""
+    from founddiff_amd import _lib as L
+    from founddiff_amd.engine import ConvW
+    e = eng_factory("bf16")
+    torch.manual_seed(11)
+    B, H, W = 2, 128, 256                       # 32768 pixels per image: row-GEMM territory
+    hw = H * W
+    bf = lambda t: t.to(torch.bfloat16).float()
+
+    def run(cw, x, out, **kw):
+        assert e.conv(cw, x, B, H, W, out, probe=True, **kw), "expected the row-GEMM path"
+        e.conv(cw, x, B, H, W, out, **kw)
+        torch.cuda.synchronize()
+        return out.float().cpu()
+
+    # (1) in_proj: LN + adaLN modulate prologue, SiLU on the z half
+    x = bf(torch.randn(B, hw, 64) * 1.5 + 0.3)
+    w = bf(torch.randn(256, 64) / 8)
+    g, b_ = torch.randn(64), torch.randn(64)
+    mod = torch.randn(B, 6 * 64) * 0.5
+    xd, md, gd, bd = x.cuda().to(torch.bfloat16), mod.cuda(), g.cuda(), b_.cuda()
+    xm = F.layer_norm(x, (64,), g, b_, 1e-5) * (1 + mod[:, None, 64:128]) + mod[:, None, 0:64]
+    ref = F.linear(bf(xm), w)
+    ref[..., 128:] = F.silu(ref[..., 128:])
+    out = torch.empty(B, H, W, 256, device="cuda", dtype=torch.bfloat16)
+    got = run(ConvW(w, None, e.dev, e.tdt), xd, out, epi=L.EPI_SILU_SPLIT, split=128, prologue=L.PRO_LN_MOD,
+              ln_gamma=gd, ln_beta=bd, ln_eps=1e-5, ln_shift=C.c_void_p(md.data_ptr()),
+              ln_scale=C.c_void_p(md.data_ptr() + 64 * 4), ln_ld=6 * 64)
+    assert rel_err(got.reshape(B, hw, 256), ref) < 1.5e-2
+    # (2) out_proj: out_norm(y) * z + local prologue, gated residual epilogue
+    y = bf(torch.randn(B, hw, 128) * 2)
+    xz = bf(torch.randn(B, hw, 256))
+    loc = torch.randn(B, 128)
+    w2 = bf(torch.randn(64, 128) / 11)
+    g2, b2 = torch.randn(128), torch.randn(128)
+    res = bf(torch.randn(B, hw, 64))
+    yz = F.layer_norm(y, (128,), g2, b2, 1e-5) * xz[..., 128:] + loc[:, None]
+    ref = res + mod[:, None, 128:192] * F.linear(bf(yz), w2)
+    yd, xzd, locd, g2d, b2d, resd = (y.cuda().to(torch.bfloat16), xz.cuda().to(torch.bfloat16), loc.cuda(),
+                                     g2.cuda(), b2.cuda(), res.cuda().to(torch.bfloat16))
+    out = torch.empty(B, H, W, 64, device="cuda", dtype=torch.bfloat16)
+    got = run(ConvW(w2, None, e.dev, e.tdt), yd, out, epi=L.EPI_GATE_RES, res=resd,
+              gate=C.c_void_p(md.data_ptr() + 128 * 4), gate_ld=6 * 64, prologue=L.PRO_LN_GATE, ln_gamma=g2d,
+              ln_beta=b2d, ln_eps=1e-5, ln_shift=locd, ln_ld=128, ln_z=xzd, ln_ldz=256, ln_offz=128)
+    assert rel_err(got.reshape(B, hw, 64), ref) < 1.5e-2
+    # (3) res_conv over a concat (128 + 64 -> 128) fused with GroupNorm+SiLU of the 3x3 output
+    a, c = bf(torch.randn(B, hw, 128)), bf(torch.randn(B, hw, 64))
+    w3, bias3 = bf(torch.randn(128, 192) / 14), torch.randn(128)
+    h = bf(torch.randn(B, hw, 128) * 2 + 1)
+    gg, gb = torch.randn(128), torch.randn(128)
+    hv = h.reshape(B, hw, 8, 16).permute(0, 2, 1, 3).reshape(B, 8, -1)
+    mr = torch.stack([hv.mean(-1), torch.rsqrt(hv.var(-1, unbiased=False) + 1e-5)], -1).contiguous()
+    gn = F.group_norm(h.permute(0, 2, 1), 8, gg, gb, 1e-5).permute(0, 2, 1)
+    ref = F.linear(torch.cat((a, c), -1), w3, bias3) + F.silu(gn)
+    ad, cd, hd, mrd, ggd, gbd = (a.cuda().to(torch.bfloat16), c.cuda().to(torch.bfloat16),
+                                 h.cuda().to(torch.bfloat16), mr.cuda(), gg.cuda(), gb.cuda())
+    out = torch.empty(B, H, W, 128, device="cuda", dtype=torch.bfloat16)
+    got = run(ConvW(w3, bias3, e.dev, e.tdt), ad, out, c0=128, in1=cd, c1=64, epi=L.EPI_GNSILU_ADD, h=hd, gn=mrd,
+              gamma=ggd, beta=gbd, groups=8)
+    assert rel_err(got.reshape(B, hw, 128), ref) < 1.5e-2
+    # (4) per-batch weights on a channel slice (attn@v folded with project_out)
+    big = bf(torch.randn(B, hw, 192))
+    wb = bf(torch.randn(B, 64, 64) / 8)
+    ref = res + mod[:, None, 320:384] * torch.einsum("bmk,bnk->bmn", big[..., 128:], wb)
+    bigd, wbd = big.cuda().to(torch.bfloat16), wb.cuda().to(torch.bfloat16)
+    out = torch.empty(B, H, W, 64, device="cuda", dtype=torch.bfloat16)
+    got = run(None, bigd, out, c0=64, ld0=192, off0=128, weight=wbd, w_batch_stride=64 * 64, bias=None, Cout=64,
+              KH=1, KW=1, epi=L.EPI_GATE_RES, res=resd, gate=C.c_void_p(md.data_ptr() + 320 * 4), gate_ld=6 * 64)
+    assert rel_err(got.reshape(B, hw, 64), ref) < 1.5e-2
