@@ -477,3 +477,139 @@ class ResidualDiffusion(nn.Module):
 
     def forward(self, *a, **k):
         raise NotImplementedError("training (p_losses) is out of scope: founddiff_amd is a sampling engine")
+
+
+class _Accel:
+    """Stand-in for the accelerate attributes train.py reads (train.py:162-177)."""
+    is_local_main_process = True
+    is_main_process = True
+
+    def __init__(self, device):
+        self.device = device
+
+    def wait_for_everyone(self):
+        pass
+
+
+class _EMAView:
+    """`trainer.ema.ema_model` of the reference (ema_pytorch wrapper around the diffusion)."""
+
+    def __init__(self, model):
+        self.ema_model = model
+
+    def to(self, device):
+        self.ema_model.to(device)
+        return self
+
+    def load_state_dict(self, sd, strict=False):
+        live = {k[len("ema_model."):]: v for k, v in sd.items() if k.startswith("ema_model.")}
+        return self.ema_model.load_state_dict(live, strict=strict)
+
+
+class Trainer(object):
+    """Sampling harness with the reference Trainer's surface (src/DADiff.py:1506-1966): `load`,
+    `sample`, `test`, `.accelerator.is_local_main_process`, `.results_folder`, `.train_logger`.
+    Training (`train`, `save`) is out of scope.  Unlike the reference (whose datasets glob
+    private paths inside the class), the evaluation dataset is passed in: any object with
+    `__len__`, `__getitem__ -> [ndct, ldct]` ((1,H,W) tensors in [0,1]) and `load_name(i)`."""
+
+    def __init__(self, opt, diffusion_model, folder=None, *, train_batch_size=16, gradient_accumulate_every=1,
+                 augment_flip=True, train_lr=1e-4, train_num_steps=100000, ema_update_every=10, ema_decay=0.995,
+                 adam_betas=(0.9, 0.99), save_and_sample_every=1000, num_samples=25, results_folder=".results/sample",
+                 amp=False, fp16=False, split_batches=True, convert_image_to=None, condition=False, sub_dir=False,
+                 equalizeHist=False, crop_patch=False, generation=False, num_unet=2, checkpoint_folder=None,
+                 is_train=True, train_logger=None, dataset=None, device=None):
+        import logging
+        import os as _os
+        self.opt = opt
+        self.checkpoint_folder = checkpoint_folder or "."
+        self.results_folder = self.checkpoint_folder + "/sample"
+        _os.makedirs(self.results_folder, exist_ok=True)
+        assert int(math.sqrt(num_samples)) ** 2 == num_samples, "number of samples must have an integer square root"
+        self.num_samples = num_samples
+        self.condition = condition
+        self.num_unet = num_unet
+        self.sub_dir, self.crop_patch = sub_dir, crop_patch
+        self.image_size = diffusion_model.image_size
+        self.device = torch.device(device or ("cuda" if torch.cuda.is_available() else "cpu"))
+        self.accelerator = _Accel(self.device)
+        self.model = diffusion_model.to(self.device)
+        self.ema = _EMAView(self.model)      # inference uses the EMA weights (src/DADiff.py:1818-1822)
+        self.sample_dataset = dataset if dataset is not None else folder
+        self.train_logger = train_logger or logging.getLogger("founddiff_amd")
+        self.step = 0
+        self.condition_type = 2
+        self.test_running_psnr, self.test_running_ssim, self.test_running_rmse = [], [], []
+
+    def load(self, milestone):
+        """Read `<ckpt>/sample/model-N.pt` = {'step','model','opt0','ema','scaler'}
+        (src/DADiff.py:1648-1669).  The EMA weights win when present; a missing file is skipped
+        silently like the reference does."""
+        from pathlib import Path
+        path = Path(self.results_folder + "/" + f"model-{milestone}.pt")
+        if not path.exists():
+            return
+        data = torch.load(str(path), map_location="cpu", weights_only=False)
+        self.model.load_state_dict(data["model"], strict=False)
+        self.step = data.get("step", 0)
+        ema = data.get("ema")
+        if ema:
+            live = {k[len("ema_model."):]: v for k, v in ema.items() if k.startswith("ema_model.")}
+            if live:
+                self.model.load_state_dict(live, strict=False)
+        self.model.to(self.device)
+        print("load model - " + str(path))
+
+    def train(self):
+        raise NotImplementedError("founddiff_amd is a sampling engine: training is out of scope")
+
+    save = train
+
+    @torch.no_grad()
+    def sample(self, milestone, last=True, FID=False):
+        """Preview grid of [NDCT, LDCT, x_T, output] in the HU display window
+        (src/DADiff.py:1765-1815) written as `<results>/sample-N.npy`."""
+        from .data import hu_window
+        n = min(self.num_samples, len(self.sample_dataset))
+        items = [self.sample_dataset[i] for i in range(n)]
+        show = [torch.stack([it[j] for it in items]).to(self.device) for j in range(len(items[0]))]
+        outs = list(self.model.sample(show[1:], batch_size=n, last=last))
+        all_images = hu_window(torch.cat(show + outs, dim=0))
+        file_name = f"sample-{milestone}"
+        np.save(self.results_folder + "/" + file_name, all_images.detach().cpu().numpy())
+        print("sampe-save " + file_name)
+        return milestone
+
+    @torch.no_grad()
+    def test(self, sample=False, last=True, FID=False, batch_size=1):
+        """Evaluation loop of src/DADiff.py:1817-1966: init() the schedule, denoise every slice,
+        PSNR/SSIM/RMSE vs NDCT (on device), np.save each output in [0,1].  `batch_size` > 1
+        batches independent slices (the reference uses 1)."""
+        from .metrics import compute_metrics
+        self.model.init()
+        print("test start")
+        self.test_running_psnr, self.test_running_ssim, self.test_running_rmse = [], [], []
+        ds = self.sample_dataset
+        for s in range(0, len(ds), batch_size):
+            idx = list(range(s, min(s + batch_size, len(ds))))
+            items = [ds[i] for i in idx]
+            y = torch.stack([it[0] for it in items]).to(self.device)
+            x = torch.stack([it[1] for it in items]).to(self.device)
+            outs = list(self.model.sample([x], batch_size=len(idx), last=last))
+            y_pred = outs[-1]
+            m = compute_metrics(y_pred, y).cpu().numpy()
+            for j, i in enumerate(idx):
+                file_name = ds.load_name(i, sub_dir=self.sub_dir)
+                self.test_running_psnr.append(m[j, 0])
+                self.test_running_ssim.append(m[j, 1])
+                self.test_running_rmse.append(m[j, 2])
+                print("(psnr: %.4f, ssim: %.4f,rmse:.%.4f) " % (m[j, 0], m[j, 1], m[j, 2]))
+                if not getattr(self.opt, "is_train", False):
+                    h, w = y_pred.shape[-2:]
+                    np.save(self.results_folder + "/" + file_name[:-4], y_pred[j].detach().cpu().numpy().reshape(h, w))
+                    print("test-save " + file_name)
+        self.train_logger.info("test_psnr: {:.4f}, test_ssim: {:.4f},test_rmse:{:.4f}".format(
+            np.mean(self.test_running_psnr), np.mean(self.test_running_ssim), np.mean(self.test_running_rmse)))
+        print("test end")
+        return float(np.mean(self.test_running_psnr)), float(np.mean(self.test_running_ssim)), \
+            float(np.mean(self.test_running_rmse))

@@ -72,6 +72,8 @@ SIGNATURES = {
     "fd_res_predictions": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i64, vp]),
     "fd_res_ddim_step": (i32, [vp, vp, vp, vp, f32, f32, i32, vp, i64, vp]),
     "fd_res_posterior_step": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i64, vp]),
+    "fd_metrics_nblk": (i32, [i32, i32]),
+    "fd_metrics": (i32, [vp, vp, i32, i32, i32, vp, vp, vp]),
     "fd_affine_f32": (i32, [vp, f32, f32, vp, i64, vp]),
     "fd_axpy_f32": (i32, [vp, vp, f32, vp, i64, vp]),
 }

@@ -213,6 +213,13 @@ int fd_res_ddim_step(const float *model_out, const float *img, const float *x_in
 int fd_res_posterior_step(const float *model_out, const float *x_t, const float *x_in,
                           const float *noise, const float *coef, float *img_out,
                           float *x_start_out, int B, int64_t npix, void *stream);
+/* ---- evaluation metrics on device (src/util.py:188-236, used by Trainer.test src/DADiff.py:1883-1885)
+ * pred/target [B,H,W] fp32 in [0,1].  partial: fp32 workspace [B][fd_metrics_nblk(H,W)][2].
+ * out [B][3] = PSNR (max_val 1), SSIM (11x11 Gaussian sigma 1.5, reflect pad, clamp, mean), RMSE. */
+int fd_metrics_nblk(int H, int W);
+int fd_metrics(const float *pred, const float *target, int B, int H, int W, float *partial,
+               float *out, void *stream);
+
 /* out = a*x + b  (normalize_to_neg_one_to_one / unnormalize, src/DADiff.py:109-120)          */
 int fd_affine_f32(const float *x, float a, float b, float *out, int64_t n, void *stream);
 /* out = x + s*noise   (x_T = x_input + sqrt(sum_scale) eps, src/DADiff.py:1294)              */

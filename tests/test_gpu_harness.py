@@ -1,0 +1,74 @@
+"""GPU tests of the evaluation harness either side of the sampling path: device metrics vs the
+CPU oracle, and Trainer.load / test / sample on a reference-format checkpoint."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+TINY_CLIP = dict(layers=(2, 1, 1, 1), width=16, embed_dim=1024)
+
+
+def test_metrics_vs_oracle():
+    from founddiff_amd import metrics, synth
+    from oracle import metrics as om
+    nd, ld = synth.ct_phantom(3, 72, seed=4)          # 72 is not a multiple of the 16-pixel tile
+    a, b = torch.from_numpy(ld), torch.from_numpy(nd)
+    got = metrics.compute_metrics(a.cuda(), b.cuda()).cpu()
+    for i in range(3):
+        assert abs(float(got[i, 0]) - float(om.psnr(a[i:i + 1], b[i:i + 1]))) < 1e-3
+        assert abs(float(got[i, 1]) - float(om.ssim(a[i:i + 1], b[i:i + 1]))) < 1e-5
+        assert abs(float(got[i, 2]) - float(om.rmse(a[i:i + 1], b[i:i + 1]))) < 1e-6
+    assert abs(float(metrics.compute_ssim(a.cuda(), a.cuda())) - 1.0) < 1e-6
+
+
+def test_trainer_load_test_sample(tmp_path):
+    from types import SimpleNamespace
+    from founddiff_amd import arch, synth
+    from founddiff_amd.DADiff import ResidualDiffusion, Trainer, UnetRes
+    from founddiff_amd.data import SyntheticCTDataset
+    from oracle import metrics as om, sampler
+
+    def make():
+        net = UnetRes(dim=32, dim_mults=(1, 2), num_unet=1, condition=True, objective="pred_res",
+                      test_res_or_noise="res", precision="fp32", clip_cfg=TINY_CLIP)
+        return ResidualDiffusion(net, image_size=64, timesteps=1000, sampling_timesteps=2, objective="pred_res",
+                                 loss_type="l2", condition=True, sum_scale=0.01, test_res_or_noise="res")
+    spec = arch.da_unet_spec(32, (1, 2), prefix="model.unet0.", clip=TINY_CLIP)
+    w = synth.synth_state_dict(spec, seed=5)
+    # a checkpoint in the reference's format, incl. dead weight and an EMA copy that must win
+    ck = tmp_path / "ck" / "sample"
+    ck.mkdir(parents=True)
+    stale = {k: torch.zeros_like(v) for k, v in w.items()}
+    ema = {"ema_model." + k: v for k, v in w.items()}
+    ema.update({"online_model." + k: v for k, v in stale.items()})
+    ema["initted"], ema["step"] = torch.tensor(True), torch.tensor(7)
+    stale["perceploss.net.lin0.model.1.weight"] = torch.zeros(1, 64, 1, 1)
+    torch.save({"step": 123, "model": stale, "opt0": {}, "ema": ema, "scaler": None}, ck / "model-400.pt")
+    ds = SyntheticCTDataset(3, 64, seed=2)
+    tr = Trainer(SimpleNamespace(is_train=False), make(), None, num_samples=1, condition=True, num_unet=1,
+                 checkpoint_folder=str(tmp_path / "ck"), is_train=False, dataset=ds)
+    assert tr.accelerator.is_local_main_process
+    tr.load(400)
+    assert tr.step == 123
+    tr.load(999)                                  # missing file: skipped silently
+    torch.manual_seed(3)
+    psnr, ssim, rmse = tr.test(last=True)
+    # same run through the CPU oracle: reproduce the global-generator noise draws
+    torch.manual_seed(3)
+    orc = sampler.ResidualOracle(w, prefix="model.unet0.", sampling_timesteps=2)
+    ps = []
+    for i in range(3):
+        y, x = ds[i]
+        noise = torch.randn((1, 1, 64, 64), device="cuda").cpu()
+        ref = orc.sample(x[None], noise)[-1]
+        out = np.load(os.path.join(tr.results_folder, ds.load_name(i)[:-4] + ".npy"))
+        assert out.shape == (64, 64)
+        assert rel_err(torch.from_numpy(out), ref[0, 0]) < 1e-3
+        ps.append(float(om.psnr(ref, y[None])))
+    assert abs(psnr - float(np.mean(ps))) < 0.05
+    tr.sample(1)
+    assert os.path.exists(os.path.join(tr.results_folder, "sample-1.npy"))

@@ -179,3 +179,21 @@ def test_full_arch_64(golden):
     assert rel_err(orc.unet(xt, xi, tt), g["unet.out"]) < 1e-4
     out = orc.sample(g["x_input"], g["noise0"])
     assert rel_err(out[-1], g["ddim2.out"]) < 2e-4
+
+
+def test_metrics_oracle_vs_scipy():
+    """SSIM restatement (kornia is absent) cross-checked against scipy's reflect-mode correlation."""
+    import numpy as np
+    from scipy import ndimage
+    from founddiff_amd import synth
+    from oracle import metrics as om
+    nd, ld = synth.ct_phantom(1, 48, seed=1)
+    a, b = torch.from_numpy(ld), torch.from_numpy(nd)
+    k = om.gaussian_window().numpy().astype(np.float64)
+    f = lambda x: ndimage.correlate(x.astype(np.float64), k, mode="mirror")
+    x, y = ld[0, 0], nd[0, 0]
+    mu1, mu2 = f(x), f(y)
+    s1, s2, s12 = f(x * x) - mu1 ** 2, f(y * y) - mu2 ** 2, f(x * y) - mu1 * mu2
+    m = ((2 * mu1 * mu2 + 1e-4) * (2 * s12 + 9e-4)) / ((mu1 ** 2 + mu2 ** 2 + 1e-4) * (s1 + s2 + 9e-4))
+    assert abs(float(om.ssim(a, b)) - float(np.clip(m, 0, 1).mean())) < 1e-5
+    assert abs(float(om.psnr(a, b)) - 10 * np.log10(1.0 / np.mean((x - y) ** 2))) < 1e-4
