@@ -72,6 +72,11 @@ SIGNATURES = {
     "fd_res_predictions": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i64, vp]),
     "fd_res_ddim_step": (i32, [vp, vp, vp, vp, f32, f32, i32, vp, i64, vp]),
     "fd_res_posterior_step": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i64, vp]),
+    "fd_gn_film_silu_apply": (i32, [i32, vp, vp, vp, vp, vp, vp, i32, vp, i32, i64, i32, i32, vp]),
+    "fd_chan_ln": (i32, [i32, vp, vp, vp, vp, i64, i32, vp]),
+    "fd_linear_attention": (i32, [i32, vp, i32, i64, i32, vp, vp, vp, vp, i32, vp]),
+    "fd_attention": (i32, [i32, vp, vp, i32, i64, i32, vp]),
+    "fd_lincomb3": (i32, [vp, vp, vp, f32, f32, f32, i32, vp, i64, vp]),
     "fd_metrics_nblk": (i32, [i32, i32]),
     "fd_metrics": (i32, [vp, vp, i32, i32, i32, vp, vp, vp]),
     "fd_affine_f32": (i32, [vp, f32, f32, vp, i64, vp]),

@@ -160,3 +160,67 @@ def is_dead_key(k, unet_prefix="model.unet0."):
     if k.startswith(unet_prefix + "clip_model.") or k.startswith("unet0.clip_model."):
         return True            # the second, never-used CLIP (src/DADiff.py:590)
     return any(m in k for m in DEAD_KEY_MARKERS)
+
+
+def _vresblock(spec, p, cin, cout, time_dim):
+    spec[p + "mlp.1.weight"] = (2 * cout, time_dim)
+    spec[p + "mlp.1.bias"] = (2 * cout,)
+    for blk, ci in (("block1.", cin), ("block2.", cout)):
+        spec[p + blk + "proj.weight"] = (cout, ci, 3, 3)
+        spec[p + blk + "proj.bias"] = (cout,)
+        spec[p + blk + "norm.weight"] = (cout,)
+        spec[p + blk + "norm.bias"] = (cout,)
+    if cin != cout:
+        spec[p + "res_conv.weight"] = (cout, cin, 1, 1)
+        spec[p + "res_conv.bias"] = (cout,)
+
+
+def _vlinattn(spec, p, dim, hidden=128):
+    spec[p + "fn.norm.g"] = (1, dim, 1, 1)
+    spec[p + "fn.fn.to_qkv.weight"] = (3 * hidden, dim, 1, 1)
+    spec[p + "fn.fn.to_out.0.weight"] = (dim, hidden, 1, 1)
+    spec[p + "fn.fn.to_out.0.bias"] = (dim,)
+    spec[p + "fn.fn.to_out.1.g"] = (1, dim, 1, 1)
+
+
+def vanilla_unet_spec(dim=32, dim_mults=(1, 2), channels=1, prefix=""):
+    """Parameters of denoising_diffusion_pytorch.Unet (src/denoising_diffusion_pytorch.py:283-369)."""
+    spec, p, td = {}, prefix, dim * 4
+    spec[p + "init_conv.weight"] = (dim, channels, 7, 7)
+    spec[p + "init_conv.bias"] = (dim,)
+    spec[p + "time_mlp.1.weight"] = (td, dim)
+    spec[p + "time_mlp.1.bias"] = (td,)
+    spec[p + "time_mlp.3.weight"] = (td, td)
+    spec[p + "time_mlp.3.bias"] = (td,)
+    dims = [dim] + [dim * m for m in dim_mults]
+    in_out = list(zip(dims[:-1], dims[1:]))
+    n = len(in_out)
+    for i, (di, do) in enumerate(in_out):
+        q = p + f"downs.{i}."
+        _vresblock(spec, q + "0.", di, di, td)
+        _vresblock(spec, q + "1.", di, di, td)
+        _vlinattn(spec, q + "2.", di)
+        spec[q + "3.weight"] = (do, di, 4, 4) if i < n - 1 else (do, di, 3, 3)
+        spec[q + "3.bias"] = (do,)
+    mid = dims[-1]
+    _vresblock(spec, p + "mid_block1.", mid, mid, td)
+    spec[p + "mid_attn.fn.norm.g"] = (1, mid, 1, 1)
+    spec[p + "mid_attn.fn.fn.to_qkv.weight"] = (384, mid, 1, 1)
+    spec[p + "mid_attn.fn.fn.to_out.weight"] = (mid, 128, 1, 1)
+    spec[p + "mid_attn.fn.fn.to_out.bias"] = (mid,)
+    _vresblock(spec, p + "mid_block2.", mid, mid, td)
+    for i, (di, do) in enumerate(reversed(in_out)):
+        q = p + f"ups.{i}."
+        _vresblock(spec, q + "0.", do + di, do, td)
+        _vresblock(spec, q + "1.", do + di, do, td)
+        _vlinattn(spec, q + "2.", do)
+        if i < n - 1:
+            spec[q + "3.1.weight"] = (di, do, 3, 3)
+            spec[q + "3.1.bias"] = (di,)
+        else:
+            spec[q + "3.weight"] = (di, do, 3, 3)
+            spec[q + "3.bias"] = (di,)
+    _vresblock(spec, p + "final_res_block.", dim * 2, dim, td)
+    spec[p + "final_conv.weight"] = (channels, dim, 1, 1)
+    spec[p + "final_conv.bias"] = (channels,)
+    return spec

@@ -213,6 +213,28 @@ int fd_res_ddim_step(const float *model_out, const float *img, const float *x_in
 int fd_res_posterior_step(const float *model_out, const float *x_t, const float *x_in,
                           const float *noise, const float *coef, float *img_out,
                           float *x_start_out, int B, int64_t npix, void *stream);
+/* ---- vanilla DDPM U-Net extras (src/denoising_diffusion_pytorch.py) -----------------------
+ * fd_gn_film_silu_apply: silu(GN(h)*(1+scale[b]) + shift[b])   Block w/ scale_shift, 190-199, 213-221
+ * fd_chan_ln:            LN over channels * g (+ res)           LayerNorm/PreNorm/Residual, 95-101,127-146
+ * fd_linear_attention:   LinearAttention core (227-255) on qkv [B,hw,3*hidden] (to_qkv output):
+ *     k softmax over pixels, context = k v^T / hw folded with to_out's weight into
+ *     wtot [B][C][hidden] (dtype); q is replaced IN PLACE by softmax_d(q)*scale, so that
+ *     to_out(context^T q) is one fd_conv2d over the q slice with per-batch weights.
+ *     kstats: fp32 [B][hidden][2], ctx: fp32 [B][hidden/32][32][32] workspaces.
+ * fd_attention:          softmax attention, dim_head 32 (257-279): qkv [B,n,3*hidden] -> out [B,n,hidden]
+ * fd_lincomb3:           out = ca*a + cb*b + cc*c (b, c may be NULL), optional clamp to [-1,1]:
+ *     GaussianDiffusion.predict_* / q_posterior / ddim update (523-554, 633-643)              */
+int fd_gn_film_silu_apply(int dtype, const void *h, const float *mean_rstd, const float *gamma,
+                          const float *beta, const float *film_scale, const float *film_shift,
+                          int film_ld, void *out, int B, int64_t hw, int C, int groups, void *stream);
+int fd_chan_ln(int dtype, const void *x, const float *g, const void *res, void *out, int64_t nrows,
+               int C, void *stream);
+int fd_linear_attention(int dtype, void *qkv, int B, int64_t hw, int hidden, const float *wout,
+                        float *kstats, float *ctx, void *wtot, int C, void *stream);
+int fd_attention(int dtype, const void *qkv, void *out, int B, int64_t n, int hidden, void *stream);
+int fd_lincomb3(const float *a, const float *b, const float *c, float ca, float cb, float cc,
+                int clamp, float *out, int64_t n, void *stream);
+
 /* ---- evaluation metrics on device (src/util.py:188-236, used by Trainer.test src/DADiff.py:1883-1885)
  * pred/target [B,H,W] fp32 in [0,1].  partial: fp32 workspace [B][fd_metrics_nblk(H,W)][2].
  * out [B][3] = PSNR (max_val 1), SSIM (11x11 Gaussian sigma 1.5, reflect pad, clamp, mean), RMSE. */
