@@ -36,7 +36,9 @@ __device__ __forceinline__ int w_off(int row, int chunk, int RS) {
     return row * RS + ((chunk ^ sw) << 4);
 }
 
-template <int KS, int PRO>
+// S = 16-pixel subtiles per wave iteration: 2 for K <= 64 (each weight fragment read from LDS feeds
+// two MFMAs), 1 for wider K where two subtiles' operands would halve the occupancy.
+template <int KS, int PRO, int EPI, int S = (KS <= 2 ? 2 : 1)>
 __global__ __launch_bounds__(256) void gemm_rows_kernel(const fd_conv_params p, int wtiles, int RS) {
     constexpr int K = 32 * KS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -77,10 +79,10 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const fd_conv_params p, 
     const bf16 *hp = p.h ? (const bf16 *)p.h + (int64_t)b * hw * N : nullptr;
     const int cpg = p.gn_groups > 0 ? N / p.gn_groups : 1;
 
-    auto load_tile = [&](int wt, bf16x8 (&xb)[2][KS], bf16x8 (&zb)[2][KS]) {
+    auto load_tile = [&](int wt, bf16x8 (&xb)[S][KS]) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int64_t m = (int64_t)wt * 32 + 16 * s + fr;
+        for (int s = 0; s < S; ++s) {
+            const int64_t m = (int64_t)wt * (16 * S) + 16 * s + fr;
             const bool ok = m < hw;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
@@ -89,11 +91,6 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const fd_conv_params p, 
                 if (ok) v = c < p.c0 ? *(const bf16x8 *)(in0 + m * p.ld0 + c)
                                      : *(const bf16x8 *)(in1 + m * p.ld1 + (c - p.c0));
                 xb[s][ks] = v;
-                if (PRO == 2) {
-                    bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-                    if (ok) z = *(const bf16x8 *)(zin + m * p.ln_ldz + c);
-                    zb[s][ks] = z;
-                }
             }
         }
     };
@@ -102,66 +99,74 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const fd_conv_params p, 
     // per SIMD and lets the other waves' MFMA/store phases cover this wave's load latency.
     const int wstride = gridDim.x * 4;
     for (int wt = blockIdx.x * 4 + wave; wt < wtiles; wt += wstride) {
-        bf16x8 xb[2][KS], zb[2][KS];
-        load_tile(wt, xb, zb);
+        bf16x8 xb[S][KS];
+        load_tile(wt, xb);
         if (PRO != 0) {
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                float f[KS][8];
+            for (int s = 0; s < S; ++s) {
+                // three cheap unpack passes instead of one fp32 copy of the row kept live across the
+                // shuffles: the fp32 temporaries are 8 values at a time (register diet -> occupancy)
                 float sum = 0.f;
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    unpack8(xb[s][ks], f[ks]);
+                    float f[8];
+                    unpack8(xb[s][ks], f);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) sum += f[ks][e];
+                    for (int e = 0; e < 8; ++e) sum += f[e];
                 }
                 sum += __shfl_xor(sum, 16, 64);
                 sum += __shfl_xor(sum, 32, 64);
                 const float mean = sum * (1.f / K);
                 float q = 0.f;
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
+                for (int ks = 0; ks < KS; ++ks) {
+                    float f[8];
+                    unpack8(xb[s][ks], f);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { const float d = f[ks][e] - mean; q += d * d; }
+                    for (int e = 0; e < 8; ++e) { const float d = f[e] - mean; q += d * d; }
+                }
                 q += __shfl_xor(q, 16, 64);
                 q += __shfl_xor(q, 32, 64);
                 const float rstd = rsqrtf(q * (1.f / K) + p.ln_eps);
+                const int64_t m = (int64_t)wt * (16 * S) + 16 * s + fr;
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     const int c = ks * 32 + fg * 8;
-                    float g8[8], b8[8];
+                    float f[8], g8[8], b8[8];
+                    unpack8(xb[s][ks], f);
                     load8(sV + c, g8);
                     load8(sV + K + c, b8);
                     if (PRO == 1) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) f[ks][e] = (f[ks][e] - mean) * rstd * g8[e] + b8[e];
+                        for (int e = 0; e < 8; ++e) f[e] = (f[e] - mean) * rstd * g8[e] + b8[e];
                     } else {
                         float z8[8], l8[8];
-                        unpack8(zb[s][ks], z8);
+                        bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                        if (m < hw) z = *(const bf16x8 *)(zin + m * p.ln_ldz + c);
+                        unpack8(z, z8);
                         load8(sV + 2 * K + c, l8);
 #pragma unroll
-                        for (int e = 0; e < 8; ++e)
-                            f[ks][e] = ((f[ks][e] - mean) * rstd * g8[e] + b8[e]) * z8[e] + l8[e];
+                        for (int e = 0; e < 8; ++e) f[e] = ((f[e] - mean) * rstd * g8[e] + b8[e]) * z8[e] + l8[e];
                     }
-                    xb[s][ks] = pack8(f[ks]);
+                    xb[s][ks] = pack8(f);
                 }
             }
         }
-        const int64_t m0 = (int64_t)wt * 32 + fr, m1 = m0 + 16;
+        const int64_t m0 = (int64_t)wt * (16 * S) + fr;
 #pragma unroll 1
         for (int ng = 0; ng < N / 32; ++ng) {
-            f32x4 acc[2][2];
+            f32x4 acc[2][S];
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int s = 0; s < 2; ++s) acc[t][s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int s = 0; s < S; ++s) acc[t][s] = (f32x4){0.f, 0.f, 0.f, 0.f};
             const int rowa = 32 * ng + 8 * (fr >> 2) + (fr & 3);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const bf16x8 wa = *(const bf16x8 *)(sW + w_off(rowa, ks * 4 + fg, RS));
                 const bf16x8 wb = *(const bf16x8 *)(sW + w_off(rowa + 4, ks * 4 + fg, RS));
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
+                for (int s = 0; s < S; ++s) {
                     acc[0][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb[s][ks], acc[0][s], 0, 0, 0);
                     acc[1][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, xb[s][ks], acc[1][s], 0, 0, 0);
                 }
@@ -174,43 +179,43 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const fd_conv_params p, 
 #pragma unroll
                 for (int e = 0; e < 8; ++e) bias[e] = 0.f;
             }
-            if (p.epilogue == FD_EPI_GATE_RES) load8(p.gate + (int64_t)b * p.gate_ld + n0, ev0);
-            if (p.epilogue == FD_EPI_GNSILU_ADD) {
+            if (EPI == FD_EPI_GATE_RES) load8(p.gate + (int64_t)b * p.gate_ld + n0, ev0);
+            if (EPI == FD_EPI_GNSILU_ADD) {
                 load8(p.gn_gamma + n0, ev0);
                 load8(p.gn_beta + n0, ev1);
+                // channels-per-group is a multiple of 8 (checked on the host): one group per vector
+                const int g = n0 / cpg;
+                const float gm = p.gn_mean_rstd[((int64_t)b * p.gn_groups + g) * 2];
+                const float gr = p.gn_mean_rstd[((int64_t)b * p.gn_groups + g) * 2 + 1];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int g = (n0 + e) / cpg;
-                    ev2[e] = p.gn_mean_rstd[((int64_t)b * p.gn_groups + g) * 2];
-                    ev3[e] = p.gn_mean_rstd[((int64_t)b * p.gn_groups + g) * 2 + 1];
-                }
+                for (int e = 0; e < 8; ++e) { ev2[e] = gm; ev3[e] = gr; }
             }
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int64_t m = s ? m1 : m0;
+            for (int s = 0; s < S; ++s) {
+                const int64_t m = m0 + 16 * s;
                 if (m >= hw) continue;
                 float val[8];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { val[e] = acc[0][s][e] + bias[e]; val[4 + e] = acc[1][s][e] + bias[4 + e]; }
-                if (p.epilogue == FD_EPI_SILU_SPLIT) {
+                if (EPI == FD_EPI_SILU_SPLIT) {
                     if (n0 >= p.epi_split) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) val[e] = fd_silu(val[e]);
                     }
-                } else if (p.epilogue == FD_EPI_RELU) {
+                } else if (EPI == FD_EPI_RELU) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) val[e] = fmaxf(val[e], 0.f);
-                } else if (p.epilogue == FD_EPI_GATE_RES || p.epilogue == FD_EPI_RES_RELU) {
+                } else if (EPI == FD_EPI_GATE_RES || EPI == FD_EPI_RES_RELU) {
                     float rs[8];
                     load8(resp + m * p.ld_res + n0, rs);
-                    if (p.epilogue == FD_EPI_GATE_RES) {
+                    if (EPI == FD_EPI_GATE_RES) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) val[e] = rs[e] + ev0[e] * val[e];
                     } else {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) val[e] = fmaxf(val[e] + rs[e], 0.f);
                     }
-                } else if (p.epilogue == FD_EPI_GNSILU_ADD) {
+                } else if (EPI == FD_EPI_GNSILU_ADD) {
                     float hv[8];
                     load8(hp + m * N + n0, hv);
 #pragma unroll
@@ -241,6 +246,9 @@ extern "C" int fd_conv_prologue_ok(const fd_conv_params *pp) {
     if (p.epilogue == FD_EPI_GATE_RES && (p.gate_ld % 4 || ((uintptr_t)p.gate & 15))) return 0;
     if (p.epilogue == FD_EPI_SILU_SPLIT && p.epi_split % 8) return 0;
     if (p.bias && ((uintptr_t)p.bias & 15)) return 0;
+    if (p.epilogue == FD_EPI_GNSILU_ADD && (p.gn_groups <= 0 || (p.Cout / p.gn_groups) % 8)) return 0;
+    if (p.prologue == FD_PRO_LN_MOD && p.epilogue != FD_EPI_NONE && p.epilogue != FD_EPI_SILU_SPLIT) return 0;
+    if (p.prologue == FD_PRO_LN_GATE && p.epilogue != FD_EPI_GATE_RES) return 0;
     if (p.prologue != FD_PRO_NONE) {
         if (p.c1 != 0) return 0;
         if (p.prologue == FD_PRO_LN_GATE && (!p.ln_z || p.ln_ldz % 8 || p.ln_offz % 8 || !p.ln_gamma || !p.ln_beta)) return 0;
@@ -253,7 +261,8 @@ extern "C" int fd_conv_prologue_ok(const fd_conv_params *pp) {
 int fd_gemm_rows_launch(const fd_conv_params &p, hipStream_t s) {
     const int K = p.c0 + p.c1, KS = K / 32, RS = row_stride(K);
     const int64_t hw = (int64_t)p.H * p.W;
-    const int wtiles = (int)((hw + 31) / 32);
+    const int px = KS <= 2 ? 32 : 16;      // pixels per wave iteration (see template parameter S)
+    const int wtiles = (int)((hw + px - 1) / px);
     const size_t lds = (size_t)p.Cout * RS + 3 * (size_t)K * sizeof(float);
     int per_cu = (int)(150 * 1024 / lds);
     if (per_cu > 4) per_cu = 4;
@@ -262,26 +271,38 @@ int fd_gemm_rows_launch(const fd_conv_params &p, hipStream_t s) {
     const int need = (wtiles + 3) / 4;
     if (gx > need) gx = need;
     dim3 grid(gx, p.B), block(256);
-#define FD_GR(KS_, PRO_)                                                                                           \
+#define FD_GR(KS_, PRO_, EPI_)                                                                                     \
     do {                                                                                                           \
         if (lds > 64 * 1024)                                                                                       \
-            (void)hipFuncSetAttribute((const void *)gemm_rows_kernel<KS_, PRO_>,                                   \
+            (void)hipFuncSetAttribute((const void *)gemm_rows_kernel<KS_, PRO_, EPI_>,                             \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
-        hipLaunchKernelGGL((gemm_rows_kernel<KS_, PRO_>), grid, block, lds, s, p, wtiles, RS);                     \
+        hipLaunchKernelGGL((gemm_rows_kernel<KS_, PRO_, EPI_>), grid, block, lds, s, p, wtiles, RS);               \
     } while (0)
-#define FD_GR_K(PRO_)                                  \
+#define FD_GR_K(PRO_, EPI_)                            \
     switch (KS) {                                      \
-    case 1: FD_GR(1, PRO_); break;                     \
-    case 2: FD_GR(2, PRO_); break;                     \
-    case 3: FD_GR(3, PRO_); break;                     \
-    case 4: FD_GR(4, PRO_); break;                     \
-    case 6: FD_GR(6, PRO_); break;                     \
-    case 8: FD_GR(8, PRO_); break;                     \
+    case 1: FD_GR(1, PRO_, EPI_); break;               \
+    case 2: FD_GR(2, PRO_, EPI_); break;               \
+    case 3: FD_GR(3, PRO_, EPI_); break;               \
+    case 4: FD_GR(4, PRO_, EPI_); break;               \
+    case 6: FD_GR(6, PRO_, EPI_); break;               \
+    case 8: FD_GR(8, PRO_, EPI_); break;               \
     default: return -1;                                \
     }
-    if (p.prologue == FD_PRO_LN_MOD) { FD_GR_K(1) }
-    else if (p.prologue == FD_PRO_LN_GATE) { FD_GR_K(2) }
-    else { FD_GR_K(0) }
+    if (p.prologue == FD_PRO_LN_MOD) {
+        if (p.epilogue == FD_EPI_SILU_SPLIT) { FD_GR_K(1, FD_EPI_SILU_SPLIT) } else { FD_GR_K(1, FD_EPI_NONE) }
+    } else if (p.prologue == FD_PRO_LN_GATE) {
+        FD_GR_K(2, FD_EPI_GATE_RES)
+    } else {
+        switch (p.epilogue) {
+        case FD_EPI_NONE: FD_GR_K(0, FD_EPI_NONE) break;
+        case FD_EPI_SILU_SPLIT: FD_GR_K(0, FD_EPI_SILU_SPLIT) break;
+        case FD_EPI_RELU: FD_GR_K(0, FD_EPI_RELU) break;
+        case FD_EPI_GATE_RES: FD_GR_K(0, FD_EPI_GATE_RES) break;
+        case FD_EPI_RES_RELU: FD_GR_K(0, FD_EPI_RES_RELU) break;
+        case FD_EPI_GNSILU_ADD: FD_GR_K(0, FD_EPI_GNSILU_ADD) break;
+        default: return -1;
+        }
+    }
 #undef FD_GR_K
 #undef FD_GR
     return 0;
