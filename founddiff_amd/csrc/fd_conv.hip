@@ -420,6 +420,8 @@ __global__ void gn_silu_apply_kernel(const T *__restrict__ h, const float *__res
 extern "C" int fd_conv_mtiles(int OH, int OW) { return cdiv((int64_t)OH * OW, conv_bm((int64_t)OH * OW)); }
 
 int fd_gemm_rows_launch(const fd_conv_params &p, hipStream_t s);
+int fd_conv3x3_ok(const fd_conv_params &p);
+int fd_conv3x3_launch(const fd_conv_params &p, hipStream_t s);
 
 extern "C" int fd_conv2d(const fd_conv_params *pp, void *stream) {
     const fd_conv_params &p = *pp;
@@ -442,6 +444,11 @@ extern "C" int fd_conv2d(const fd_conv_params *pp, void *stream) {
     if (fd_conv_prologue_ok(pp)) {
         FD_REQUIRE(fd_gemm_rows_launch(p, (hipStream_t)stream) == 0, "fd_conv2d: row-GEMM dispatch failed");
         FD_LAUNCH_OK("fd_conv2d(row-gemm)");
+        return FD_OK;
+    }
+    if (fd_conv3x3_ok(p)) {
+        fd_conv3x3_launch(p, (hipStream_t)stream);
+        FD_LAUNCH_OK("fd_conv2d(3x3 halo)");
         return FD_OK;
     }
     FD_REQUIRE(p.prologue == FD_PRO_NONE, "fd_conv2d: fused LN prologue requested for a conv the row-GEMM path "

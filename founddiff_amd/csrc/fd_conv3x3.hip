@@ -1,0 +1,254 @@
+// fd_conv3x3.hip -- 3x3 / stride-1 / pad-1 convolution (62 % of the denoiser's FLOPs) as a
+// halo-tiled implicit GEMM on MFMA, bf16.
+//
+// The generic kernel (fd_conv.hip) re-fetches the shifted A tile from L2 for each of the 9 taps
+// and pays one global-load latency per K step.  Here a workgroup owns an 8 x 16 pixel output
+// tile; per 64-channel slab it loads the (8+2) x (16+2) halo ONCE into LDS (coalesced 128-byte
+// pixel rows, through the nearest-x2 up-sampling index map and the two-source concat when
+// present) and all 9 taps read their A fragments straight from that halo tile: an MFMA fragment
+// is "16 bytes of one pixel's channel vector", so a tap is just a different pixel offset -- no
+// im2col copy exists anywhere.  Global->LDS traffic for A drops 9x -> 1.4x, the only per-tap
+// traffic is the 8/16 KiB weight tile (L2-resident, register-prefetched one tap ahead), and the
+// next slab's halo is in flight during the current slab's 9 taps.
+// Epilogue = the generic kernel's (LDS-staged accumulators, row-contiguous 16-byte stores,
+// deterministic per-tile GroupNorm partial sums).
+#include "fd_common.h"
+
+namespace {
+
+constexpr int TH = 8, TW = 16, BM = TH * TW;      // output tile (pixels)
+constexpr int HY = TH + 2, HX = TW + 2, HP = HY * HX;   // halo
+constexpr int ROWB = 128;                          // bytes per pixel row of a 64-channel bf16 slab
+constexpr int HL = (HP * 8 + 255) / 256;           // halo 16-byte chunks per thread (6)
+
+__device__ __forceinline__ int swz(int row, int chunk) { return (chunk ^ ((row >> 1) & 7)) << 4; }
+
+template <int BN>
+__global__ __launch_bounds__(256) void conv3x3_halo_kernel(const fd_conv_params p) {
+    constexpr int NB = BN / 32, NT = BN / 32, MT = 4;
+    constexpr int HALO_B = HP * ROWB;                 // 23040
+    constexpr int WT_B = BN * ROWB;
+    constexpr int LOOP_B = HALO_B + 2 * WT_B;      // ONE halo buffer (the next slab waits in registers)
+    constexpr int C_B = BM * BN * 4;
+    constexpr int SM_B = LOOP_B > C_B ? LOOP_B : C_B;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SM_B];
+    __shared__ float s_stat[4][BN][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_x = p.OW / TW;
+    const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
+    const int nt = blockIdx.y, b = blockIdx.z;
+    const int Cin = p.c0 + p.c1, K = 9 * Cin, nslab = Cin / 64;
+    const int Hs = p.OH, Ws = p.OW;                   // conv input grid == output grid (stride 1, pad 1)
+    const bf16 *in0 = (const bf16 *)p.in0 + (int64_t)b * p.H * p.W * p.ld0 + p.off0;
+    const bf16 *in1 = p.in1 ? (const bf16 *)p.in1 + (int64_t)b * p.H * p.W * p.ld1 + p.off1 : nullptr;
+    const bf16 *wgt = (const bf16 *)p.weight;
+
+    // ---- halo loader: chunk ids hid = tid + 256*i -> (halo pixel, 16-byte channel chunk)
+    int hoff[HL];          // element offset of the source pixel inside the image, or -1
+#pragma unroll
+    for (int i = 0; i < HL; ++i) {
+        const int hid = tid + 256 * i;
+        const int hp = hid >> 3;
+        hoff[i] = -1;
+        if (hp < HP) {
+            const int hy = hp / HX, hx = hp - hy * HX;
+            int y = ty0 + hy - 1, x = tx0 + hx - 1;
+            if (y >= 0 && y < Hs && x >= 0 && x < Ws) {
+                if (p.upsample) { y >>= 1; x >>= 1; }
+                hoff[i] = y * p.W + x;
+            }
+        }
+    }
+    u32x4 rh[HL], rb[NB];
+    auto halo_gload = [&](int slab) {
+        const int c = slab * 64 + (tid & 7) * 8;
+        const bf16 *src;
+        int ld, cc;
+        if (c < p.c0) { src = in0; ld = p.ld0; cc = c; }
+        else { src = in1; ld = p.ld1; cc = c - p.c0; }
+#pragma unroll
+        for (int i = 0; i < HL; ++i) {
+            u32x4 v = {0, 0, 0, 0};
+            if (hoff[i] >= 0) v = *(const u32x4 *)(src + (int64_t)hoff[i] * ld + cc);
+            rh[i] = v;
+        }
+    };
+    auto halo_lstore = [&]() {
+        unsigned char *sH = smem;
+#pragma unroll
+        for (int i = 0; i < HL; ++i) {
+            const int hid = tid + 256 * i, hp = hid >> 3;
+            if (hp < HP) *(u32x4 *)(sH + hp * ROWB + swz(hp, tid & 7)) = rh[i];
+        }
+    };
+    // ---- weight tile loader: [BN rows][64 k] of tap t, slab s
+    const int chunk = tid & 7, rbase = tid >> 3;
+    auto w_gload = [&](int slab, int tap) {
+        const int k = tap * Cin + slab * 64 + chunk * 8;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int n = nt * BN + rbase + 32 * i;
+            u32x4 v = {0, 0, 0, 0};
+            if (n < p.Cout) v = *(const u32x4 *)(wgt + (int64_t)n * K + k);
+            rb[i] = v;
+        }
+    };
+    auto w_lstore = [&](int buf) {
+        unsigned char *sB = smem + HALO_B + buf * WT_B;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int r = rbase + 32 * i;
+            *(u32x4 *)(sB + r * ROWB + swz(r, chunk)) = rb[i];
+        }
+    };
+
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fg = lane >> 4;
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    halo_gload(0);
+    w_gload(0, 0);
+    halo_lstore();
+    w_lstore(0);
+    __syncthreads();
+    int wbuf = 0;
+    for (int slab = 0; slab < nslab; ++slab) {
+        if (slab + 1 < nslab) halo_gload(slab + 1);          // in flight during this slab's 9 taps
+        const unsigned char *sH = smem;
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            const bool last_tap = tap == 8;
+            const bool more = !(last_tap && slab + 1 == nslab);
+            if (more) w_gload(last_tap ? slab + 1 : slab, last_tap ? 0 : tap + 1);
+            const unsigned char *sB = smem + HALO_B + wbuf * WT_B;
+            const int kh = tap / 3, kw = tap - kh * 3;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 af[MT], bfr[NT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int ty = 4 * wm + i;                         // m tile = one tile row of 16 pixels
+                    const int hp = (ty + kh) * HX + fr + kw;
+                    af[i] = *(const bf16x8 *)(sH + hp * ROWB + swz(hp, ks * 4 + fg));
+                }
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int r = (BN / 2) * wn + 16 * j + fr;
+                    bfr[j] = *(const bf16x8 *)(sB + r * ROWB + swz(r, ks * 4 + fg));
+                }
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+            if (more) w_lstore(wbuf ^ 1);
+            __syncthreads();
+            if (last_tap && slab + 1 < nslab) {     // every wave is done with this slab's halo
+                halo_lstore();
+                __syncthreads();
+            }
+            wbuf ^= 1;
+        }
+    }
+
+    // ---- stage accumulators, row r = tile pixel (ty = r >> 4, tx = r & 15)
+    float *sC = (float *)smem;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 64 * wm + 16 * i + fg * 4 + e;
+                const int cc = (BN / 2) * wn + 16 * j + fr;
+                sC[r * BN + cc] = acc[i][j][e];
+            }
+    __syncthreads();
+    constexpr int VPR = BN / 8, RPP = 256 / VPR;
+    const int v = tid % VPR, r0 = tid / VPR;
+    const int n0 = nt * BN + v * 8;
+    float bias[8], ssum[8], ssq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        bias[e] = (p.bias && n0 + e < p.Cout) ? p.bias[n0 + e] : 0.f;
+        ssum[e] = ssq[e] = 0.f;
+    }
+    bf16 *outp = (bf16 *)p.out + (int64_t)b * p.OH * p.OW * p.ldo + p.offo;
+    if (n0 < p.Cout) {
+        for (int r = r0; r < BM; r += RPP) {
+            const int y = ty0 + (r >> 4), x = tx0 + (r & 15);
+            float val[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) val[e] = sC[r * BN + v * 8 + e] + bias[e];
+            if (p.epilogue == FD_EPI_RELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) val[e] = fmaxf(val[e], 0.f);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { ssum[e] += val[e]; ssq[e] += val[e] * val[e]; }
+            store8(outp + ((int64_t)y * p.OW + x) * p.ldo + n0, val);
+        }
+    }
+    if (p.stats_partial) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+#pragma unroll
+            for (int o = VPR; o < 64; o <<= 1) {
+                ssum[e] += __shfl_xor(ssum[e], o, 64);
+                ssq[e] += __shfl_xor(ssq[e], o, 64);
+            }
+        }
+        if (lane < VPR) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                s_stat[wave][lane * 8 + e][0] = ssum[e];
+                s_stat[wave][lane * 8 + e][1] = ssq[e];
+            }
+        }
+        __syncthreads();
+        if (tid < BN) {
+            const int n = nt * BN + tid;
+            if (n < p.Cout) {
+                float s = 0.f, q = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) { s += s_stat[w][tid][0]; q += s_stat[w][tid][1]; }
+                float *sp = p.stats_partial + (((int64_t)b * gridDim.x + blockIdx.x) * p.Cout + n) * 2;
+                sp[0] = s;
+                sp[1] = q;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// 1 if `p` runs on the halo-tiled 3x3 kernel.
+int fd_conv3x3_ok(const fd_conv_params &p) {
+    const int Cin = p.c0 + p.c1;
+    if (p.dtype != FD_BF16 || p.out_f32 || p.ndir != 1) return 0;
+    if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad_h != 1 || p.pad_w != 1) return 0;
+    if (p.epilogue != FD_EPI_NONE && p.epilogue != FD_EPI_RELU) return 0;
+    if (p.prologue != FD_PRO_NONE) return 0;
+    if (Cin % 64 || p.c0 % 64 || p.Cout % 8) return 0;
+    if (p.ld0 % 8 || p.off0 % 8 || (p.in1 && (p.ld1 % 8 || p.off1 % 8)) || p.ldo % 8 || p.offo % 8) return 0;
+    if (p.OH % TH || p.OW % TW) return 0;
+    if (p.OH != (p.upsample ? 2 * p.H : p.H) || p.OW != (p.upsample ? 2 * p.W : p.W)) return 0;
+    // only where fd_conv_mtiles() counts 128-pixel tiles (GroupNorm partial layout must match) --
+    // at <= 16384 pixels per image the 64-row generic tile fills the chip better anyway
+    if ((int64_t)p.OH * p.OW <= 16384) return 0;
+    if ((int64_t)p.H * p.W * (p.ld0 > p.ld1 ? p.ld0 : p.ld1) >= (1ll << 31)) return 0;
+    return 1;
+}
+
+int fd_conv3x3_launch(const fd_conv_params &p, hipStream_t s) {
+    const bool wide = p.Cout > 64;
+    dim3 grid((p.OH / TH) * (p.OW / TW), cdiv(p.Cout, wide ? 128 : 64), p.B), block(256);
+    if (wide) hipLaunchKernelGGL(conv3x3_halo_kernel<128>, grid, block, 0, s, p);
+    else hipLaunchKernelGGL(conv3x3_halo_kernel<64>, grid, block, 0, s, p);
+    return 0;
+}
