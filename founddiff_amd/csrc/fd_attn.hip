@@ -12,7 +12,9 @@
 
 namespace {
 
-constexpr int PB = 1024;    // pixels per block
+// pixels per Gram block: 1024 for big images, 256 for small ones so the low-resolution levels
+// still spread over the chip (a function of the image size only -> batch-invariant results)
+__host__ __device__ inline int gram_pb(int64_t hw) { return hw >= 65536 ? 1024 : 256; }
 constexpr int LDP = 48;     // LDS row stride in floats (32 channels + pad: conflict-free b32 reads)
 
 template <typename T>
@@ -23,6 +25,7 @@ __global__ __launch_bounds__(256) void gram_kernel(const T *__restrict__ qkv, in
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int blk = blockIdx.x, head = blockIdx.y, b = blockIdx.z, heads = gridDim.y;
     const int pr = tid >> 2, cv = tid & 3;
+    const int PB = gram_pb(hw);
     const int64_t p0 = (int64_t)blk * PB;
     const int64_t p1 = min(p0 + PB, hw);
     const T *base = qkv + (int64_t)b * hw * 3 * C;
@@ -133,7 +136,9 @@ __global__ __launch_bounds__(256) void weff_kernel(const float *__restrict__ par
         for (int j = 0; j < 32; ++j) sG[tid * 33 + j] = row[j] * inv;
     }
     __syncthreads();
-    for (int idx = tid; idx < C * 32; idx += 256) {
+    // 64 output rows per workgroup (blockIdx.z): C/64 workgroups per (head, batch)
+    const int o0 = blockIdx.z * 64, o1 = min(o0 + 64, C);
+    for (int idx = o0 * 32 + tid; idx < o1 * 32; idx += 256) {
         const int o = idx >> 5, j = idx & 31;
         float s = 0.f;
 #pragma unroll
@@ -185,7 +190,7 @@ __global__ __launch_bounds__(256) void attnpool_core_kernel(const float *__restr
 
 }  // namespace
 
-extern "C" int fd_chan_attn_nblk(int64_t hw) { return (int)((hw + PB - 1) / PB); }
+extern "C" int fd_chan_attn_nblk(int64_t hw) { return (int)((hw + gram_pb(hw) - 1) / gram_pb(hw)); }
 
 extern "C" int fd_chan_attn_gram(int dtype, const void *qkv, int B, int64_t hw, int C, float *partial, void *stream) {
     FD_REQUIRE(qkv && partial, "fd_chan_attn_gram: null pointer");
@@ -203,7 +208,7 @@ extern "C" int fd_chan_attn_gram(int dtype, const void *qkv, int B, int64_t hw, 
 extern "C" int fd_chan_attn_weff(int dtype, float *partial, int nblk, const float *temperature,
                                  const float *wproj, void *weff, int B, int C, void *stream) {
     FD_REQUIRE(partial && temperature && wproj && weff && C % 32 == 0, "fd_chan_attn_weff: bad args");
-    dim3 grid(C / 32, B), block(256);
+    dim3 grid(C / 32, B, (C + 63) / 64), block(256);
     if (nblk > 1)
         hipLaunchKernelGGL(gram_reduce_kernel, dim3(17, B * (C / 32)), dim3(256), 0, (hipStream_t)stream, partial, nblk);
     if (dtype == FD_BF16)

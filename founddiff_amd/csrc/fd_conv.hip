@@ -356,23 +356,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const fd_conv_params p)
     }
 }
 
-__global__ void gn_finalize_kernel(const float *__restrict__ part, int mtiles, int C, int groups,
-                                   double inv_cnt, float eps, float *__restrict__ mean_rstd) {
+__global__ __launch_bounds__(1024) void gn_finalize_kernel(const float *__restrict__ part, int mtiles, int C, int groups,
+                                                        double inv_cnt, float eps, float *__restrict__ mean_rstd) {
+    // one workgroup of 1024 threads per (batch, group); float2 loads, fixed reduction order
     const int b = blockIdx.x / groups, g = blockIdx.x % groups;
     const int cpg = C / groups;
     double s = 0.0, q = 0.0;
     const int total = mtiles * cpg;
-    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+    for (int i = threadIdx.x; i < total; i += 1024) {
         int t = i / cpg, c = g * cpg + i % cpg;
-        const float *pp = part + (((int64_t)b * mtiles + t) * C + c) * 2;
-        s += pp[0];
-        q += pp[1];
+        const float2 pp = *(const float2 *)(part + (((int64_t)b * mtiles + t) * C + c) * 2);
+        s += pp.x;
+        q += pp.y;
     }
-    __shared__ double sh[2][256];
+    __shared__ double sh[2][1024];
     sh[0][threadIdx.x] = s;
     sh[1][threadIdx.x] = q;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
+    for (int o = 512; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) {
             sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
             sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
@@ -476,7 +477,7 @@ extern "C" int fd_gn_finalize(const float *stats_partial, int B, int mtiles, int
                               int64_t hw, float eps, float *mean_rstd, void *stream) {
     FD_REQUIRE(stats_partial && mean_rstd && groups > 0 && C % groups == 0, "fd_gn_finalize: bad args");
     double inv = 1.0 / ((double)hw * (C / groups));
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(1024), 0, (hipStream_t)stream,
                        stats_partial, mtiles, C, groups, inv, eps, mean_rstd);
     FD_LAUNCH_OK("fd_gn_finalize");
     return FD_OK;
