@@ -49,6 +49,7 @@ SIGNATURES = {
     "fd_conv_mtiles": (i32, [i32, i32]),
     "fd_conv2d": (i32, [C.POINTER(ConvParams), vp]),
     "fd_conv_prologue_ok": (i32, [C.POINTER(ConvParams)]),
+    "fd_conv_kernel_id": (i32, [C.POINTER(ConvParams)]),
     "fd_gn_finalize": (i32, [vp, i32, i32, i32, i32, i64, f32, vp, vp]),
     "fd_gn_silu_apply": (i32, [i32, vp, vp, vp, vp, vp, vp, i32, i64, i32, i32, vp]),
     "fd_ln_modulate": (i32, [i32, vp, vp, vp, f32, vp, vp, i32, vp, i32, i64, i32, vp]),

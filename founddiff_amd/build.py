@@ -14,6 +14,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fno-slp-vector
          "-I" + os.path.join(HERE, "..", "include")]
 
 
+# -fno-slp-vectorize is the default (packed-f32 + ds_bpermute run-to-run differences);
+# files listed here contain no cross-lane traffic fed by packed math and profit from v_pk_*_f32.
+SLP_OK = set()
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -32,7 +37,8 @@ def build(force=False, verbose=False):
         o = os.path.join(objdir, os.path.basename(s) + ".o")
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            jobs.append([HIPCC] + FLAGS + ["-c", s, "-o", o])
+            flags = [f for f in FLAGS if not (f == "-fno-slp-vectorize" and os.path.basename(s) in SLP_OK)]
+            jobs.append([HIPCC] + flags + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

@@ -28,6 +28,14 @@ void fd_set_error(const char *fmt, ...);
         }                                                                      \
     } while (0)
 
+// bf16-mode softplus: log(1 + e) directly.  For e < 0.018 the rounding of 1 + e costs up to 4e-4 relative
+// in a dt that is itself < 0.018 -- far below the bf16 resolution of the activations it multiplies.
+__device__ __forceinline__ float fd_softplus_bf16(float x) {
+    const float e = __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
+    const float lg = __builtin_amdgcn_logf(1.0f + e) * 0.6931471805599453f;
+    return x > 20.0f ? x : lg;
+}
+
 template <typename T> struct TT;
 template <> struct TT<float> { static constexpr int CH = 4; };   // elements per 16-byte chunk
 template <> struct TT<bf16> { static constexpr int CH = 8; };

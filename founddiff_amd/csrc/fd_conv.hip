@@ -424,6 +424,15 @@ int fd_gemm_rows_launch(const fd_conv_params &p, hipStream_t s);
 int fd_conv3x3_ok(const fd_conv_params &p);
 int fd_conv3x3_launch(const fd_conv_params &p, hipStream_t s);
 
+// Which kernel fd_conv2d dispatches `p` to: 10 streaming row-GEMM, 11 halo-tiled 3x3, else the
+// implicit-GEMM tile variant 0 <128,128>, 1 <128,64>, 2 <64,128>, 3 <64,64>  (BM, BN).
+extern "C" int fd_conv_kernel_id(const fd_conv_params *pp) {
+    if (fd_conv_prologue_ok(pp)) return 10;
+    if (fd_conv3x3_ok(*pp)) return 11;
+    const bool wide = pp->Cout > 64, tall = conv_bm((int64_t)pp->OH * pp->OW) == 128;
+    return (tall ? 0 : 2) + (wide ? 0 : 1);
+}
+
 extern "C" int fd_conv2d(const fd_conv_params *pp, void *stream) {
     const fd_conv_params &p = *pp;
     const int CH = p.dtype == FD_BF16 ? 8 : 4;

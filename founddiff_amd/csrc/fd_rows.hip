@@ -94,13 +94,13 @@ int launch_ln(const T *x, const float *gamma, const float *beta, float eps, cons
     return FD_OK;
 }
 
-// depthwise 3x3, pad 1, LDS-tiled: a workgroup owns an 8 x 32 pixel tile x 64 channels.  The
-// (8+2) x (32+2) halo tile is read from HBM once (coalesced 128-byte pixel rows) into LDS; a
+// depthwise 3x3, pad 1, LDS-tiled: a workgroup owns an 8 x 16 pixel tile x 64 channels.  The
+// (8+2) x (16+2) halo tile is read from HBM once (coalesced 128-byte pixel rows) into LDS; a
 // thread owns one 8-channel vector of one tile column, keeps its 9 tap vectors in registers and
 // walks down the 8 rows reading 9 LDS vectors per output (a wave reads 1 KiB contiguous: no
 // bank conflicts).  HBM traffic = 1.33x input (halo) + output instead of relying on L1/L2 for
 // the 9x tap reuse.
-constexpr int DW_TY = 8, DW_TX = 32, DW_CB = 64;
+constexpr int DW_TY = 8, DW_TX = 16, DW_CB = 64;
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(const T *__restrict__ in, int ld_in, int off_in,
                                                        const float *__restrict__ w, const float *__restrict__ bias,
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const T *__restrict__ in
         }
         *(u32x4 *)(tile + (int64_t)pxl * DW_CB + v * 8) = val;
     }
-    const int cv = tid & 7, px = tid >> 3;
+    const int cv = tid & 7, px = (tid >> 3) & 15, rhalf = tid >> 7;   // 2 row halves x 16 columns x 8 vectors
     const int c0 = cbase + cv * 8;
     float wt[9][8], bs[8];
     const bool cok = c0 < C;
@@ -153,7 +153,8 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const T *__restrict__ in
     const int x = x0 + px;
     if (x >= W || !cok) return;
 #pragma unroll
-    for (int r = 0; r < DW_TY; ++r) {
+    for (int rr = 0; rr < DW_TY / 2; ++rr) {
+        const int r = rhalf * (DW_TY / 2) + rr;
         const int y = y0 + r;
         if (y >= H) break;
         float acc[8];

@@ -82,8 +82,10 @@ __global__ __launch_bounds__(256) void scan_chunk_kernel(const T *__restrict__ x
         for (int n = 0; n < N; ++n) h[n] = 0.f;
     }
     float sdt = 0.f;
-    const T *ub = xc + (int64_t)b * g.H * g.W * g.D + d;
-    T *yb = FINAL ? y + (int64_t)b * g.H * g.W * g.D + d : nullptr;
+    // wave-uniform row base + per-lane channel index: the row address stays on the scalar unit and the
+    // loads/stores use the (sgpr base, vgpr offset) form -- no 64-bit vector address math per step
+    const T *ub = xc + (int64_t)b * g.H * g.W * g.D;
+    T *yb = FINAL ? y + (int64_t)b * g.H * g.W * g.D : nullptr;
     // scan position -> (h2, w2) kept as scalar counters: no division in the loop
     int h2, w2;
     if (odd) { w2 = l0 / g.H2; h2 = l0 - w2 * g.H2; }
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(256) void scan_chunk_kernel(const T *__restrict__ x
         float dv = bias;
 #pragma unroll
         for (int r = 0; r < R; ++r) dv += w[r] * xr[r];
-        const float dt = fd_softplus_fast(dv);
+        const float dt = sizeof(T) == 2 ? fd_softplus_bf16(dv) : fd_softplus_fast(dv);
         const float dtu = dt * u;
         if (!FINAL) sdt += dt;
         float acc = 0.f;
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(256) void scan_chunk_kernel(const T *__restrict__ x
             h[n] = da * h[n] + dtu * xr[R + n];
             if (FINAL) acc += h[n] * xr[R + N + n];
         }
-        if (FINAL) st1(yb + (int64_t)pix * g.D, acc + Dd * u);
+        if (FINAL) st1(yb + (int64_t)pix * g.D + d, acc + Dd * u);
     };
     auto advance = [&](int &pix) {
         pix = (2 * h2 + ph) * g.W + 2 * w2 + pw;
@@ -119,14 +121,14 @@ __global__ __launch_bounds__(256) void scan_chunk_kernel(const T *__restrict__ x
 #pragma unroll
         for (int s = 0; s < U; ++s) advance(pix[s]);
 #pragma unroll
-        for (int s = 0; s < U; ++s) u[s] = ld1(ub + (int64_t)pix[s] * g.D);
+        for (int s = 0; s < U; ++s) u[s] = ld1(ub + (int64_t)pix[s] * g.D + d);
 #pragma unroll
         for (int s = 0; s < U; ++s) step(sx + (l - l0 + s) * CDP, u[s], pix[s]);
     }
     for (; l < l1; ++l) {
         int pix;
         advance(pix);
-        step(sx + (l - l0) * CDP, ld1(ub + (int64_t)pix * g.D), pix);
+        step(sx + (l - l0) * CDP, ld1(ub + (int64_t)pix * g.D + d), pix);
     }
     if (!FINAL) {
 #pragma unroll
