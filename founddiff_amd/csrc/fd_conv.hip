@@ -15,6 +15,7 @@
 // The accumulators are staged through LDS so the epilogue works on row-contiguous 8-channel
 // vectors: 16/32-byte stores, vector loads of the residual / GroupNorm operand, and
 // per-channel partial sums for the next GroupNorm.
+#include <stdlib.h>
 #include "fd_common.h"
 
 namespace {
@@ -35,18 +36,30 @@ template <> struct Frag<float> {
 
 __device__ __forceinline__ int swz(int row, int chunk) { return (chunk ^ ((row >> 1) & 7)) << 4; }
 
-template <typename T, int BM, int BN>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const fd_conv_params p) {
-    constexpr int MT = BM / 32;   // 16-row m tiles per wave == A rows per loading thread
+// WM x WN waves per workgroup, each owning a (BM/WM) x (BN/WN) sub-tile.  Configurations built:
+//   <128,128,2,2> <128,64,2,2>   big images (> 16384 pixels)
+//   <64,128,2,2>  <64,64,2,2>    small images, Cout < 256
+//   <128,256,2,4>                small images, Cout >= 256: 8 waves, 64x64 per wave -- the dense layers of the
+//                                64x64 / 128x128 levels re-read their operands from beyond L2 (weights up to
+//                                7 MB, A up to 450 MB per launch at batch 8): bytes per FLOP scale with
+//                                1/BM + 1/BN, so the larger tile halves that traffic.
+// GroupNorm partial sums are always written per 64-row band (one epilogue pass per wave row), so the
+// workspace layout [B][ceil(OHW/64)..] does not depend on the tile height.
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const fd_conv_params p) {
+    constexpr int NTHR = 64 * WM * WN, NWAVE = WM * WN;
+    constexpr int RPL = NTHR / 8;            // tile rows covered by one loader pass (8 chunks per row)
+    constexpr int AR = BM / RPL, NB = BN / RPL;
+    constexpr int TMW = BM / WM, TNW = BN / WN;
+    constexpr int MT = TMW / 16, NT = TNW / 16;
     constexpr int CH = TT<T>::CH;
     constexpr int BK = ROWB / (int)sizeof(T);
-    constexpr int NB = BN / 32;   // B rows per loading thread
-    constexpr int NT = BN / 32;   // 16-wide n tiles per wave
     constexpr int AB_BYTES = 2 * (BM + BN) * ROWB;
-    constexpr int C_BYTES = BM * BN * 4;
+    constexpr int C_BYTES = TMW * BN * 4;    // accumulators are staged one wave-row (TMW rows) at a time
     constexpr int SM_BYTES = AB_BYTES > C_BYTES ? AB_BYTES : C_BYTES;
+    static_assert(TMW == 64 || (BM == 64 && TMW == 32), "GroupNorm partials are written per 64-row band");
     __shared__ __attribute__((aligned(16))) unsigned char smem[SM_BYTES];
-    __shared__ float s_stat[4][BN][2];
+    __shared__ float s_stat[NWAVE][BN][2];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -64,10 +77,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const fd_conv_params p)
 
     // ---- loader roles
     const int chunk = tid & 7, rbase = tid >> 3;
-    int ihb[MT], iwb[MT];
+    int ihb[AR], iwb[AR];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        int m = mt * BM + rbase + 32 * i;
+    for (int i = 0; i < AR; ++i) {
+        int m = mt * BM + rbase + RPL * i;
         if (m < OHW) {
             int oh = m / p.OW, ow = m - oh * p.OW;
             ihb[i] = oh * p.stride - pad_h;
@@ -77,7 +90,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const fd_conv_params p)
             iwb[i] = 0;
         }
     }
-    u32x4 ra[MT], rb[NB];
+    u32x4 ra[AR], rb[NB];
     const int nkt = (K + BK - 1) / BK;
 
     // (kh, kw, channel base) of the next K tile, kept as wave-uniform counters: when the tile
@@ -107,7 +120,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const fd_conv_params p)
         if (c < p.c0) { src = in0b; ld = p.ld0; coff = p.off0 + c; }
         else { src = in1b; ld = p.ld1; coff = p.off1 + c - p.c0; }
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
+        for (int i = 0; i < AR; ++i) {
             int ih = ihb[i] + kh, iw = iwb[i] + kw;
             bool ok = kv && ih >= 0 && ih < Hs && iw >= 0 && iw < Ws;
             if (p.upsample) { ih >>= 1; iw >>= 1; }
@@ -117,7 +130,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const fd_conv_params p)
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            int n = nt * BN + rbase + 32 * i;
+            int n = nt * BN + rbase + RPL * i;
             u32x4 v = {0, 0, 0, 0};
             if (kv && n < p.Cout) v = *(const u32x4 *)(wgt + (int64_t)n * K + k);
             rb[i] = v;
@@ -132,19 +145,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const fd_conv_params p)
         unsigned char *sA = smem + buf * (BM + BN) * ROWB;
         unsigned char *sB = sA + BM * ROWB;
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            int r = rbase + 32 * i;
+        for (int i = 0; i < AR; ++i) {
+            int r = rbase + RPL * i;
             *(u32x4 *)(sA + r * ROWB + swz(r, chunk)) = ra[i];
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            int r = rbase + 32 * i;
+            int r = rbase + RPL * i;
             *(u32x4 *)(sB + r * ROWB + swz(r, chunk)) = rb[i];
         }
     };
 
     // ---- compute roles
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int fr = lane & 15, fg = lane >> 4;
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -163,15 +176,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const fd_conv_params p)
 #pragma unroll
         for (int ks = 0; ks < Frag<T>::KSTEPS; ++ks) {
             if constexpr (sizeof(T) == 2) {
-                bf16x8 af[4], bfr[NT];
+                bf16x8 af[MT], bfr[NT];
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
-                    int r = (BM / 2) * wm + 16 * i + fr;
+                    int r = TMW * wm + 16 * i + fr;
                     af[i] = *(const bf16x8 *)(sA + r * ROWB + swz(r, ks * 4 + fg));
                 }
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
-                    int r = (BN / 2) * wn + 16 * j + fr;
+                    int r = TNW * wn + 16 * j + fr;
                     bfr[j] = *(const bf16x8 *)(sB + r * ROWB + swz(r, ks * 4 + fg));
                 }
 #pragma unroll
@@ -182,16 +195,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const fd_conv_params p)
             } else {
                 // f32: lane group fg owns k = 8*fg .. 8*fg+7 of the 32-wide step; MFMA step e
                 // contracts the k-set {8g + e}: any consistent A/B k-permutation is a valid sum.
-                f32x4 a0[4], a1[4], b0[NT], b1[NT];
+                f32x4 a0[MT], a1[MT], b0[NT], b1[NT];
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
-                    int r = (BM / 2) * wm + 16 * i + fr;
+                    int r = TMW * wm + 16 * i + fr;
                     a0[i] = *(const f32x4 *)(sA + r * ROWB + swz(r, 2 * fg));
                     a1[i] = *(const f32x4 *)(sA + r * ROWB + swz(r, 2 * fg + 1));
                 }
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
-                    int r = (BN / 2) * wn + 16 * j + fr;
+                    int r = TNW * wn + 16 * j + fr;
                     b0[j] = *(const f32x4 *)(sB + r * ROWB + swz(r, 2 * fg));
                     b1[j] = *(const f32x4 *)(sB + r * ROWB + swz(r, 2 * fg + 1));
                 }
@@ -215,23 +228,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const fd_conv_params p)
         __syncthreads();
     }
 
-    // ---- stage accumulators: sC[row][col] f32, row-major BN floats per row
-    float *sC = (float *)smem;
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                int r = (BM / 2) * wm + 16 * i + fg * 4 + e;
-                int cc = (BN / 2) * wn + 16 * j + fr;
-                sC[r * BN + cc] = acc[i][j][e];
-            }
-    __syncthreads();
-
-    // ---- epilogue on 8-channel vectors
+    // ---- epilogue on 8-channel vectors, one wave row (TMW tile rows) per pass through LDS
     constexpr int VPR = BN / 8;          // vectors per row
-    constexpr int RPP = 256 / VPR;       // rows per pass
+    constexpr int RPP = NTHR / VPR;      // rows per pass step
+    static_assert(VPR <= 64 && (VPR & (VPR - 1)) == 0, "vector column groups must tile a wave");
     const int v = tid % VPR, r0 = tid / VPR;
     const int n0 = nt * BN + v * 8;
     const bool vec_ok = (p.Cout % 8 == 0) && (p.ldo % 8 == 0) && (p.offo % 8 == 0) &&
@@ -253,104 +253,123 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const fd_conv_params p)
             gam[e] = bet[e] = gmean[e] = grstd[e] = 0.f;
         }
     }
+    float *sC = (float *)smem;
     float ssum[8], ssq[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ssum[e] = ssq[e] = 0.f;
-
     void *outp = p.out;
     const int64_t obase = (int64_t)dir * p.out_dir_stride;
-    for (int r = r0; r < BM; r += RPP) {
-        const int m = mt * BM + r;
-        if (m >= OHW || n0 >= p.Cout) continue;
-        const int64_t pix = (int64_t)b * OHW + m;
-        float val[8];
+    const int bands = (OHW + 63) / 64;       // 64-row bands per image = stats_partial tiles
+    for (int h = 0; h < WM; ++h) {
+        if (h > 0) __syncthreads();
+        if (wm == h) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) val[e] = sC[r * BN + v * 8 + e] + bias[e];
-        if (p.epilogue == FD_EPI_SILU_SPLIT) {
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-                if (n0 + e >= p.epi_split) val[e] = fd_silu(val[e]);
-        } else if (p.epilogue == FD_EPI_RELU) {
+                for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) val[e] = fmaxf(val[e], 0.f);
-        } else if (p.epilogue == FD_EPI_GATE_RES || p.epilogue == FD_EPI_RES_RELU) {
-            float rs[8];
-            const T *rp = (const T *)p.res + pix * p.ld_res + p.off_res + n0;
-            if (vec_ok) load8(rp, rs);
-            else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) rs[e] = (n0 + e < p.Cout) ? ld1(rp + e) : 0.f;
-            }
-            if (p.epilogue == FD_EPI_GATE_RES) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) val[e] = rs[e] + gate[e] * val[e];
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) val[e] = fmaxf(val[e] + rs[e], 0.f);
-            }
-        } else if (p.epilogue == FD_EPI_GNSILU_ADD) {
-            float hv[8];
-            const T *hp = (const T *)p.h + pix * p.Cout + n0;
-            if (vec_ok) load8(hp, hv);
-            else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) hv[e] = (n0 + e < p.Cout) ? ld1(hp + e) : 0.f;
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                val[e] += fd_silu((hv[e] - gmean[e]) * grstd[e] * gam[e] + bet[e]);
-        }
-        if (p.stats_partial) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { ssum[e] += val[e]; ssq[e] += val[e] * val[e]; }
-        }
-        if (p.out_f32) {
-            float *op = (float *)outp + obase + pix * p.ldo + p.offo + n0;
-            if (vec_ok) store8(op, val);
-            else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (n0 + e < p.Cout) op[e] = val[e];
-            }
-        } else {
-            T *op = (T *)outp + obase + pix * p.ldo + p.offo + n0;
-            if (vec_ok) store8(op, val);
-            else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (n0 + e < p.Cout) st1(op + e, val[e]);
-            }
-        }
-    }
-
-    if (p.stats_partial) {
-        // lanes with equal (tid % VPR) hold the same 8 columns: reduce inside the wave, then
-        // across the 4 waves through LDS (fixed order -> deterministic).
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-#pragma unroll
-            for (int o = VPR; o < 64; o <<= 1) {
-                ssum[e] += __shfl_xor(ssum[e], o, 64);
-                ssq[e] += __shfl_xor(ssq[e], o, 64);
-            }
-        }
-        if (lane < VPR) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                s_stat[wave][lane * 8 + e][0] = ssum[e];
-                s_stat[wave][lane * 8 + e][1] = ssq[e];
-            }
+                    for (int e = 0; e < 4; ++e) {
+                        int r = 16 * i + fg * 4 + e;
+                        int cc = TNW * wn + 16 * j + fr;
+                        sC[r * BN + cc] = acc[i][j][e];
+                    }
         }
         __syncthreads();
-        if (tid < BN) {
-            int n = nt * BN + tid;
-            if (n < p.Cout) {
-                float s = 0.f, q = 0.f;
+        if ((h * TMW) % 64 == 0) {       // first pass of a 64-row band
 #pragma unroll
-                for (int w = 0; w < 4; ++w) { s += s_stat[w][tid][0]; q += s_stat[w][tid][1]; }
-                float *sp = p.stats_partial + (((int64_t)b * gridDim.x + mt) * p.Cout + n) * 2;
-                sp[0] = s;
-                sp[1] = q;
+            for (int e = 0; e < 8; ++e) ssum[e] = ssq[e] = 0.f;
+        }
+        for (int r = r0; r < TMW; r += RPP) {
+            const int m = mt * BM + h * TMW + r;
+            if (m >= OHW || n0 >= p.Cout) continue;
+            const int64_t pix = (int64_t)b * OHW + m;
+            float val[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) val[e] = sC[r * BN + v * 8 + e] + bias[e];
+            if (p.epilogue == FD_EPI_SILU_SPLIT) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (n0 + e >= p.epi_split) val[e] = fd_silu(val[e]);
+            } else if (p.epilogue == FD_EPI_RELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) val[e] = fmaxf(val[e], 0.f);
+            } else if (p.epilogue == FD_EPI_GATE_RES || p.epilogue == FD_EPI_RES_RELU) {
+                float rs[8];
+                const T *rp = (const T *)p.res + pix * p.ld_res + p.off_res + n0;
+                if (vec_ok) load8(rp, rs);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) rs[e] = (n0 + e < p.Cout) ? ld1(rp + e) : 0.f;
+                }
+                if (p.epilogue == FD_EPI_GATE_RES) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) val[e] = rs[e] + gate[e] * val[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) val[e] = fmaxf(val[e] + rs[e], 0.f);
+                }
+            } else if (p.epilogue == FD_EPI_GNSILU_ADD) {
+                float hv[8];
+                const T *hp = (const T *)p.h + pix * p.Cout + n0;
+                if (vec_ok) load8(hp, hv);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) hv[e] = (n0 + e < p.Cout) ? ld1(hp + e) : 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    val[e] += fd_silu((hv[e] - gmean[e]) * grstd[e] * gam[e] + bet[e]);
+            }
+            if (p.stats_partial) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { ssum[e] += val[e]; ssq[e] += val[e] * val[e]; }
+            }
+            if (p.out_f32) {
+                float *op = (float *)outp + obase + pix * p.ldo + p.offo + n0;
+                if (vec_ok) store8(op, val);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (n0 + e < p.Cout) op[e] = val[e];
+                }
+            } else {
+                T *op = (T *)outp + obase + pix * p.ldo + p.offo + n0;
+                if (vec_ok) store8(op, val);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (n0 + e < p.Cout) st1(op + e, val[e]);
+                }
+            }
+        }
+        if (p.stats_partial && ((h + 1) * TMW) % 64 == 0) {      // last pass of the band
+            // lanes with equal (tid % VPR) hold the same 8 columns: reduce inside the wave, then
+            // across the waves through LDS (fixed order -> deterministic).
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+#pragma unroll
+                for (int o = VPR; o < 64; o <<= 1) {
+                    ssum[e] += __shfl_xor(ssum[e], o, 64);
+                    ssq[e] += __shfl_xor(ssq[e], o, 64);
+                }
+            }
+            if (lane < VPR) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    s_stat[wave][lane * 8 + e][0] = ssum[e];
+                    s_stat[wave][lane * 8 + e][1] = ssq[e];
+                }
+            }
+            __syncthreads();
+            const int band = (mt * BM + h * TMW) / 64;      // (TMW = 32: both passes belong to band mt)
+            if (tid < BN && band < bands) {
+                int n = nt * BN + tid;
+                if (n < p.Cout) {
+                    float s = 0.f, q = 0.f;
+#pragma unroll
+                    for (int w = 0; w < NWAVE; ++w) { s += s_stat[w][tid][0]; q += s_stat[w][tid][1]; }
+                    float *sp = p.stats_partial + (((int64_t)b * bands + band) * p.Cout + n) * 2;
+                    sp[0] = s;
+                    sp[1] = q;
+                }
             }
         }
     }
@@ -418,18 +437,24 @@ __global__ void gn_silu_apply_kernel(const T *__restrict__ h, const float *__res
 
 }  // namespace
 
-extern "C" int fd_conv_mtiles(int OH, int OW) { return cdiv((int64_t)OH * OW, conv_bm((int64_t)OH * OW)); }
+// GroupNorm partial-sum bands per image (64 output pixels each, whatever tile the conv runs with)
+extern "C" int fd_conv_mtiles(int OH, int OW) { return cdiv((int64_t)OH * OW, 64); }
 
 int fd_gemm_rows_launch(const fd_conv_params &p, hipStream_t s);
 int fd_conv3x3_ok(const fd_conv_params &p);
 int fd_conv3x3_launch(const fd_conv_params &p, hipStream_t s);
 
 // Which kernel fd_conv2d dispatches `p` to: 10 streaming row-GEMM, 11 halo-tiled 3x3, else the
-// implicit-GEMM tile variant 0 <128,128>, 1 <128,64>, 2 <64,128>, 3 <64,64>  (BM, BN).
+// implicit-GEMM tile variant 0 <128,128>, 1 <128,64>, 2 <64,128>, 3 <64,64>, 4 <128,256> (BM, BN).
 extern "C" int fd_conv_kernel_id(const fd_conv_params *pp) {
     if (fd_conv_prologue_ok(pp)) return 10;
     if (fd_conv3x3_ok(*pp)) return 11;
     const bool wide = pp->Cout > 64, tall = conv_bm((int64_t)pp->OH * pp->OW) == 128;
+    // The 8-wave 128x256 tile (id 4) is built and parity-tested but not selected: on the 64x64 / 128x128
+    // levels it is +20 % at batch 8 (775 vs 648 TFLOP/s on 768->512 3x3) and -40 % at batch 1 (64
+    // workgroups on 256 CUs), and the tile choice must not depend on the batch size (batch-invariant
+    // results).  It needs a deterministic split-K before it can replace <64,128>.
+    if (!tall && pp->Cout >= 256 && getenv("FD_CONV_BIG_TILE")) return 4;
     return (tall ? 0 : 2) + (wide ? 0 : 1);
 }
 
@@ -465,18 +490,22 @@ extern "C" int fd_conv2d(const fd_conv_params *pp, void *stream) {
                                           "cannot run (check fd_conv_prologue_ok first)");
     FD_REQUIRE((int64_t)p.H * p.W * (p.ld0 > p.ld1 ? p.ld0 : p.ld1) < (1ll << 31),
                "fd_conv2d: one image of a source must hold < 2^31 elements");
-    const int mt = fd_conv_mtiles(p.OH, p.OW);
-    const bool wide = p.Cout > 64, tall = conv_bm((int64_t)p.OH * p.OW) == 128;
-    dim3 grid(mt, cdiv(p.Cout, wide ? 128 : 64), p.B * p.ndir), block(256);
+    const int kid = fd_conv_kernel_id(pp);
+    const int BMs[5] = {128, 128, 64, 64, 128}, BNs[5] = {128, 64, 128, 64, 256};
+    dim3 grid(cdiv((int64_t)p.OH * p.OW, BMs[kid]), cdiv(p.Cout, BNs[kid]), p.B * p.ndir), block(kid == 4 ? 512 : 256);
     hipStream_t s = (hipStream_t)stream;
-#define FD_CONV_LAUNCH(T_, BM_, BN_) hipLaunchKernelGGL((conv_igemm_kernel<T_, BM_, BN_>), grid, block, 0, s, p)
-    if (p.dtype == FD_BF16) {
-        if (tall) { if (wide) FD_CONV_LAUNCH(bf16, 128, 128); else FD_CONV_LAUNCH(bf16, 128, 64); }
-        else { if (wide) FD_CONV_LAUNCH(bf16, 64, 128); else FD_CONV_LAUNCH(bf16, 64, 64); }
-    } else {
-        if (tall) { if (wide) FD_CONV_LAUNCH(float, 128, 128); else FD_CONV_LAUNCH(float, 128, 64); }
-        else { if (wide) FD_CONV_LAUNCH(float, 64, 128); else FD_CONV_LAUNCH(float, 64, 64); }
+#define FD_CONV_LAUNCH(T_, BM_, BN_, WM_, WN_) \
+    hipLaunchKernelGGL((conv_igemm_kernel<T_, BM_, BN_, WM_, WN_>), grid, block, 0, s, p)
+#define FD_CONV_DISPATCH(T_)                                     \
+    switch (kid) {                                               \
+    case 0: FD_CONV_LAUNCH(T_, 128, 128, 2, 2); break;           \
+    case 1: FD_CONV_LAUNCH(T_, 128, 64, 2, 2); break;            \
+    case 2: FD_CONV_LAUNCH(T_, 64, 128, 2, 2); break;            \
+    case 3: FD_CONV_LAUNCH(T_, 64, 64, 2, 2); break;             \
+    default: FD_CONV_LAUNCH(T_, 128, 256, 2, 4); break;          \
     }
+    if (p.dtype == FD_BF16) { FD_CONV_DISPATCH(bf16) } else { FD_CONV_DISPATCH(float) }
+#undef FD_CONV_DISPATCH
 #undef FD_CONV_LAUNCH
     FD_LAUNCH_OK("fd_conv2d");
     return FD_OK;

@@ -217,9 +217,13 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const fd_conv_params 
                 float s = 0.f, q = 0.f;
 #pragma unroll
                 for (int w = 0; w < 4; ++w) { s += s_stat[w][tid][0]; q += s_stat[w][tid][1]; }
-                float *sp = p.stats_partial + (((int64_t)b * gridDim.x + blockIdx.x) * p.Cout + n) * 2;
+                // the workspace holds one entry per 64 output pixels (fd_conv_mtiles): this 128-pixel
+                // tile fills entry 2t and zeroes entry 2t+1
+                float *sp = p.stats_partial + (((int64_t)b * 2 * gridDim.x + 2 * blockIdx.x) * p.Cout + n) * 2;
                 sp[0] = s;
                 sp[1] = q;
+                sp[2 * p.Cout] = 0.f;
+                sp[2 * p.Cout + 1] = 0.f;
             }
         }
     }
@@ -238,8 +242,7 @@ int fd_conv3x3_ok(const fd_conv_params &p) {
     if (p.ld0 % 8 || p.off0 % 8 || (p.in1 && (p.ld1 % 8 || p.off1 % 8)) || p.ldo % 8 || p.offo % 8) return 0;
     if (p.OH % TH || p.OW % TW) return 0;
     if (p.OH != (p.upsample ? 2 * p.H : p.H) || p.OW != (p.upsample ? 2 * p.W : p.W)) return 0;
-    // only where fd_conv_mtiles() counts 128-pixel tiles (GroupNorm partial layout must match) --
-    // at <= 16384 pixels per image the 64-row generic tile fills the chip better anyway
+    // at <= 16384 pixels per image the generic tiles (64-row / 8-wave 128x256) fill the chip better
     if ((int64_t)p.OH * p.OW <= 16384) return 0;
     if ((int64_t)p.H * p.W * (p.ld0 > p.ld1 ? p.ld0 : p.ld1) >= (1ll << 31)) return 0;
     return 1;
