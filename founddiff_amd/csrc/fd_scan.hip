@@ -87,9 +87,15 @@ __global__ __launch_bounds__(256) void scan_chunk_kernel(const T *__restrict__ x
     const T *ub = xc + (int64_t)b * g.H * g.W * g.D;
     T *yb = FINAL ? y + (int64_t)b * g.H * g.W * g.D : nullptr;
     // scan position -> (h2, w2) kept as scalar counters: no division in the loop
-    int h2, w2;
-    if (odd) { w2 = l0 / g.H2; h2 = l0 - w2 * g.H2; }
-    else { h2 = l0 / g.W2; w2 = l0 - h2 * g.W2; }
+    // The integer division is computed on the vector unit; readfirstlane moves the (uniform) result to
+    // SGPRs, otherwise everything derived from it (counters, wrap tests, row addresses) is treated as
+    // divergent: exec-mask branches and 64-bit VALU address math in every step.
+    // Branch-free walk: fast index i in [0, NI), slow index o; pix = base + i*s_i + o*s_o.
+    const int NI = odd ? g.H2 : g.W2;
+    const int s_i = odd ? 2 * g.W : 2, s_o = odd ? 2 : 2 * g.W;
+    int ci = __builtin_amdgcn_readfirstlane(l0 % NI);
+    int pixc = __builtin_amdgcn_readfirstlane(ph * g.W + pw + (l0 % NI) * s_i + (l0 / NI) * s_o);
+    const int wrap_fix = s_o - NI * s_i;
     __syncthreads();
 
     auto step = [&](const float *xr, float u, int pix) {
@@ -109,21 +115,39 @@ __global__ __launch_bounds__(256) void scan_chunk_kernel(const T *__restrict__ x
         if (FINAL) st1(yb + (int64_t)pix * g.D + d, acc + Dd * u);
     };
     auto advance = [&](int &pix) {
-        pix = (2 * h2 + ph) * g.W + 2 * w2 + pw;
-        if (odd) { if (++h2 == g.H2) { h2 = 0; ++w2; } }
-        else { if (++w2 == g.W2) { w2 = 0; ++h2; } }
+        pix = pixc;
+        ++ci;
+        const bool wrap = ci == NI;
+        ci = wrap ? 0 : ci;
+        pixc += s_i + (wrap ? wrap_fix : 0);
     };
-    constexpr int U = (N >= 16) ? 4 : 8;   // u values in flight per lane
+    constexpr int U = (N >= 16) ? 8 : 16;  // steps per group
+    // Two groups of u values in registers: group g+1 is loaded while group g runs the recurrence, so a
+    // wave always has U loads in flight behind ~U steps of arithmetic (HBM latency under load is longer
+    // than one group's compute; 4 waves per SIMD alone do not cover it).
     int l = l0;
-    for (; l + U <= l1; l += U) {
-        int pix[U];
-        float u[U];
+    const int ngroups = (l1 - l0) / U;
+    int pixA[U], pixB[U];
+    T uA[U], uB[U];
+    auto fetch = [&](int (&pix)[U], T (&u)[U]) {
 #pragma unroll
         for (int s = 0; s < U; ++s) advance(pix[s]);
 #pragma unroll
-        for (int s = 0; s < U; ++s) u[s] = ld1(ub + (int64_t)pix[s] * g.D + d);
+        for (int s = 0; s < U; ++s) u[s] = *(ub + (int64_t)pix[s] * g.D + d);
+    };
+    auto run = [&](const int (&pix)[U], const T (&u)[U]) {
 #pragma unroll
-        for (int s = 0; s < U; ++s) step(sx + (l - l0 + s) * CDP, u[s], pix[s]);
+        for (int s = 0; s < U; ++s) step(sx + (l - l0 + s) * CDP, (float)u[s], pix[s]);
+        l += U;
+    };
+    if (ngroups > 0) fetch(pixA, uA);
+    for (int gi = 0; gi < ngroups; gi += 2) {
+        if (gi + 1 < ngroups) fetch(pixB, uB);
+        run(pixA, uA);
+        if (gi + 1 < ngroups) {
+            if (gi + 2 < ngroups) fetch(pixA, uA);
+            run(pixB, uB);
+        }
     }
     for (; l < l1; ++l) {
         int pix;
