@@ -450,11 +450,18 @@ extern "C" int fd_conv_kernel_id(const fd_conv_params *pp) {
     if (fd_conv_prologue_ok(pp)) return 10;
     if (fd_conv3x3_ok(*pp)) return 11;
     const bool wide = pp->Cout > 64, tall = conv_bm((int64_t)pp->OH * pp->OW) == 128;
-    // The 8-wave 128x256 tile (id 4) is built and parity-tested but not selected: on the 64x64 / 128x128
-    // levels it is +20 % at batch 8 (775 vs 648 TFLOP/s on 768->512 3x3) and -40 % at batch 1 (64
-    // workgroups on 256 CUs), and the tile choice must not depend on the batch size (batch-invariant
-    // results).  It needs a deterministic split-K before it can replace <64,128>.
-    if (!tall && pp->Cout >= 256 && getenv("FD_CONV_BIG_TILE")) return 4;
+    // 8-wave 128x256 tile (id 4) for the dense layers of the 64x64 / 128x128 levels: it halves the operand
+    // traffic from beyond L2 (+15..30 % at batch 8) but launches 4x fewer workgroups, so it is chosen only
+    // when the batch fills the chip.  This choice may depend on the batch size without breaking batch
+    // invariance: every output element accumulates its K tiles in the same order whatever the tile shape
+    // (bitwise identical results); only the GroupNorm partial sums depend on the tiling, so convolutions
+    // that emit them keep the batch-independent configuration.
+    // (measured at batch 8: wins 12-25 % for Cout 256..512; loses 5-10 % for Cout >= 1024, where the small
+    //  tile already launches plenty of workgroups per A tile)
+    if (!tall && pp->Cout >= 256 && pp->Cout <= 512 && !pp->stats_partial && pp->KH * pp->KW * (pp->c0 + pp->c1) >= 256) {
+        const int64_t wgs = (int64_t)pp->B * pp->ndir * cdiv((int64_t)pp->OH * pp->OW, 128) * cdiv(pp->Cout, 256);
+        if (wgs >= 192 || getenv("FD_CONV_BIG_TILE")) return 4;
+    }
     return (tall ? 0 : 2) + (wide ? 0 : 1);
 }
 

@@ -243,7 +243,7 @@ int fd_conv3x3_ok(const fd_conv_params &p) {
     if (p.OH % TH || p.OW % TW) return 0;
     if (p.OH != (p.upsample ? 2 * p.H : p.H) || p.OW != (p.upsample ? 2 * p.W : p.W)) return 0;
     // at <= 16384 pixels per image the generic tiles (64-row / 8-wave 128x256) fill the chip better
-    if ((int64_t)p.OH * p.OW <= 16384) return 0;
+    if ((int64_t)p.OH * p.OW < 4096) return 0;
     if ((int64_t)p.H * p.W * (p.ld0 > p.ld1 ? p.ld0 : p.ld1) >= (1ll << 31)) return 0;
     return 1;
 }
