@@ -109,9 +109,11 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const T *__restrict__ in
     extern __shared__ __attribute__((aligned(16))) unsigned char dw_smem[];
     T *tile = (T *)dw_smem;                          // [(TY+2)][(TX+2)][CB]
     const int tid = threadIdx.x;
-    const int cb = blockIdx.z % cblocks;
-    const int64_t img = blockIdx.z / cblocks;
-    const int x0 = blockIdx.x * DW_TX, y0 = blockIdx.y * DW_TY;
+    // channel block fastest: the workgroups that read the other 128-byte pieces of the same pixel rows
+    // are dispatched back to back (same DRAM pages, same L2 lines for the halo)
+    const int cb = blockIdx.x % cblocks;
+    const int64_t img = blockIdx.z;
+    const int x0 = (blockIdx.x / cblocks) * DW_TX, y0 = blockIdx.y * DW_TY;
     const int cbase = cb * DW_CB;
     constexpr int HX = DW_TX + 2, HY = DW_TY + 2;
     for (int idx = tid; idx < HY * HX * 8; idx += 256) {
@@ -297,7 +299,7 @@ extern "C" int fd_dwconv3x3(int dtype, const void *in, int ld_in, int off_in, co
     FD_REQUIRE(C % 8 == 0 && ld_in % 8 == 0 && off_in % 8 == 0 && ld_out % 8 == 0 && off_out % 8 == 0,
                "fd_dwconv3x3: channels/strides/offsets must be multiples of 8");
     const int cblocks = (C + DW_CB - 1) / DW_CB;
-    dim3 grid((W + DW_TX - 1) / DW_TX, (H + DW_TY - 1) / DW_TY, (unsigned)(B * cblocks)), block(256);
+    dim3 grid(((W + DW_TX - 1) / DW_TX) * cblocks, (H + DW_TY - 1) / DW_TY, (unsigned)B), block(256);
     const size_t lds = (size_t)(DW_TY + 2) * (DW_TX + 2) * DW_CB * (dtype == FD_BF16 ? 2 : 4);
     if (dtype == FD_BF16)
         hipLaunchKernelGGL(dwconv3x3_kernel<bf16>, grid, block, lds, (hipStream_t)stream, (const bf16 *)in, ld_in, off_in,
