@@ -179,6 +179,120 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const T *__restrict__ in
     }
 }
 
+// bf16 specialisation (the production mode).  Two changes against the generic kernel, both aimed at
+// its measured co-bottlenecks (VALU 53 % busy, LDS reads ~55 % of the run time):
+//  * 16 x 16 pixel tile, a thread walks 8 rows of one column keeping a 3-row x 3-tap window of packed
+//    bf16 pairs in registers: 30 ds_read_b128 per 8 outputs instead of 72;
+//  * each multiply-accumulate is ONE v_dot2c_f32_bf16 on the packed pair register with a weight
+//    register that holds the tap weight in the wanted half and 0 in the other -- no bf16->f32 unpack.
+//    The tap weights are therefore rounded to bf16 (as every dense conv weight in this mode is);
+//    accumulation stays f32.
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+constexpr int DWB_T = 16;
+__global__ __launch_bounds__(256) void dwconv3x3_bf16_kernel(const bf16 *__restrict__ in, int ld_in, int off_in,
+                                                            const float *__restrict__ w,
+                                                            const float *__restrict__ bias, int silu,
+                                                            bf16 *__restrict__ out, int ld_out, int off_out, int H,
+                                                            int W, int C, int cblocks) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dw_smem[];
+    bf16 *tile = (bf16 *)dw_smem;                    // [18][18][64]
+    const int tid = threadIdx.x;
+    const int cb = blockIdx.x % cblocks;
+    const int64_t img = blockIdx.z;
+    const int x0 = (blockIdx.x / cblocks) * DWB_T, y0 = blockIdx.y * DWB_T;
+    const int cbase = cb * DW_CB;
+    constexpr int HX = DWB_T + 2, HY = DWB_T + 2;
+    // all halo loads of the thread are issued before the first LDS write (one HBM round trip per
+    // workgroup instead of one per loop iteration)
+    constexpr int NLD = (HY * HX * 8 + 255) / 256;
+    u32x4 vals[NLD];
+    uint32_t okm = 0;
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int idx = tid + k * 256;
+        const int v = idx & 7, pxl = idx >> 3;
+        const int hy = pxl / HX, hx = pxl - hy * HX;
+        const int yy = y0 + hy - 1, xx = x0 + hx - 1, c0 = cbase + v * 8;
+        // branch-free: always load from a clamped in-bounds address, zero the padding on the LDS write
+        const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W && c0 < C;
+        okm |= (ok ? 1u : 0u) << k;
+        const int yc = min(max(yy, 0), H - 1), xc = min(max(xx, 0), W - 1), cc = min(c0, C - 8);
+        vals[k] = *(const u32x4 *)(in + ((img * H + yc) * W + xc) * ld_in + off_in + cc);
+    }
+    const int cv = tid & 7, px = (tid >> 3) & 15, rhalf = tid >> 7;
+    const int c0 = cbase + cv * 8;
+    const bool cok = c0 < C;
+    const int cw = min(c0, C - 8);                    // threads beyond C exit below; keep their loads in bounds
+    uint32_t wlo[9][4], whi[9][4];
+    float bs[8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        float wv[8];
+        load8(w + t * C + cw, wv);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bf16 a = (bf16)wv[2 * j], b = (bf16)wv[2 * j + 1];
+            wlo[t][j] = (uint32_t)__builtin_bit_cast(uint16_t, a);
+            whi[t][j] = (uint32_t)__builtin_bit_cast(uint16_t, b) << 16;
+        }
+    }
+    if (bias) load8(bias + cw, bs);
+    else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bs[e] = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int idx = tid + k * 256;
+        const u32x4 z4 = {0, 0, 0, 0};
+        if (idx < HY * HX * 8) *(u32x4 *)(tile + (idx >> 3) * DW_CB + (idx & 7) * 8) = ((okm >> k) & 1) ? vals[k] : z4;
+    }
+    __syncthreads();
+    const int x = x0 + px;
+    if (x >= W || !cok) return;
+    const int r0 = rhalf * (DWB_T / 2);
+    uint32_t win[3][3][4];                            // [row slot][dx][channel pair]
+    const bf16 *col = tile + px * DW_CB + cv * 8;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const u32x4 t4 = *(const u32x4 *)(col + ((r0 + s) * HX + dx) * DW_CB);
+            win[s][dx][0] = t4.x; win[s][dx][1] = t4.y; win[s][dx][2] = t4.z; win[s][dx][3] = t4.w;
+        }
+#pragma unroll
+    for (int rr = 0; rr < DWB_T / 2; ++rr) {
+        const int r = r0 + rr, y = y0 + r;
+        if (y >= H) break;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const u32x4 t4 = *(const u32x4 *)(col + ((r + 2) * HX + dx) * DW_CB);
+            uint32_t *wr = win[(rr + 2) % 3][dx];
+            wr[0] = t4.x; wr[1] = t4.y; wr[2] = t4.z; wr[3] = t4.w;
+        }
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = bs[e];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bf16x2 xv = __builtin_bit_cast(bf16x2, win[(rr + dy) % 3][dx][j]);
+                    acc[2 * j] = __builtin_amdgcn_fdot2_f32_bf16(
+                        xv, __builtin_bit_cast(bf16x2, wlo[dy * 3 + dx][j]), acc[2 * j], false);
+                    acc[2 * j + 1] = __builtin_amdgcn_fdot2_f32_bf16(
+                        xv, __builtin_bit_cast(bf16x2, whi[dy * 3 + dx][j]), acc[2 * j + 1], false);
+                }
+        if (silu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = fd_silu(acc[e]);
+        }
+        store8(out + ((img * H + y) * W + x) * ld_out + off_out + c0, acc);
+    }
+}
+
 template <typename T>
 __global__ void avgpool_kernel(const T *__restrict__ in, T *__restrict__ out, int H, int W, int C, int k,
                                int64_t total) {
@@ -301,10 +415,12 @@ extern "C" int fd_dwconv3x3(int dtype, const void *in, int ld_in, int off_in, co
     const int cblocks = (C + DW_CB - 1) / DW_CB;
     dim3 grid(((W + DW_TX - 1) / DW_TX) * cblocks, (H + DW_TY - 1) / DW_TY, (unsigned)B), block(256);
     const size_t lds = (size_t)(DW_TY + 2) * (DW_TX + 2) * DW_CB * (dtype == FD_BF16 ? 2 : 4);
-    if (dtype == FD_BF16)
-        hipLaunchKernelGGL(dwconv3x3_kernel<bf16>, grid, block, lds, (hipStream_t)stream, (const bf16 *)in, ld_in, off_in,
-                           weight, bias, silu, (bf16 *)out, ld_out, off_out, H, W, C, cblocks);
-    else {
+    if (dtype == FD_BF16) {
+        dim3 gridb(((W + DWB_T - 1) / DWB_T) * cblocks, (H + DWB_T - 1) / DWB_T, (unsigned)B);
+        const size_t ldsb = (size_t)(DWB_T + 2) * (DWB_T + 2) * DW_CB * 2;
+        hipLaunchKernelGGL(dwconv3x3_bf16_kernel, gridb, block, ldsb, (hipStream_t)stream, (const bf16 *)in, ld_in,
+                           off_in, weight, bias, silu, (bf16 *)out, ld_out, off_out, H, W, C, cblocks);
+    } else {
         static bool attr_set = false;
         if (!attr_set) {
             (void)hipFuncSetAttribute((const void *)dwconv3x3_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -184,6 +184,18 @@ def test_dwconv_avgpool_gn(eng_factory, mode, tol):
            out.data_ptr(), Cc, 0, B, H, W, Cc, e.stream)
     torch.cuda.synchronize()
     assert rel_err(nchw(out), ref) < tol
+    # several tiles / both row halves / channel blocks, strided channel window in and out, no SiLU
+    Cb, Hb, Wb = 128, 40, 36
+    xb = rq(torch.randn(B, Cb + 16, Hb, Wb), mode)
+    wb, bb_ = torch.randn(Cb, 1, 3, 3) / 3, torch.randn(Cb)
+    refb = F.conv2d(xb[:, 8:8 + Cb], wb, bb_, padding=1, groups=Cb)
+    outb = torch.zeros(B, Hb, Wb, Cb + 8, device="cuda", dtype=e.tdt)
+    wbd, bbd_, xbd = wb.reshape(Cb, 9).t().contiguous().cuda(), bb_.cuda(), nhwc(xb, e.tdt)
+    L.call("fd_dwconv3x3", e.dt, xbd.data_ptr(), Cb + 16, 8, wbd.data_ptr(), bbd_.data_ptr(), 0,
+           outb.data_ptr(), Cb + 8, 8, B, Hb, Wb, Cb, e.stream)
+    torch.cuda.synchronize()
+    assert rel_err(nchw(outb[..., 8:]), refb) < tol
+    assert float(outb[..., :8].float().abs().max()) == 0.0
     x2 = rq(torch.randn(B, 16, 8, 12), mode)
     o2 = torch.empty(B, 4, 6, 16, device="cuda", dtype=e.tdt)
     x2d = nhwc(x2, e.tdt)
