@@ -65,21 +65,25 @@ __global__ __launch_bounds__(256) void scan_chunk_kernel(const T *__restrict__ x
         sx[row * CDP + e] = xb[(int64_t)(h2 * g.W2 + w2) * CD + e];
     }
 
-    float w[R], a2[N], h[N];
+    // state / weights as float pairs: the recurrence runs on v_pk_mul_f32 / v_pk_fma_f32 (two states
+    // per instruction at the scalar-op issue rate); only the two v_exp_f32 per pair stay scalar
+    f32x2 w[R / 2], a2[N / 2], h[N / 2];
 #pragma unroll
-    for (int r = 0; r < R; ++r) w[r] = dtw[(int64_t)kd * R + r];
+    for (int r = 0; r < R / 2; ++r) w[r] = f32x2{dtw[(int64_t)kd * R + 2 * r], dtw[(int64_t)kd * R + 2 * r + 1]};
     // exp(dt*A) = exp2(dt * A*log2(e)): fold the constant into A once (v_exp_f32 is exp2)
 #pragma unroll
-    for (int n = 0; n < N; ++n) a2[n] = A[(int64_t)kd * N + n] * 1.4426950408889634f;
+    for (int n = 0; n < N / 2; ++n)
+        a2[n] = f32x2{A[(int64_t)kd * N + 2 * n], A[(int64_t)kd * N + 2 * n + 1]} * 1.4426950408889634f;
     const float bias = dtb[kd];
     const float Dd = FINAL ? Ds[kd] : 0.f;
     const int64_t cbase = (((int64_t)bk * g.nch + chunk) * N) * g.D + d;   // [bk][chunk][n][d]
     if (FINAL) {
 #pragma unroll
-        for (int n = 0; n < N; ++n) h[n] = wsH[cbase + (int64_t)n * g.D];
+        for (int n = 0; n < N / 2; ++n)
+            h[n] = f32x2{wsH[cbase + (int64_t)(2 * n) * g.D], wsH[cbase + (int64_t)(2 * n + 1) * g.D]};
     } else {
 #pragma unroll
-        for (int n = 0; n < N; ++n) h[n] = 0.f;
+        for (int n = 0; n < N / 2; ++n) h[n] = f32x2{0.f, 0.f};
     }
     float sdt = 0.f;
     // wave-uniform row base + per-lane channel index: the row address stays on the scalar unit and the
@@ -99,20 +103,23 @@ __global__ __launch_bounds__(256) void scan_chunk_kernel(const T *__restrict__ x
     __syncthreads();
 
     auto step = [&](const float *xr, float u, int pix) {
-        float dv = bias;
+        const f32x2 *xr2 = (const f32x2 *)xr;          // row = [dt_r (R) | B (N) | C (N)], all even
+        f32x2 dv2 = {bias, 0.f};
 #pragma unroll
-        for (int r = 0; r < R; ++r) dv += w[r] * xr[r];
+        for (int r = 0; r < R / 2; ++r) dv2 = w[r] * xr2[r] + dv2;
+        const float dv = dv2.x + dv2.y;
         const float dt = sizeof(T) == 2 ? fd_softplus_bf16(dv) : fd_softplus_fast(dv);
         const float dtu = dt * u;
         if (!FINAL) sdt += dt;
-        float acc = 0.f;
+        f32x2 acc2 = {0.f, 0.f};
 #pragma unroll
-        for (int n = 0; n < N; ++n) {
-            const float da = __builtin_amdgcn_exp2f(dt * a2[n]);
-            h[n] = da * h[n] + dtu * xr[R + n];
-            if (FINAL) acc += h[n] * xr[R + N + n];
+        for (int n = 0; n < N / 2; ++n) {
+            const f32x2 t = a2[n] * dt;
+            const f32x2 da = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+            h[n] = da * h[n] + xr2[R / 2 + n] * dtu;
+            if (FINAL) acc2 = h[n] * xr2[R / 2 + N / 2 + n] + acc2;
         }
-        if (FINAL) st1(yb + (int64_t)pix * g.D + d, acc + Dd * u);
+        if (FINAL) st1(yb + (int64_t)pix * g.D + d, acc2.x + acc2.y + Dd * u);
     };
     auto advance = [&](int &pix) {
         pix = pixc;
@@ -156,9 +163,11 @@ __global__ __launch_bounds__(256) void scan_chunk_kernel(const T *__restrict__ x
     }
     if (!FINAL) {
 #pragma unroll
-        for (int n = 0; n < N; ++n) {
-            wsH[cbase + (int64_t)n * g.D] = h[n];
-            wsP[cbase + (int64_t)n * g.D] = __builtin_amdgcn_exp2f(a2[n] * sdt);
+        for (int n = 0; n < N / 2; ++n) {
+            wsH[cbase + (int64_t)(2 * n) * g.D] = h[n].x;
+            wsH[cbase + (int64_t)(2 * n + 1) * g.D] = h[n].y;
+            wsP[cbase + (int64_t)(2 * n) * g.D] = __builtin_amdgcn_exp2f(a2[n].x * sdt);
+            wsP[cbase + (int64_t)(2 * n + 1) * g.D] = __builtin_amdgcn_exp2f(a2[n].y * sdt);
         }
     }
 }
