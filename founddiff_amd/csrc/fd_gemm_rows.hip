@@ -38,8 +38,12 @@ __device__ __forceinline__ int w_off(int row, int chunk, int RS) {
 
 // S = 16-pixel subtiles per wave iteration: 2 for K <= 64 (each weight fragment read from LDS feeds
 // two MFMAs), 1 for wider K where two subtiles' operands would halve the occupancy.
-template <int KS, int PRO, int EPI, int S = (KS <= 2 ? 2 : 1)>
-__global__ __launch_bounds__(256) void gemm_rows_kernel(const fd_conv_params p, int wtiles, int RS) {
+// NT = threads per workgroup: 256 when >= 3 workgroups fit a CU's LDS, 512 / 768 when the weight image is
+// so large (Cout*RS up to 128 KiB) that only 2 / 1 fit -- the waves that hide each other's HBM latency
+// then have to live in ONE workgroup sharing the weights (768 = 12 waves: 3 per SIMD, 170 VGPRs each).
+template <int KS, int PRO, int EPI, int NT, int S = (KS <= 2 ? 2 : 1)>
+__global__ __launch_bounds__(NT) void gemm_rows_kernel(const fd_conv_params p, int wtiles, int RS) {
+    constexpr int NW = NT / 64;
     constexpr int K = 32 * KS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int N = p.Cout;
@@ -51,19 +55,19 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const fd_conv_params p, 
     const int64_t hw = (int64_t)p.H * p.W;
     const bf16 *wg = (const bf16 *)p.weight + (int64_t)b * p.w_batch_stride;
     // ---- stage W (and the per-channel prologue vectors) once per workgroup
-    for (int idx = tid; idx < N * (K / 8); idx += 256) {
+    for (int idx = tid; idx < N * (K / 8); idx += NT) {
         const int row = idx / (K / 8), ch = idx - row * (K / 8);
         *(u32x4 *)(sW + w_off(row, ch, RS)) = *(const u32x4 *)(wg + (int64_t)row * K + ch * 8);
     }
     if (PRO == 1) {          // G = gamma (1+scale), Bc = beta (1+scale) + shift
-        for (int c = tid; c < K; c += 256) {
+        for (int c = tid; c < K; c += NT) {
             const float g = p.ln_gamma ? p.ln_gamma[c] : 1.f, be = p.ln_beta ? p.ln_beta[c] : 0.f;
             const float sc = 1.f + p.ln_scale[(int64_t)b * p.ln_ld + c], sh = p.ln_shift[(int64_t)b * p.ln_ld + c];
             sV[c] = g * sc;
             sV[K + c] = be * sc + sh;
         }
     } else if (PRO == 2) {   // gamma, beta, local
-        for (int c = tid; c < K; c += 256) {
+        for (int c = tid; c < K; c += NT) {
             sV[c] = p.ln_gamma[c];
             sV[K + c] = p.ln_beta[c];
             sV[2 * K + c] = p.ln_shift[(int64_t)b * p.ln_ld + c];
@@ -97,8 +101,8 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const fd_conv_params p, 
 
     // No software prefetch: the kernel keeps its register footprint small enough for 3-4 waves
     // per SIMD and lets the other waves' MFMA/store phases cover this wave's load latency.
-    const int wstride = gridDim.x * 4;
-    for (int wt = blockIdx.x * 4 + wave; wt < wtiles; wt += wstride) {
+    const int wstride = gridDim.x * NW;
+    for (int wt = blockIdx.x * NW + wave; wt < wtiles; wt += wstride) {
         bf16x8 xb[S][KS];
         load_tile(wt, xb);
         if (PRO != 0) {
@@ -229,6 +233,28 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const fd_conv_params p, 
 
 int row_stride(int K) { return K <= 64 ? 128 : (K <= 128 ? 256 : 512); }
 
+// 12 waves per workgroup leave 170 VGPRs per lane: enough for every variant without a prologue, for
+// LN+modulate up to K=128 and for LN*z+local up to K=96; the wider ones stay at 8 waves (256 VGPRs).
+constexpr bool fits_768(int KS, int PRO) { return PRO == 0 || (PRO == 1 && KS <= 4) || KS <= 3; }
+// ... and the widest fused-LayerNorm variants need more than the 256 VGPRs of an 8-wave workgroup
+constexpr bool fits_512(int KS, int PRO) { return !(PRO == 1 && KS >= 8) && !(PRO == 2 && KS >= 6); }
+
+template <int KS, int PRO, int EPI, int NT>
+void launch_rows_nt(const fd_conv_params &p, dim3 grid, size_t lds, int wtiles, int RS, hipStream_t s) {
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void *)gemm_rows_kernel<KS, PRO, EPI, NT>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((gemm_rows_kernel<KS, PRO, EPI, NT>), grid, dim3(NT), lds, s, p, wtiles, RS);
+}
+
+template <int KS, int PRO, int EPI>
+void launch_rows(const fd_conv_params &p, int nt, dim3 grid, size_t lds, int wtiles, int RS, hipStream_t s) {
+    if (nt == 256) launch_rows_nt<KS, PRO, EPI, 256>(p, grid, lds, wtiles, RS, s);
+    else if (nt == 512) {
+        if constexpr (fits_512(KS, PRO)) launch_rows_nt<KS, PRO, EPI, 512>(p, grid, lds, wtiles, RS, s);
+    } else if constexpr (fits_768(KS, PRO)) launch_rows_nt<KS, PRO, EPI, 768>(p, grid, lds, wtiles, RS, s);
+}
+
 }  // namespace
 
 // 1 if `p` can run on the streaming row-GEMM (and therefore may carry a fused LN prologue).
@@ -267,17 +293,13 @@ int fd_gemm_rows_launch(const fd_conv_params &p, hipStream_t s) {
     int per_cu = (int)(150 * 1024 / lds);
     if (per_cu > 4) per_cu = 4;
     if (per_cu < 1) per_cu = 1;
+    int nt = per_cu >= 3 ? 256 : ((per_cu == 2 || !fits_768(KS, p.prologue)) ? 512 : 768);
+    if (nt == 512 && !fits_512(KS, p.prologue)) nt = 256;
     int gx = (256 * per_cu + p.B - 1) / p.B;
-    const int need = (wtiles + 3) / 4;
+    const int need = (wtiles + nt / 64 - 1) / (nt / 64);
     if (gx > need) gx = need;
-    dim3 grid(gx, p.B), block(256);
-#define FD_GR(KS_, PRO_, EPI_)                                                                                     \
-    do {                                                                                                           \
-        if (lds > 64 * 1024)                                                                                       \
-            (void)hipFuncSetAttribute((const void *)gemm_rows_kernel<KS_, PRO_, EPI_>,                             \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
-        hipLaunchKernelGGL((gemm_rows_kernel<KS_, PRO_, EPI_>), grid, block, lds, s, p, wtiles, RS);               \
-    } while (0)
+    dim3 grid(gx, p.B);
+#define FD_GR(KS_, PRO_, EPI_) launch_rows<KS_, PRO_, EPI_>(p, nt, grid, lds, wtiles, RS, s)
 #define FD_GR_K(PRO_, EPI_)                            \
     switch (KS) {                                      \
     case 1: FD_GR(1, PRO_, EPI_); break;               \

@@ -398,3 +398,27 @@ def test_row_gemm_fused_prologues(eng_factory):
     got = run(None, bigd, out, c0=64, ld0=192, off0=128, weight=wbd, w_batch_stride=64 * 64, bias=None, Cout=64,
               KH=1, KW=1, epi=L.EPI_GATE_RES, res=resd, gate=C.c_void_p(md.data_ptr() + 320 * 4), gate_ld=6 * 64)
     assert rel_err(got.reshape(B, hw, 64), ref) < 1.5e-2
+    # (5) wide Cout: the weight image (512 x 256 B = 128 KiB) leaves one workgroup per CU -> 12-wave
+    # workgroups; LN + modulate prologue over K = 128, SiLU on the upper half
+    x5 = bf(torch.randn(B, hw, 128) * 1.5 - 0.2)
+    w5 = bf(torch.randn(512, 128) / 11)
+    g5, b5 = torch.randn(128), torch.randn(128)
+    mod5 = torch.randn(B, 6 * 128) * 0.5
+    x5d, m5d, g5d, b5d = x5.cuda().to(torch.bfloat16), mod5.cuda(), g5.cuda(), b5.cuda()
+    xm = F.layer_norm(x5, (128,), g5, b5, 1e-5) * (1 + mod5[:, None, 128:256]) + mod5[:, None, 0:128]
+    ref = F.linear(bf(xm), w5)
+    ref[..., 256:] = F.silu(ref[..., 256:])
+    out = torch.empty(B, H, W, 512, device="cuda", dtype=torch.bfloat16)
+    got = run(ConvW(w5, None, e.dev, e.tdt), x5d, out, epi=L.EPI_SILU_SPLIT, split=256, prologue=L.PRO_LN_MOD,
+              ln_gamma=g5d, ln_beta=b5d, ln_eps=1e-5, ln_shift=C.c_void_p(m5d.data_ptr()),
+              ln_scale=C.c_void_p(m5d.data_ptr() + 128 * 4), ln_ld=6 * 128)
+    assert rel_err(got.reshape(B, hw, 512), ref) < 1.5e-2
+    # (6) K = 256 -> 128 (64 KiB of weights: two 8-wave workgroups per CU), residual + ReLU epilogue
+    x6 = bf(torch.randn(B, hw, 256))
+    w6, bias6 = bf(torch.randn(128, 256) / 16), torch.randn(128)
+    res6 = bf(torch.randn(B, hw, 128))
+    ref = F.relu(F.linear(x6, w6, bias6) + res6)
+    x6d, r6d = x6.cuda().to(torch.bfloat16), res6.cuda().to(torch.bfloat16)
+    out = torch.empty(B, H, W, 128, device="cuda", dtype=torch.bfloat16)
+    got = run(ConvW(w6, bias6, e.dev, e.tdt), x6d, out, epi=L.EPI_RES_RELU, res=r6d)
+    assert rel_err(got.reshape(B, hw, 128), ref) < 1.5e-2
