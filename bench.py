@@ -25,6 +25,7 @@ import torch  # noqa: E402
 SIZE, S_DDIM = 512, 50
 DIM, MULTS = 64, (1, 2, 4, 8)
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0          # HBM3E, MI355X_MICROARCH.md
 ALG_GFLOP_PER_FORWARD = 575.5  # SURVEY.md section 8(d), 512x512, B=1
 
 
@@ -50,9 +51,30 @@ def conv_flops(p):
     return 2.0 * p.B * p.OH * p.OW * p.Cout * p.KH * p.KW * cin * p.ndir
 
 
-def roofline_leg(dif, x, noise, reps=5):
-    """Dominant kernel family = conv_igemm_kernel (all dense contractions).  Replays exactly the
-    fd_conv2d launches of one UNet forward between HIP events on the launch stream."""
+def _time_launches(lib, launches, reps=5):
+    """Best-of-`reps` HIP-event time (ms) of replaying `launches` back to back.  Every launch of this
+    library goes to torch's CURRENT stream (engine.stream), which is the stream torch.cuda.Event
+    records on."""
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    best = None
+    for _ in range(reps):
+        ev0.record()
+        for n, a in launches:
+            getattr(lib, n)(*a)
+        ev1.record()
+        ev1.synchronize()
+        ms = ev0.elapsed_time(ev1)
+        best = ms if best is None else min(best, ms)
+    return best
+
+
+def roofline_leg(dif, x, noise):
+    """Roofline of the dominant kernel symbol of the rocprofv3 --stats summary of this command
+    (profiles/): dwconv3x3_bf16_kernel, the depthwise 3x3 of the SS2D / channel-attention branches
+    (HBM-bound: 18 flop per 4 algorithmic bytes).  Replays exactly its launches of one UNet forward
+    between HIP events.  `others` carries the same measurement for the runner-up symbols
+    (conv3x3_halo_kernel: MFMA-bound implicit GEMM) so the table in profiles/ can be cross-checked."""
     from founddiff_amd import _lib as L
     eng = dif._eng()
     B = x.shape[0]
@@ -65,43 +87,39 @@ def roofline_leg(dif, x, noise, reps=5):
     eng.forward(img, x_in, tb)
     trace, L.TRACE = L.TRACE, None
     lib = L.lib()
-    # dominant kernel symbol of the rocprofv3 --stats summary of this command (profiles/): the
-    # implicit-GEMM tile variant <bf16, BM=64, BN=128> (fd_conv_kernel_id == 2): every dense layer of
-    # the <=128x128 levels with Cout > 64.
-    convs = [(n, a) for n, a in trace if n == "fd_conv2d" and lib.fd_conv_kernel_id(a[0]) == 2]
-    flops = sum(conv_flops(a[0]._obj) for _, a in convs)
-    # HIP events recorded on the stream the kernels are launched on: every launch of this library
-    # goes to torch's CURRENT stream (engine.stream), which is the stream torch.cuda.Event records on.
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    best = None
-    for _ in range(reps):
-        ev0.record()
-        for n, a in convs:
-            lib.fd_conv2d(*a)
-        ev1.record()
-        ev1.synchronize()
-        ms = ev0.elapsed_time(ev1)
-        best = ms if best is None else min(best, ms)
-    # whole-forward time with the same events, for the share of the dominant kernel
-    ev0.record()
-    for n, a in trace:
-        getattr(lib, n)(*a)
-    ev1.record()
-    ev1.synchronize()
-    all_ms = ev0.elapsed_time(ev1)
-    achieved = flops / (best * 1e-3) / 1e12
-    traffic = None
+    traffic = {}
     tp = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tp):
-        traffic = json.load(open(tp)).get("conv_igemm_bf16_64_128_hbm_bytes_per_launch")
-    return {"bound": "mfma", "kernel": "conv_igemm_kernel<bf16,64,128>",
-            "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-            "launches_per_forward": len(convs), "avg_launch_us": round(best * 1e3 / len(convs), 2),
-            "alg_gflop_per_launch": round(flops / 1e9 / len(convs), 2),
-            "kernel_ms_per_forward": round(best, 3), "all_kernels_ms_per_forward": round(all_ms, 3),
-            "batch": B}
+        traffic = json.load(open(tp))
+    all_ms = _time_launches(lib, trace, reps=2)
+
+    # ---- dominant: depthwise 3x3.  args = (dtype, in, ld_in, off_in, w, bias, silu, out, ld_out, off_out, B, H, W, C, stream)
+    dws = [(n, a) for n, a in trace if n == "fd_dwconv3x3"]
+    esz = 2                                                     # bf16
+    dw_bytes = sum(2.0 * a[10] * a[11] * a[12] * a[13] * esz for _, a in dws)     # read once + write once
+    dw_ms = _time_launches(lib, dws)
+    dw_gbs = dw_bytes / (dw_ms * 1e-3) / 1e9
+    res = {"bound": "hbm", "kernel": "dwconv3x3_bf16_kernel",
+           "achieved": round(dw_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+           "frac": round(dw_gbs / PEAK_HBM_GBS, 4),
+           "traffic": traffic.get("dwconv3x3_bf16_hbm_bytes_per_launch"),
+           "launches_per_forward": len(dws), "avg_launch_us": round(dw_ms * 1e3 / len(dws), 2),
+           "alg_bytes_per_launch": round(dw_bytes / len(dws)),
+           "kernel_ms_per_forward": round(dw_ms, 3), "all_kernels_ms_per_forward": round(all_ms, 3),
+           "batch": B, "others": []}
+    # ---- runner-up symbols: halo-tiled 3x3 implicit GEMM (fd_conv_kernel_id == 11), MFMA-bound
+    halo = [(n, a) for n, a in trace if n == "fd_conv2d" and lib.fd_conv_kernel_id(a[0]) == 11]
+    if halo:
+        fl = sum(conv_flops(a[0]._obj) for _, a in halo)
+        ms = _time_launches(lib, halo)
+        tf = fl / (ms * 1e-3) / 1e12
+        res["others"].append({"bound": "mfma", "kernel": "conv3x3_halo_kernel<64|128>", "achieved": round(tf, 1),
+                              "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4),
+                              "traffic": traffic.get("conv3x3_halo_hbm_bytes_per_launch"),
+                              "launches_per_forward": len(halo), "avg_launch_us": round(ms * 1e3 / len(halo), 2),
+                              "alg_gflop_per_launch": round(fl / 1e9 / len(halo), 2),
+                              "kernel_ms_per_forward": round(ms, 3)})
+    return res
 
 
 def cpu_baseline_leg(w, x_in01, noise):
