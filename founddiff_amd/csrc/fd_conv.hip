@@ -45,7 +45,11 @@ __device__ __forceinline__ int swz(int row, int chunk) { return (chunk ^ ((row >
 //                                1/BM + 1/BN, so the larger tile halves that traffic.
 // GroupNorm partial sums are always written per 64-row band (one epilogue pass per wave row), so the
 // workspace layout [B][ceil(OHW/64)..] does not depend on the tile height.
-template <typename T, int BM, int BN, int WM, int WN>
+// PW = pointwise fast path (1x1, stride 1, no padding / upsampling / directions, Cin and c0 multiples of
+// the K tile): the gather degenerates to "row m, channels k..k+63", so every per-lane offset is computed
+// once and a K step only advances a wave-uniform base pointer (SGPR base + 32-bit VGPR offset loads) --
+// the general decode costs ~80 VALU instructions per K step against 16-32 MFMAs.
+template <typename T, int BM, int BN, int WM, int WN, bool PW = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const fd_conv_params p) {
     constexpr int NTHR = 64 * WM * WN, NWAVE = WM * WN;
     constexpr int RPL = NTHR / 8;            // tile rows covered by one loader pass (8 chunks per row)
@@ -100,7 +104,45 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const fd_conv_
     const int64_t img_px = (int64_t)p.H * p.W;
     const T *in0b = in0 + (int64_t)b * img_px * p.ld0;
     const T *in1b = in1 ? in1 + (int64_t)b * img_px * p.ld1 : nullptr;
-    auto gload = [&](int) {
+    unsigned aoff0[AR], adelta[AR], woff[NB];   // adelta = offset in source 1 minus offset in source 0
+    bool aok[AR], wok[NB];
+    if constexpr (PW) {
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            const int m = mt * BM + rbase + RPL * i;
+            aok[i] = m < OHW;
+            const int mm = aok[i] ? m : 0;
+            aoff0[i] = (unsigned)(mm * p.ld0 + chunk * CH);
+            adelta[i] = (unsigned)(mm * p.ld1) - (unsigned)(mm * p.ld0);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int n = nt * BN + rbase + RPL * i;
+            wok[i] = n < p.Cout;
+            woff[i] = (unsigned)((wok[i] ? n : 0) * K + chunk * CH);
+        }
+    }
+    auto gload = [&](int kt) {
+        if constexpr (PW) {
+            const int kb = kt * BK;                    // wave-uniform
+            const bool from0 = kb < p.c0;
+            const unsigned sel = from0 ? 0u : ~0u;     // uniform mask instead of a select between arrays
+            const T *src = from0 ? in0b + p.off0 + kb : in1b + p.off1 + (kb - p.c0);
+            const T *wsrc = wgt + kb;
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
+                u32x4 v = {0, 0, 0, 0};
+                if (aok[i]) v = *(const u32x4 *)(src + (aoff0[i] + (adelta[i] & sel)));
+                ra[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                u32x4 v = {0, 0, 0, 0};
+                if (wok[i]) v = *(const u32x4 *)(wsrc + woff[i]);
+                rb[i] = v;
+            }
+            return;
+        }
         int kh, kw, c;
         bool kv;
         if (t_cb + BK <= Cin) {
@@ -501,17 +543,23 @@ extern "C" int fd_conv2d(const fd_conv_params *pp, void *stream) {
     const int BMs[5] = {128, 128, 64, 64, 128}, BNs[5] = {128, 64, 128, 64, 256};
     dim3 grid(cdiv((int64_t)p.OH * p.OW, BMs[kid]), cdiv(p.Cout, BNs[kid]), p.B * p.ndir), block(kid == 4 ? 512 : 256);
     hipStream_t s = (hipStream_t)stream;
-#define FD_CONV_LAUNCH(T_, BM_, BN_, WM_, WN_) \
-    hipLaunchKernelGGL((conv_igemm_kernel<T_, BM_, BN_, WM_, WN_>), grid, block, 0, s, p)
-#define FD_CONV_DISPATCH(T_)                                     \
-    switch (kid) {                                               \
-    case 0: FD_CONV_LAUNCH(T_, 128, 128, 2, 2); break;           \
-    case 1: FD_CONV_LAUNCH(T_, 128, 64, 2, 2); break;            \
-    case 2: FD_CONV_LAUNCH(T_, 64, 128, 2, 2); break;            \
-    case 3: FD_CONV_LAUNCH(T_, 64, 64, 2, 2); break;             \
-    default: FD_CONV_LAUNCH(T_, 128, 256, 2, 4); break;          \
+    // pointwise fast path (bf16): same tiles, same K order, same results -- only the address math differs
+    const bool pw = p.dtype == FD_BF16 && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad_h == 0 && p.pad_w == 0 &&
+                    !p.upsample && p.ndir == 1 && p.OH == p.H && p.OW == p.W && (p.c0 + p.c1) % 64 == 0 &&
+                    p.c0 % 64 == 0 && (int64_t)p.Cout * (p.c0 + p.c1) < (1ll << 31);
+#define FD_CONV_LAUNCH(T_, BM_, BN_, WM_, WN_, PW_) \
+    hipLaunchKernelGGL((conv_igemm_kernel<T_, BM_, BN_, WM_, WN_, PW_>), grid, block, 0, s, p)
+#define FD_CONV_DISPATCH(T_, PW_)                                     \
+    switch (kid) {                                                    \
+    case 0: FD_CONV_LAUNCH(T_, 128, 128, 2, 2, PW_); break;           \
+    case 1: FD_CONV_LAUNCH(T_, 128, 64, 2, 2, PW_); break;            \
+    case 2: FD_CONV_LAUNCH(T_, 64, 128, 2, 2, PW_); break;            \
+    case 3: FD_CONV_LAUNCH(T_, 64, 64, 2, 2, PW_); break;             \
+    default: FD_CONV_LAUNCH(T_, 128, 256, 2, 4, PW_); break;          \
     }
-    if (p.dtype == FD_BF16) { FD_CONV_DISPATCH(bf16) } else { FD_CONV_DISPATCH(float) }
+    if (p.dtype == FD_BF16) {
+        if (pw) { FD_CONV_DISPATCH(bf16, true) } else { FD_CONV_DISPATCH(bf16, false) }
+    } else { FD_CONV_DISPATCH(float, false) }
 #undef FD_CONV_DISPATCH
 #undef FD_CONV_LAUNCH
     FD_LAUNCH_OK("fd_conv2d");

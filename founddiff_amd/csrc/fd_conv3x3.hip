@@ -2,8 +2,8 @@
 // halo-tiled implicit GEMM on MFMA, bf16.
 //
 // The generic kernel (fd_conv.hip) re-fetches the shifted A tile from L2 for each of the 9 taps
-// and pays one global-load latency per K step.  Here a workgroup owns an 8 x 16 pixel output
-// tile; per 64-channel slab it loads the (8+2) x (16+2) halo ONCE into LDS (coalesced 128-byte
+// and pays one global-load latency per K step.  Here a workgroup owns an 8 x 16 (or 16 x 16) pixel
+// output tile; per 64-channel slab it loads the (TH+2) x (16+2) halo ONCE into LDS (coalesced 128-byte
 // pixel rows, through the nearest-x2 up-sampling index map and the two-source concat when
 // present) and all 9 taps read their A fragments straight from that halo tile: an MFMA fragment
 // is "16 bytes of one pixel's channel vector", so a tap is just a different pixel offset -- no
@@ -16,16 +16,23 @@
 
 namespace {
 
-constexpr int TH = 8, TW = 16, BM = TH * TW;      // output tile (pixels)
-constexpr int HY = TH + 2, HX = TW + 2, HP = HY * HX;   // halo
+constexpr int TW = 16, HX = TW + 2;                // output tile width (pixels), halo width
 constexpr int ROWB = 128;                          // bytes per pixel row of a 64-channel bf16 slab
-constexpr int HL = (HP * 8 + 255) / 256;           // halo 16-byte chunks per thread (6)
 
 __device__ __forceinline__ int swz(int row, int chunk) { return (chunk ^ ((row >> 1) & 7)) << 4; }
 
-template <int BN>
-__global__ __launch_bounds__(256) void conv3x3_halo_kernel(const fd_conv_params p) {
-    constexpr int NB = BN / 32, NT = BN / 32, MT = 4;
+// Tile = TH x 16 output pixels x BN channels, 4 waves, every wave a 64-pixel x 64-channel sub-tile (4 tile
+// rows x 16 px, MT = NT = 4: 8 fragment reads per 16 MFMAs -- a 32-channel wave tile needs 6 per 8 and
+// saturates the LDS array):
+//   <128, 8>   Cout > 64:  2 (row groups) x 2 (channel halves) waves
+//   <64, 16>   Cout <= 64: 4 row groups, each wave all 64 channels (halo overhead 1.27x instead of 1.41x)
+//   <64, 8>    Cout <= 64 when OH is not a multiple of 16: 2 x 2 waves of 64 px x 32 channels
+template <int BN, int TH>
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_params p) {
+    constexpr int BM = TH * TW, HY = TH + 2, HP = HY * HX;
+    constexpr int HL = (HP * 8 + 255) / 256;          // halo 16-byte chunks per thread
+    constexpr int WMW = TH / 4, WNW = 4 / WMW;        // wave grid
+    constexpr int NB = BN / 32, NT = BN / WNW / 16, MT = 4;
     constexpr int HALO_B = HP * ROWB;                 // 23040
     constexpr int WT_B = BN * ROWB;
     constexpr int LOOP_B = HALO_B + 2 * WT_B;      // ONE halo buffer (the next slab waits in registers)
@@ -83,15 +90,18 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const fd_conv_params 
     };
     // ---- weight tile loader: [BN rows][64 k] of tap t, slab s
     const int chunk = tid & 7, rbase = tid >> 3;
-    auto w_gload = [&](int slab, int tap) {
-        const int k = tap * Cin + slab * 64 + chunk * 8;
+    // per-lane element offset of its weight row, computed once; a tap / slab only moves the wave-uniform
+    // base (rows beyond Cout read row Cout-1: their products land in columns the epilogue never stores)
+    unsigned woff[NB];
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int n = nt * BN + rbase + 32 * i;
-            u32x4 v = {0, 0, 0, 0};
-            if (n < p.Cout) v = *(const u32x4 *)(wgt + (int64_t)n * K + k);
-            rb[i] = v;
-        }
+    for (int i = 0; i < NB; ++i) {
+        const int n = min(nt * BN + rbase + 32 * i, p.Cout - 1);
+        woff[i] = (unsigned)(n * K + chunk * 8) * 2u;     // BYTE offset: (SGPR base + 32-bit VGPR offset) loads
+    }
+    auto w_gload = [&](int slab, int tap) {
+        const bf16 *wb = wgt + (tap * Cin + slab * 64);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) rb[i] = *(const u32x4 *)((const char *)wb + woff[i]);
     };
     auto w_lstore = [&](int buf) {
         unsigned char *sB = smem + HALO_B + buf * WT_B;
@@ -102,13 +112,32 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const fd_conv_params 
         }
     };
 
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WNW, wn = wave % WNW;
     const int fr = lane & 15, fg = lane >> 4;
     f32x4 acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // LDS byte offsets of the A / B fragments, computed ONCE: with the 9 taps unrolled a tap is the
+    // compile-time pick aoff[i + kh][kw] (6 halo rows x 3 column shifts cover all 36 (tap, m-tile) pairs)
+    // and the second K32 step of a 64-channel slab flips bit 6 of the swizzled chunk (chunk ^ 4).  Before,
+    // the per-tap swizzle arithmetic cost 3.6 VALU instructions per MFMA (PMC) -- more than the 8 issue
+    // cycles a 16x16x32 MFMA leaves free.
+    int aoff[6][3], boff[NT];
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int hp = (4 * wm + j) * HX + fr + kw;
+            aoff[j][kw] = hp * ROWB + swz(hp, fg);
+        }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int r = (BN / WNW) * wn + 16 * j + fr;
+        boff[j] = r * ROWB + swz(r, fg);
+    }
 
     halo_gload(0);
     w_gload(0, 0);
@@ -119,7 +148,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const fd_conv_params 
     for (int slab = 0; slab < nslab; ++slab) {
         if (slab + 1 < nslab) halo_gload(slab + 1);          // in flight during this slab's 9 taps
         const unsigned char *sH = smem;
-#pragma unroll 1
+#pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const bool last_tap = tap == 8;
             const bool more = !(last_tap && slab + 1 == nslab);
@@ -130,16 +159,10 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const fd_conv_params 
             for (int ks = 0; ks < 2; ++ks) {
                 bf16x8 af[MT], bfr[NT];
 #pragma unroll
-                for (int i = 0; i < MT; ++i) {
-                    const int ty = 4 * wm + i;                         // m tile = one tile row of 16 pixels
-                    const int hp = (ty + kh) * HX + fr + kw;
-                    af[i] = *(const bf16x8 *)(sH + hp * ROWB + swz(hp, ks * 4 + fg));
-                }
+                for (int i = 0; i < MT; ++i)                         // m tile i = tile row 4*wm + i
+                    af[i] = *(const bf16x8 *)(sH + (aoff[i + kh][kw] ^ (ks << 6)));
 #pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    const int r = (BN / 2) * wn + 16 * j + fr;
-                    bfr[j] = *(const bf16x8 *)(sB + r * ROWB + swz(r, ks * 4 + fg));
-                }
+                for (int j = 0; j < NT; ++j) bfr[j] = *(const bf16x8 *)(sB + (boff[j] ^ (ks << 6)));
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -165,7 +188,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const fd_conv_params 
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int r = 64 * wm + 16 * i + fg * 4 + e;
-                const int cc = (BN / 2) * wn + 16 * j + fr;
+                const int cc = (BN / WNW) * wn + 16 * j + fr;
                 sC[r * BN + cc] = acc[i][j][e];
             }
     __syncthreads();
@@ -217,13 +240,17 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const fd_conv_params 
                 float s = 0.f, q = 0.f;
 #pragma unroll
                 for (int w = 0; w < 4; ++w) { s += s_stat[w][tid][0]; q += s_stat[w][tid][1]; }
-                // the workspace holds one entry per 64 output pixels (fd_conv_mtiles): this 128-pixel
-                // tile fills entry 2t and zeroes entry 2t+1
-                float *sp = p.stats_partial + (((int64_t)b * 2 * gridDim.x + 2 * blockIdx.x) * p.Cout + n) * 2;
+                // the workspace holds one entry per 64 output pixels (fd_conv_mtiles): this BM-pixel
+                // tile fills its first entry and zeroes the other BM/64 - 1
+                constexpr int EPT = BM / 64;
+                float *sp = p.stats_partial + (((int64_t)b * EPT * gridDim.x + EPT * blockIdx.x) * p.Cout + n) * 2;
                 sp[0] = s;
                 sp[1] = q;
-                sp[2 * p.Cout] = 0.f;
-                sp[2 * p.Cout + 1] = 0.f;
+#pragma unroll
+                for (int e = 1; e < EPT; ++e) {
+                    sp[2 * e * p.Cout] = 0.f;
+                    sp[2 * e * p.Cout + 1] = 0.f;
+                }
             }
         }
     }
@@ -240,18 +267,21 @@ int fd_conv3x3_ok(const fd_conv_params &p) {
     if (p.prologue != FD_PRO_NONE) return 0;
     if (Cin % 64 || p.c0 % 64 || p.Cout % 8) return 0;
     if (p.ld0 % 8 || p.off0 % 8 || (p.in1 && (p.ld1 % 8 || p.off1 % 8)) || p.ldo % 8 || p.offo % 8) return 0;
-    if (p.OH % TH || p.OW % TW) return 0;
+    if (p.OH % 8 || p.OW % TW) return 0;
     if (p.OH != (p.upsample ? 2 * p.H : p.H) || p.OW != (p.upsample ? 2 * p.W : p.W)) return 0;
     // at <= 16384 pixels per image the generic tiles (64-row / 8-wave 128x256) fill the chip better
     if ((int64_t)p.OH * p.OW < 4096) return 0;
-    if ((int64_t)p.H * p.W * (p.ld0 > p.ld1 ? p.ld0 : p.ld1) >= (1ll << 31)) return 0;
+    if ((int64_t)p.H * p.W * (p.ld0 > p.ld1 ? p.ld0 : p.ld1) >= (1ll << 30)) return 0;   // 32-bit byte offsets
+    if ((int64_t)p.Cout * 9 * Cin >= (1ll << 30)) return 0;
     return 1;
 }
 
 int fd_conv3x3_launch(const fd_conv_params &p, hipStream_t s) {
     const bool wide = p.Cout > 64;
-    dim3 grid((p.OH / TH) * (p.OW / TW), cdiv(p.Cout, wide ? 128 : 64), p.B), block(256);
-    if (wide) hipLaunchKernelGGL(conv3x3_halo_kernel<128>, grid, block, 0, s, p);
-    else hipLaunchKernelGGL(conv3x3_halo_kernel<64>, grid, block, 0, s, p);
+    const int th = (!wide && p.OH % 16 == 0) ? 16 : 8;
+    dim3 grid((p.OH / th) * (p.OW / TW), cdiv(p.Cout, wide ? 128 : 64), p.B), block(256);
+    if (wide) hipLaunchKernelGGL((conv3x3_halo_kernel<128, 8>), grid, block, 0, s, p);
+    else if (th == 16) hipLaunchKernelGGL((conv3x3_halo_kernel<64, 16>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((conv3x3_halo_kernel<64, 8>), grid, block, 0, s, p);
     return 0;
 }

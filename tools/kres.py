@@ -18,6 +18,6 @@ for line in r.stderr.splitlines():
             if key == "lds":
                 n = re.sub(r"\(anonymous namespace\)::|void ", "", cur.get("name", "?"))
                 n = re.sub(r"\(.*", "", n)
-                print(f"{n[:70]:70s} vgpr={cur.get('vgpr')} scratch={cur.get('scratch')} occ={cur.get('occ')} lds={cur.get('lds')}")
+                print(f"{n[:70]:70s} vgpr={cur.get('vgpr')}+a{cur.get('agpr')} scratch={cur.get('scratch')} occ={cur.get('occ')} lds={cur.get('lds')}")
 if r.returncode:
     print(r.stderr[-2000:])
