@@ -233,7 +233,8 @@ class DAEngine:
              prologue=L.PRO_NONE, ln_gamma=None, ln_beta=None, ln_eps=1e-5, ln_shift=None, ln_scale=None,
              ln_ld=0, ln_z=None, ln_ldz=0, ln_offz=0, probe=False):
         """One fd_conv2d launch.  `probe=True` only asks the library whether this conv can take the
-        fused LayerNorm prologue (bf16 streaming row-GEMM path) and launches nothing."""
+        fused LayerNorm prologue (bf16 streaming row-GEMM path) and launches nothing; `probe="kid"`
+        returns fd_conv_kernel_id (tests pin which kernel a shape exercises)."""
         def ptr(v):
             if v is None:
                 return None
@@ -276,6 +277,8 @@ class DAEngine:
         p.ln_gamma, p.ln_beta = ptr(ln_gamma), ptr(ln_beta)
         p.ln_shift, p.ln_scale, p.ln_ld = ptr(ln_shift), ptr(ln_scale), ln_ld
         p.ln_z, p.ln_ldz, p.ln_offz = ptr(ln_z), ln_ldz, ln_offz
+        if probe == "kid":          # which kernel would run (include/founddiff_hip.h: fd_conv_kernel_id)
+            return int(L.lib().fd_conv_kernel_id(C.byref(p)))
         if probe:
             return bool(L.lib().fd_conv_prologue_ok(C.byref(p)))
         L.call("fd_conv2d", C.byref(p), self.stream)

@@ -422,3 +422,41 @@ def test_row_gemm_fused_prologues(eng_factory):
     out = torch.empty(B, H, W, 128, device="cuda", dtype=torch.bfloat16)
     got = run(ConvW(w6, bias6, e.dev, e.tdt), x6d, out, epi=L.EPI_RES_RELU, res=r6d)
     assert rel_err(got.reshape(B, hw, 128), ref) < 1.5e-2
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(c0=64, c1=0, cout=64, hw=(64, 64), up=False, relu=False),      # <64, 16>: 16x16 tile, 64x64 wave tiles
+    dict(c0=64, c1=64, cout=192, hw=(72, 80), up=False, relu=False),    # <128, 8>: two sources, ragged last N tile
+    dict(c0=64, c1=0, cout=40, hw=(72, 64), up=True, relu=True),        # <64, 8>: OH % 16 != 0, x2 upsample, ReLU
+])
+def test_conv3x3_halo(eng_factory, cfg):
+    """Halo-tiled 3x3 implicit GEMM (bf16): every tile variant, with the GroupNorm partial sums."""
+    from founddiff_amd import _lib as L
+    from founddiff_amd.engine import ConvW
+    e = eng_factory("bf16")
+    torch.manual_seed(21)
+    B = 2
+    OH, OW = cfg["hw"]
+    H, W = (OH // 2, OW // 2) if cfg["up"] else (OH, OW)
+    cin = cfg["c0"] + cfg["c1"]
+    x = rq(torch.randn(B, cin, H, W), "bf16")
+    w = rq(torch.randn(cfg["cout"], cin, 3, 3) / (3 * cin ** 0.5), "bf16")
+    bias = torch.randn(cfg["cout"])
+    xin = F.interpolate(x, scale_factor=2, mode="nearest") if cfg["up"] else x
+    ref = F.conv2d(xin, w, bias, padding=1)
+    if cfg["relu"]:
+        ref = F.relu(ref)
+    cw = ConvW(w, bias, e.dev, e.tdt)
+    out = torch.empty(B, OH, OW, cfg["cout"], device="cuda", dtype=e.tdt)
+    part = torch.full((B, L.lib().fd_conv_mtiles(OH, OW), cfg["cout"], 2), 7.0, device="cuda")   # must be overwritten
+    kw = dict(c0=cfg["c0"], stats=part, upsample=cfg["up"], epi=L.EPI_RELU if cfg["relu"] else L.EPI_NONE)
+    xa = nhwc(x[:, :cfg["c0"]], e.tdt)
+    if cfg["c1"]:
+        kw.update(in1=nhwc(x[:, cfg["c0"]:], e.tdt), c1=cfg["c1"])
+    assert e.conv(cw, xa, B, H, W, out, probe="kid", **kw) == 11, "expected the halo-tiled kernel"
+    e.conv(cw, xa, B, H, W, out, **kw)
+    torch.cuda.synchronize()
+    assert rel_err(nchw(out), ref) < 1.2e-2
+    s = part.sum(1).cpu()
+    assert rel_err(s[..., 0], ref.sum((2, 3))) < 5e-3
+    assert rel_err(s[..., 1], (ref ** 2).sum((2, 3))) < 5e-3
