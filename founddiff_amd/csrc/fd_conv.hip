@@ -500,7 +500,8 @@ extern "C" int fd_conv_kernel_id(const fd_conv_params *pp) {
     // that emit them keep the batch-independent configuration.
     // (measured at batch 8: wins 12-25 % for Cout 256..512; loses 5-10 % for Cout >= 1024, where the small
     //  tile already launches plenty of workgroups per A tile)
-    if (!tall && pp->Cout >= 256 && pp->Cout <= 512 && !pp->stats_partial && pp->KH * pp->KW * (pp->c0 + pp->c1) >= 256) {
+    static const int big_max = getenv("FD_CONV_BIG_MAX") ? atoi(getenv("FD_CONV_BIG_MAX")) : 512;
+    if (!tall && pp->Cout >= 256 && pp->Cout <= big_max && !pp->stats_partial && pp->KH * pp->KW * (pp->c0 + pp->c1) >= 256) {
         const int64_t wgs = (int64_t)pp->B * pp->ndir * cdiv((int64_t)pp->OH * pp->OW, 128) * cdiv(pp->Cout, 256);
         if (wgs >= 192 || getenv("FD_CONV_BIG_TILE")) return 4;
     }

@@ -34,13 +34,20 @@ __device__ __forceinline__ void scan_pos(const ScanGeom &g, int k, int l, int &l
 // back as wave-uniform broadcasts; each lane prefetches U of its u values per group so U
 // global loads are in flight per wave while the recurrence of the previous group runs.
 template <typename T, int N, int R, bool FINAL>
-__global__ __launch_bounds__(256) void scan_chunk_kernel(const T *__restrict__ xc, const float *__restrict__ xdbl,
+__global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 8 ? 5 : 1))) void scan_chunk_kernel(const T *__restrict__ xc, const float *__restrict__ xdbl,
                                                         const float *__restrict__ dtw, const float *__restrict__ dtb,
                                                         const float *__restrict__ A, const float *__restrict__ Ds,
                                                         T *__restrict__ y, float *__restrict__ wsH,
                                                         float *__restrict__ wsP, const ScanGeom g) {
     constexpr int CD = R + 2 * N;
     constexpr int CDP = (CD + 3) & ~3;
+    // bf16 mode: dt is carried as L = log2(1 + 2^z), z = log2e*(w.x + bias), i.e. dt/ln2.  log2e is folded
+    // into w and bias, exp(dt*A) = exp2(L*A) needs no constant at all, and the state is h/ln2 in both
+    // passes and in the carries (linear in dt*u) -- softplus shrinks from 7 VALU instructions to 4
+    // (v_min, v_exp, v_add, v_log).  z is clamped at 126: 1 + 2^z == 2^z there, so L == z exactly.
+    constexpr bool LOG2U = sizeof(T) == 2;
+    constexpr float WS = LOG2U ? 1.4426950408889634f : 1.f;          // scale of w, bias
+    constexpr float AS = LOG2U ? 1.f : 1.4426950408889634f;          // scale of A
     extern __shared__ __attribute__((aligned(16))) float sx[];      // [CL][CDP]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -62,19 +69,23 @@ __global__ __launch_bounds__(256) void scan_chunk_kernel(const T *__restrict__ x
         int h2, w2;
         if (odd) { w2 = l / g.H2; h2 = l - w2 * g.H2; }
         else { h2 = l / g.W2; w2 = l - h2 * g.W2; }
-        sx[row * CDP + e] = xb[(int64_t)(h2 * g.W2 + w2) * CD + e];
+        float v = xb[(int64_t)(h2 * g.W2 + w2) * CD + e];
+        // bf16 mode keeps dt in base-2 units (see `step`): the missing ln2 of dt*u is applied once per
+        // staged C element instead of once per (step, channel)
+        if (LOG2U && FINAL && e >= R + N) v *= 0.6931471805599453f;
+        sx[row * CDP + e] = v;
     }
 
     // state / weights as float pairs: the recurrence runs on v_pk_mul_f32 / v_pk_fma_f32 (two states
     // per instruction at the scalar-op issue rate); only the two v_exp_f32 per pair stay scalar
     f32x2 w[R / 2], a2[N / 2], h[N / 2];
 #pragma unroll
-    for (int r = 0; r < R / 2; ++r) w[r] = f32x2{dtw[(int64_t)kd * R + 2 * r], dtw[(int64_t)kd * R + 2 * r + 1]};
+    for (int r = 0; r < R / 2; ++r) w[r] = f32x2{dtw[(int64_t)kd * R + 2 * r], dtw[(int64_t)kd * R + 2 * r + 1]} * WS;
     // exp(dt*A) = exp2(dt * A*log2(e)): fold the constant into A once (v_exp_f32 is exp2)
 #pragma unroll
     for (int n = 0; n < N / 2; ++n)
-        a2[n] = f32x2{A[(int64_t)kd * N + 2 * n], A[(int64_t)kd * N + 2 * n + 1]} * 1.4426950408889634f;
-    const float bias = dtb[kd];
+        a2[n] = f32x2{A[(int64_t)kd * N + 2 * n], A[(int64_t)kd * N + 2 * n + 1]} * AS;
+    const float bias = dtb[kd] * WS;
     const float Dd = FINAL ? Ds[kd] : 0.f;
     const int64_t cbase = (((int64_t)bk * g.nch + chunk) * N) * g.D + d;   // [bk][chunk][n][d]
     if (FINAL) {
@@ -88,8 +99,31 @@ __global__ __launch_bounds__(256) void scan_chunk_kernel(const T *__restrict__ x
     float sdt = 0.f;
     // wave-uniform row base + per-lane channel index: the row address stays on the scalar unit and the
     // loads/stores use the (sgpr base, vgpr offset) form -- no 64-bit vector address math per step
+    // u / y rows through raw buffer descriptors: address = image base (SGPRs of the descriptor) + scalar
+    // row offset (soffset) + the lane's constant channel offset -- no per-step VALU address arithmetic
     const T *ub = xc + (int64_t)b * g.H * g.W * g.D;
     T *yb = FINAL ? y + (int64_t)b * g.H * g.W * g.D : nullptr;
+    const int rowb = g.D * (int)sizeof(T);
+    const int img_bytes = g.H * g.W * rowb;
+    const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc((void *)ub, 0, img_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void *)(FINAL ? yb : (T *)ub), 0, img_bytes, 0x00020000);
+    const int voff = d * (int)sizeof(T);
+    auto ld_u = [&](int soff) -> float {
+        if constexpr (sizeof(T) == 2) {
+            const unsigned short r = __builtin_amdgcn_raw_buffer_load_b16(rs_u, voff, soff, 0);
+            return __builtin_bit_cast(float, (uint32_t)r << 16);
+        } else {
+            return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_u, voff, soff, 0));
+        }
+    };
+    auto st_y = [&](int soff, float v) {
+        if constexpr (sizeof(T) == 2) {
+            const bf16 hv = (bf16)v;
+            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hv), rs_y, voff, soff, 0);
+        } else {
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs_y, voff, soff, 0);
+        }
+    };
     // scan position -> (h2, w2) kept as scalar counters: no division in the loop
     // The integer division is computed on the vector unit; readfirstlane moves the (uniform) result to
     // SGPRs, otherwise everything derived from it (counters, wrap tests, row addresses) is treated as
@@ -102,13 +136,15 @@ __global__ __launch_bounds__(256) void scan_chunk_kernel(const T *__restrict__ x
     const int wrap_fix = s_o - NI * s_i;
     __syncthreads();
 
-    auto step = [&](const float *xr, float u, int pix) {
+    auto step = [&](const float *xr, float u, int soff) {
         const f32x2 *xr2 = (const f32x2 *)xr;          // row = [dt_r (R) | B (N) | C (N)], all even
         f32x2 dv2 = {bias, 0.f};
 #pragma unroll
         for (int r = 0; r < R / 2; ++r) dv2 = w[r] * xr2[r] + dv2;
         const float dv = dv2.x + dv2.y;
-        const float dt = sizeof(T) == 2 ? fd_softplus_bf16(dv) : fd_softplus_fast(dv);
+        float dt;
+        if constexpr (LOG2U) dt = __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(fminf(dv, 126.f)));
+        else dt = fd_softplus_fast(dv);
         const float dtu = dt * u;
         if (!FINAL) sdt += dt;
         f32x2 acc2 = {0.f, 0.f};
@@ -119,10 +155,10 @@ __global__ __launch_bounds__(256) void scan_chunk_kernel(const T *__restrict__ x
             h[n] = da * h[n] + xr2[R / 2 + n] * dtu;
             if (FINAL) acc2 = h[n] * xr2[R / 2 + N / 2 + n] + acc2;
         }
-        if (FINAL) st1(yb + (int64_t)pix * g.D + d, acc2.x + acc2.y + Dd * u);
+        if (FINAL) st_y(soff, acc2.x + acc2.y + Dd * u);
     };
-    auto advance = [&](int &pix) {
-        pix = pixc;
+    auto advance = [&](int &soff) {            // -> byte offset of the pixel's row inside the image
+        soff = pixc * rowb;
         ++ci;
         const bool wrap = ci == NI;
         ci = wrap ? 0 : ci;
@@ -135,16 +171,16 @@ __global__ __launch_bounds__(256) void scan_chunk_kernel(const T *__restrict__ x
     int l = l0;
     const int ngroups = (l1 - l0) / U;
     int pixA[U], pixB[U];
-    T uA[U], uB[U];
-    auto fetch = [&](int (&pix)[U], T (&u)[U]) {
+    float uA[U], uB[U];
+    auto fetch = [&](int (&pix)[U], float (&u)[U]) {
 #pragma unroll
         for (int s = 0; s < U; ++s) advance(pix[s]);
 #pragma unroll
-        for (int s = 0; s < U; ++s) u[s] = *(ub + (int64_t)pix[s] * g.D + d);
+        for (int s = 0; s < U; ++s) u[s] = ld_u(pix[s]);
     };
-    auto run = [&](const int (&pix)[U], const T (&u)[U]) {
+    auto run = [&](const int (&pix)[U], const float (&u)[U]) {
 #pragma unroll
-        for (int s = 0; s < U; ++s) step(sx + (l - l0 + s) * CDP, (float)u[s], pix[s]);
+        for (int s = 0; s < U; ++s) step(sx + (l - l0 + s) * CDP, u[s], pix[s]);
         l += U;
     };
     if (ngroups > 0) fetch(pixA, uA);
@@ -157,9 +193,9 @@ __global__ __launch_bounds__(256) void scan_chunk_kernel(const T *__restrict__ x
         }
     }
     for (; l < l1; ++l) {
-        int pix;
-        advance(pix);
-        step(sx + (l - l0) * CDP, ld1(ub + (int64_t)pix * g.D + d), pix);
+        int soff;
+        advance(soff);
+        step(sx + (l - l0) * CDP, ld_u(soff), soff);
     }
     if (!FINAL) {
 #pragma unroll
@@ -279,6 +315,7 @@ extern "C" int fd_selective_scan(int dtype, const void *xc, const float *xdbl, c
     FD_REQUIRE(xc && xdbl && dtw && dtb && A && Ds && y && ws, "fd_selective_scan: null pointer");
     FD_REQUIRE(H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "fd_selective_scan: H,W must be even (got %d,%d)", H, W);
     FD_REQUIRE(D % 64 == 0, "fd_selective_scan: d_inner=%d must be a multiple of 64", D);
+    FD_REQUIRE((int64_t)H * W * D * 4 < (1ll << 31), "fd_selective_scan: one image must stay below 2^31 bytes");
     ScanGeom g = make_geom(B, H, W, D, N, R);
     int rc = dtype == FD_BF16
                  ? dispatch_n<bf16>((const bf16 *)xc, xdbl, dtw, dtb, A, Ds, (bf16 *)y, ws, g, (hipStream_t)stream)
