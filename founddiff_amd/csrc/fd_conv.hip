@@ -487,7 +487,7 @@ int fd_conv3x3_ok(const fd_conv_params &p);
 int fd_conv3x3_launch(const fd_conv_params &p, hipStream_t s);
 
 // Which kernel fd_conv2d dispatches `p` to: 10 streaming row-GEMM, 11 halo-tiled 3x3, else the
-// implicit-GEMM tile variant 0 <128,128>, 1 <128,64>, 2 <64,128>, 3 <64,64>, 4 <128,256> (BM, BN).
+// implicit-GEMM tile variant 0 <128,128>, 1 <128,64>, 2 <64,128>, 3 <64,64>, 4 <128,256>, 5 <256,256> (BM, BN).
 extern "C" int fd_conv_kernel_id(const fd_conv_params *pp) {
     if (fd_conv_prologue_ok(pp)) return 10;
     if (fd_conv3x3_ok(*pp)) return 11;
@@ -500,8 +500,13 @@ extern "C" int fd_conv_kernel_id(const fd_conv_params *pp) {
     // that emit them keep the batch-independent configuration.
     // (measured at batch 8: wins 12-25 % for Cout 256..512; loses 5-10 % for Cout >= 1024, where the small
     //  tile already launches plenty of workgroups per A tile)
-    static const int big_max = getenv("FD_CONV_BIG_MAX") ? atoi(getenv("FD_CONV_BIG_MAX")) : 512;
-    if (!tall && pp->Cout >= 256 && pp->Cout <= big_max && !pp->stats_partial && pp->KH * pp->KW * (pp->c0 + pp->c1) >= 256) {
+    // 256x256 (id 5, 8 waves of 64x128): a CU sustains only ~20 B/clk of L2-hit loads, so the MFMA rate of
+    // these K-streaming tiles is set by FLOP per loaded byte = BM*BN/(BM+BN): 600-680 TFLOP/s against 560
+    // for every smaller tile (measured, batch 8; K >= 384 so the 8-step prologue/epilogue amortises).
+    if (!tall && !pp->stats_partial && pp->Cout >= 256 && pp->KH * pp->KW * (pp->c0 + pp->c1) >= 384 &&
+        (int64_t)pp->B * pp->ndir * cdiv((int64_t)pp->OH * pp->OW, 256) * cdiv(pp->Cout, 256) >= 192)
+        return 5;
+    if (!tall && pp->Cout >= 256 && pp->Cout <= 512 && !pp->stats_partial && pp->KH * pp->KW * (pp->c0 + pp->c1) >= 256) {
         const int64_t wgs = (int64_t)pp->B * pp->ndir * cdiv((int64_t)pp->OH * pp->OW, 128) * cdiv(pp->Cout, 256);
         if (wgs >= 192 || getenv("FD_CONV_BIG_TILE")) return 4;
     }
@@ -541,8 +546,8 @@ extern "C" int fd_conv2d(const fd_conv_params *pp, void *stream) {
     FD_REQUIRE((int64_t)p.H * p.W * (p.ld0 > p.ld1 ? p.ld0 : p.ld1) < (1ll << 31),
                "fd_conv2d: one image of a source must hold < 2^31 elements");
     const int kid = fd_conv_kernel_id(pp);
-    const int BMs[5] = {128, 128, 64, 64, 128}, BNs[5] = {128, 64, 128, 64, 256};
-    dim3 grid(cdiv((int64_t)p.OH * p.OW, BMs[kid]), cdiv(p.Cout, BNs[kid]), p.B * p.ndir), block(kid == 4 ? 512 : 256);
+    const int BMs[6] = {128, 128, 64, 64, 128, 256}, BNs[6] = {128, 64, 128, 64, 256, 256};
+    dim3 grid(cdiv((int64_t)p.OH * p.OW, BMs[kid]), cdiv(p.Cout, BNs[kid]), p.B * p.ndir), block(kid >= 4 ? 512 : 256);
     hipStream_t s = (hipStream_t)stream;
     // pointwise fast path (bf16): same tiles, same K order, same results -- only the address math differs
     const bool pw = p.dtype == FD_BF16 && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad_h == 0 && p.pad_w == 0 &&
@@ -556,6 +561,7 @@ extern "C" int fd_conv2d(const fd_conv_params *pp, void *stream) {
     case 1: FD_CONV_LAUNCH(T_, 128, 64, 2, 2, PW_); break;            \
     case 2: FD_CONV_LAUNCH(T_, 64, 128, 2, 2, PW_); break;            \
     case 3: FD_CONV_LAUNCH(T_, 64, 64, 2, 2, PW_); break;             \
+    case 5: FD_CONV_LAUNCH(T_, 256, 256, 4, 2, PW_); break;           \
     default: FD_CONV_LAUNCH(T_, 128, 256, 2, 4, PW_); break;          \
     }
     if (p.dtype == FD_BF16) {
