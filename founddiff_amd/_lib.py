@@ -55,6 +55,9 @@ SIGNATURES = {
     "fd_ln_modulate": (i32, [i32, vp, vp, vp, f32, vp, vp, i32, vp, i32, i64, i32, vp]),
     "fd_ln_gate": (i32, [i32, vp, vp, vp, f32, vp, i32, i32, vp, i32, vp, i32, i64, i32, vp]),
     "fd_dwconv3x3": (i32, [i32, vp, i32, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "fd_pw_dw3x3_ok": (i32, [i32, i32, i32, i32, i32, i32]),
+    "fd_pw_dw3x3": (i32, [i32, vp, i32, i32, i32, vp, vp, f32, vp, vp, i32, vp, i32, vp, vp, i32, vp, i32, i32,
+                          i32, vp, i32, i32, i32, i32, i32, vp]),
     "fd_scan_ws_floats": (i64, [i32, i32, i32, i32, i32]),
     "fd_selective_scan": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "fd_chan_attn_nblk": (i32, [i64]),

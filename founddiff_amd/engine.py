@@ -99,6 +99,15 @@ class DAEngine:
             r["res"] = self._convw(s["res_conv.weight"], s["res_conv.bias"])
         return r
 
+    @staticmethod
+    def _dw_masked(w9c):
+        """[9][C] fp32 taps (tap = 3*dy + dx) -> [5][C] int32 words of bf16 pairs in the layout
+        include/founddiff_hip.h documents for fd_pw_dw3x3."""
+        b = w9c.to(torch.bfloat16).view(torch.int16).to(torch.int32) & 0xFFFF
+        odd = (torch.arange(w9c.shape[1], device=w9c.device) & 1).to(torch.int32) * 16
+        rows = [b[p] | (b[3 + p] << 16) for p in range(3)] + [b[6] | (b[7] << 16), b[8] << odd]
+        return torch.stack(rows).contiguous()
+
     def _pack_mamba(self, s):
         m = s.sub("mamba.")
         C_ = s["norm1.weight"].shape[0]
@@ -123,6 +132,8 @@ class DAEngine:
             temp=self._f(a["temperature"].reshape(-1)),
             wproj=self._f(a["project_out.weight"].reshape(C_, C_)),
         )
+        # tap weights of the two depthwise convs in the operand layout of the fused 1x1 -> 3x3 kernel
+        d["dw_wm"], d["qdw_wm"] = self._dw_masked(d["dw_w"]), self._dw_masked(d["qdw_w"])
         assert d["heads"] * 32 == C_, "TransposedAttention heads must be C/32 (src/DADiff.py:468)"
         d["adaln_w"] = s["adaLN_modulation.1.weight"].detach().float()
         d["adaln_b"] = s["adaLN_modulation.1.bias"].detach().float()
@@ -328,16 +339,24 @@ class DAEngine:
         xz = self._b("xz", (B, H, W, 2 * D))
         ln1 = dict(prologue=L.PRO_LN_MOD, ln_gamma=m["n1w"], ln_beta=m["n1b"], ln_eps=1e-5, ln_shift=mp(0),
                    ln_scale=mp(1), ln_ld=ml)
-        if self.conv(m["in_proj"], x, B, H, W, xz, epi=L.EPI_SILU_SPLIT, split=D, probe=True, **ln1):
+        xc = self._b("xc", (B, H, W, D))
+        fused = bool(L.lib().fd_pw_dw3x3_ok(self.dt, Cc, D, D, H, W))
+        if fused:
+            # LN+modulate -> in_proj -> conv2d+SiLU (x half) / SiLU (z half) in one pass: the x half of
+            # in_proj's output never exists in HBM (xz[..., :D] stays unwritten, z lands in xz[..., D:])
+            L.call("fd_pw_dw3x3", self.dt, _p(x), Cc, 0, Cc, _p(m["n1w"]), _p(m["n1b"]), 1e-5, mp(0), mp(1), ml,
+                   _p(m["in_proj"].w), D, _p(m["dw_wm"]), _p(m["dw_b"]), 1, _p(xc), D, 0,
+                   D, _p(xz), 2 * D, D, B, H, W, s)
+        elif self.conv(m["in_proj"], x, B, H, W, xz, epi=L.EPI_SILU_SPLIT, split=D, probe=True, **ln1):
             self.conv(m["in_proj"], x, B, H, W, xz, epi=L.EPI_SILU_SPLIT, split=D, **ln1)
         else:
             xm = self._b("xm", (B, H, W, Cc))
             L.call("fd_ln_modulate", self.dt, _p(x), _p(m["n1w"]), _p(m["n1b"]), 1e-5, mp(0), mp(1), ml, _p(xm),
                    B, hw, Cc, s)
             self.conv(m["in_proj"], xm, B, H, W, xz, epi=L.EPI_SILU_SPLIT, split=D)
-        xc = self._b("xc", (B, H, W, D))
-        L.call("fd_dwconv3x3", self.dt, _p(xz), 2 * D, 0, _p(m["dw_w"]), _p(m["dw_b"]), 1, _p(xc), D, 0,
-               B, H, W, D, s)
+        if not fused:
+            L.call("fd_dwconv3x3", self.dt, _p(xz), 2 * D, 0, _p(m["dw_w"]), _p(m["dw_b"]), 1, _p(xc), D, 0,
+                   B, H, W, D, s)
         Lq = (H // 2) * (W // 2)
         xdbl = self._b("xdbl", (4, B, Lq, CD), torch.float32)
         self.conv(None, xc, B, H, W, xdbl, c0=D, weight=m["x_proj"], bias=None, Cout=CD, KH=1, KW=1, stride=2,
@@ -361,17 +380,22 @@ class DAEngine:
                    self.loc_total, _p(yz), B, hw, D, s)
             self.conv(m["out_proj"], yz, B, H, W, x1, **ep1)
         # --- channel attention branch
-        qkv = self._b("qkv", (B, H, W, 3 * Cc))
-        ln2 = dict(prologue=L.PRO_LN_MOD, ln_eps=1e-6, ln_shift=mp(3), ln_scale=mp(4), ln_ld=ml)
-        if self.conv(m["qkv"], x1, B, H, W, qkv, probe=True, **ln2):
-            self.conv(m["qkv"], x1, B, H, W, qkv, **ln2)
-        else:
-            xm2 = self._b("xm", (B, H, W, Cc))
-            L.call("fd_ln_modulate", self.dt, _p(x1), None, None, 1e-6, mp(3), mp(4), ml, _p(xm2), B, hw, Cc, s)
-            self.conv(m["qkv"], xm2, B, H, W, qkv)
         qkv2 = self._b("qkv2", (B, H, W, 3 * Cc))
-        L.call("fd_dwconv3x3", self.dt, _p(qkv), 3 * Cc, 0, _p(m["qdw_w"]), None, 0, _p(qkv2), 3 * Cc, 0,
-               B, H, W, 3 * Cc, s)
+        ln2 = dict(prologue=L.PRO_LN_MOD, ln_eps=1e-6, ln_shift=mp(3), ln_scale=mp(4), ln_ld=ml)
+        if L.lib().fd_pw_dw3x3_ok(self.dt, Cc, 3 * Cc, 0, H, W):
+            L.call("fd_pw_dw3x3", self.dt, _p(x1), Cc, 0, Cc, None, None, 1e-6, mp(3), mp(4), ml,
+                   _p(m["qkv"].w), 3 * Cc, _p(m["qdw_wm"]), None, 0, _p(qkv2), 3 * Cc, 0,
+                   0, None, 0, 0, B, H, W, s)
+        else:
+            qkv = self._b("qkv", (B, H, W, 3 * Cc))
+            if self.conv(m["qkv"], x1, B, H, W, qkv, probe=True, **ln2):
+                self.conv(m["qkv"], x1, B, H, W, qkv, **ln2)
+            else:
+                xm2 = self._b("xm", (B, H, W, Cc))
+                L.call("fd_ln_modulate", self.dt, _p(x1), None, None, 1e-6, mp(3), mp(4), ml, _p(xm2), B, hw, Cc, s)
+                self.conv(m["qkv"], xm2, B, H, W, qkv)
+            L.call("fd_dwconv3x3", self.dt, _p(qkv), 3 * Cc, 0, _p(m["qdw_w"]), None, 0, _p(qkv2), 3 * Cc, 0,
+                   B, H, W, 3 * Cc, s)
         nblk = L.lib().fd_chan_attn_nblk(hw)
         part = self._b("gram", (B, m["heads"], nblk, 1024 + 64), torch.float32)
         L.call("fd_chan_attn_gram", self.dt, _p(qkv2), B, hw, Cc, _p(part), s)

@@ -139,6 +139,27 @@ int fd_dwconv3x3(int dtype, const void *in, int ld_in, int off_in, const float *
                  const float *bias, int silu, void *out, int ld_out, int off_out, int B, int H,
                  int W, int C, void *stream);
 
+/* ---- fused LayerNorm+modulate -> 1x1 conv -> depthwise 3x3 (bf16, Cin = 64, >= 32768 px/image)
+ * Replaces, in one pass over the pixels, the pairs
+ *   SS2D   in_proj + conv2d(3x3, groups=D)+SiLU (x half), SiLU (z half)   src/emamba2.py:716-722
+ *   attn   qkv + qkv_dwconv                                               src/DADiff.py:266, 275
+ * including the adaLN-modulated LayerNorm in front of them (src/DADiff.py:480-487).
+ *   x      [B,H,W,ld_x] channels [off_x, +Cin)
+ *   w_pw   bf16 [Cdw + Cz][Cin]: rows [0, Cdw) feed the depthwise conv, rows [Cdw, Cdw+Cz) are passed
+ *          through SiLU to out_z (Cz = 0: none)
+ *   w_dw   [5][Cdw] 32-bit words of bf16 tap weights k[dy][dx], packed for v_dot2c_f32_bf16:
+ *          word p = 0..2: (low, high) = (k[0][p], k[1][p]);  word 3: (k[2][0], k[2][1]);
+ *          word 4: k[2][2] in the LOW half for even channels, in the HIGH half for odd ones.
+ *          b_dw [Cdw] fp32 or NULL
+ *   ln_*   as fd_conv_params' LN_MOD prologue (gamma/beta may be NULL)
+ * fd_pw_dw3x3_ok: 1 if the shape is served (callers fall back to fd_conv2d + fd_dwconv3x3).   */
+int fd_pw_dw3x3_ok(int dtype, int Cin, int Cdw, int Cz, int H, int W);
+int fd_pw_dw3x3(int dtype, const void *x, int ld_x, int off_x, int Cin, const float *ln_gamma,
+                const float *ln_beta, float ln_eps, const float *ln_shift, const float *ln_scale,
+                int ln_ld, const void *w_pw, int Cdw, const uint32_t *w_dw, const float *b_dw,
+                int dw_silu, void *out_dw, int ld_dw, int off_dw, int Cz, void *out_z, int ld_z,
+                int off_z, int B, int H, int W, void *stream);
+
 /* ---- SS2D selective scan (replaces selective_scan_cuda_core.fwd, src/emamba2.py:154, together
  * with EfficientScan/EfficientMerge index maps 182-262, dt_proj einsum 340, softplus/bias).
  *   xc    [B,H,W,D]    (dtype)  dwconv+SiLU output, D = d_inner = 2C

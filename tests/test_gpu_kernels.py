@@ -460,3 +460,51 @@ def test_conv3x3_halo(eng_factory, cfg):
     s = part.sum(1).cpu()
     assert rel_err(s[..., 0], ref.sum((2, 3))) < 5e-3
     assert rel_err(s[..., 1], (ref ** 2).sum((2, 3))) < 5e-3
+
+
+@pytest.mark.parametrize("cfg", [dict(cdw=128, cz=128, silu=1, bias=True, affine=True, hw=(128, 256)),     # SS2D in_proj + conv2d
+                                 dict(cdw=192, cz=0, silu=0, bias=False, affine=False, hw=(256, 128))])   # qkv + qkv_dwconv
+def test_pw_dw3x3_fused(eng_factory, cfg):
+    """Fused LN+modulate -> 1x1 -> depthwise 3x3 (bf16) against the unfused fp32 composition; borders
+    included (the depthwise conv zero-pads the 1x1 OUTPUT)."""
+    from founddiff_amd import _lib as L
+    from founddiff_amd.engine import DAEngine
+    e = eng_factory("bf16")
+    torch.manual_seed(31)
+    B, (H, W), Cin = 2, cfg["hw"], 64
+    cdw, cz = cfg["cdw"], cfg["cz"]
+    bf = lambda t: t.to(torch.bfloat16).float()
+    x = bf(torch.randn(B, H, W, Cin) * 1.3 + 0.2)
+    g, be = (torch.randn(Cin), torch.randn(Cin)) if cfg["affine"] else (None, None)
+    mod = torch.randn(B, 6 * Cin) * 0.5
+    wpw = bf(torch.randn(cdw + cz, Cin) / 8)
+    wdw = torch.randn(cdw, 1, 3, 3) / 3
+    bdw = torch.randn(cdw) if cfg["bias"] else None
+    eps = 1e-5 if cfg["affine"] else 1e-6
+    xn = F.layer_norm(x, (Cin,), g, be, eps) * (1 + mod[:, None, None, Cin:2 * Cin]) + mod[:, None, None, :Cin]
+    t = bf(F.linear(bf(xn), wpw))                                    # 1x1 output, rounded where the kernel rounds
+    ref_dw = F.conv2d(t[..., :cdw].permute(0, 3, 1, 2), bf(wdw), bdw, padding=1, groups=cdw)
+    if cfg["silu"]:
+        ref_dw = F.silu(ref_dw)
+    assert L.lib().fd_pw_dw3x3_ok(L.FD_BF16, Cin, cdw, cz, H, W)
+    xd, md = x.cuda().to(torch.bfloat16), mod.cuda()
+    wpd = wpw.cuda().to(torch.bfloat16)
+    wm = DAEngine._dw_masked(wdw.reshape(cdw, 9).t().contiguous().cuda())
+    out_dw = torch.zeros(B, H, W, cdw + 8, device="cuda", dtype=torch.bfloat16)
+    out_z = torch.zeros(B, H, W, 2 * cz + 8, device="cuda", dtype=torch.bfloat16)
+    gd, bd = (g.cuda(), be.cuda()) if cfg["affine"] else (None, None)
+    bdd = bdw.cuda() if bdw is not None else None
+    ptr = lambda t_: None if t_ is None else t_.data_ptr()
+    L.call("fd_pw_dw3x3", L.FD_BF16, xd.data_ptr(), Cin, 0, Cin, ptr(gd), ptr(bd), eps, md.data_ptr(),
+           md.data_ptr() + Cin * 4, 6 * Cin, wpd.data_ptr(), cdw, wm.data_ptr(), ptr(bdd), cfg["silu"],
+           out_dw.data_ptr(), cdw + 8, 8, cz, out_z.data_ptr(), 2 * cz + 8, cz, B, H, W, None)
+    torch.cuda.synchronize()
+    got = out_dw[..., 8:].float().cpu().permute(0, 3, 1, 2)
+    assert rel_err(got, ref_dw) < 1.2e-2
+    # border rows / columns separately: a wrong padding rule hides in the global norm
+    assert rel_err(got[:, :, 0], ref_dw[:, :, 0]) < 1.5e-2 and rel_err(got[:, :, :, -1], ref_dw[:, :, :, -1]) < 1.5e-2
+    assert float(out_dw[..., :8].float().abs().max()) == 0.0
+    if cz:
+        ref_z = F.silu(t[..., cdw:])
+        assert rel_err(out_z[..., cz:2 * cz].float().cpu(), ref_z) < 1.2e-2
+        assert float(out_z[..., :cz].float().abs().max()) == 0.0 and float(out_z[..., 2 * cz:].float().abs().max()) == 0.0
