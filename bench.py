@@ -71,10 +71,12 @@ def _time_launches(lib, launches, reps=5):
 
 def roofline_leg(dif, x, noise):
     """Roofline of the dominant kernel symbol of the rocprofv3 --stats summary of this command
-    (profiles/): dwconv3x3_bf16_kernel, the depthwise 3x3 of the SS2D / channel-attention branches
-    (HBM-bound: 18 flop per 4 algorithmic bytes).  Replays exactly its launches of one UNet forward
-    between HIP events.  `others` carries the same measurement for the runner-up symbols
-    (conv3x3_halo_kernel: MFMA-bound implicit GEMM) so the table in profiles/ can be cross-checked."""
+    (profiles/): pwdw_kernel, the fused LayerNorm+modulate -> 1x1 -> depthwise 3x3 of the 64-channel
+    Mamba blocks (HBM roofline: it reads 64 and writes 192..256 channels per pixel; in practice it is
+    VALU-issue limited).  Replays exactly its launches of one UNet forward between HIP
+    events.  `others` carries the same measurement for the runner-up symbols (conv3x3_halo_kernel:
+    MFMA-bound implicit GEMM; dwconv3x3_bf16_kernel: HBM-bound) so the table in profiles/ can be
+    cross-checked."""
     from founddiff_amd import _lib as L
     eng = dif._eng()
     B = x.shape[0]
@@ -92,33 +94,39 @@ def roofline_leg(dif, x, noise):
     if os.path.exists(tp):
         traffic = json.load(open(tp))
     all_ms = _time_launches(lib, trace, reps=2)
-
-    # ---- dominant: depthwise 3x3.  args = (dtype, in, ld_in, off_in, w, bias, silu, out, ld_out, off_out, B, H, W, C, stream)
-    dws = [(n, a) for n, a in trace if n == "fd_dwconv3x3"]
     esz = 2                                                     # bf16
-    dw_bytes = sum(2.0 * a[10] * a[11] * a[12] * a[13] * esz for _, a in dws)     # read once + write once
-    dw_ms = _time_launches(lib, dws)
-    dw_gbs = dw_bytes / (dw_ms * 1e-3) / 1e9
-    res = {"bound": "hbm", "kernel": "dwconv3x3_bf16_kernel",
-           "achieved": round(dw_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-           "frac": round(dw_gbs / PEAK_HBM_GBS, 4),
-           "traffic": traffic.get("dwconv3x3_bf16_hbm_bytes_per_launch"),
-           "launches_per_forward": len(dws), "avg_launch_us": round(dw_ms * 1e3 / len(dws), 2),
-           "alg_bytes_per_launch": round(dw_bytes / len(dws)),
-           "kernel_ms_per_forward": round(dw_ms, 3), "all_kernels_ms_per_forward": round(all_ms, 3),
-           "batch": B, "others": []}
-    # ---- runner-up symbols: halo-tiled 3x3 implicit GEMM (fd_conv_kernel_id == 11), MFMA-bound
+
+    def hbm_entry(kernel, launches, nbytes, key):
+        ms = _time_launches(lib, launches)
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": kernel, "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic.get(key),
+                "launches_per_forward": len(launches), "avg_launch_us": round(ms * 1e3 / len(launches), 2),
+                "alg_bytes_per_launch": round(nbytes / len(launches)), "kernel_ms_per_forward": round(ms, 3)}
+
+    # ---- dominant: fused 1x1 -> depthwise.  args = (dtype, x, ld_x, off_x, Cin, gamma, beta, eps, shift, scale, ln_ld,
+    #      w_pw, Cdw, w_dw, b_dw, silu, out_dw, ld_dw, off_dw, Cz, out_z, ld_z, off_z, B, H, W, stream)
+    pw = [(n, a) for n, a in trace if n == "fd_pw_dw3x3"]
+    pw_bytes = sum(1.0 * a[23] * a[24] * a[25] * (a[4] + a[12] + a[19]) * esz for _, a in pw)   # in + dw out + z out, once
+    res = hbm_entry("pwdw_kernel", pw, pw_bytes, "pwdw_hbm_bytes_per_launch")
+    res.update({"all_kernels_ms_per_forward": round(all_ms, 3), "batch": B, "others": []})
+    # ---- runner-up symbols
     halo = [(n, a) for n, a in trace if n == "fd_conv2d" and lib.fd_conv_kernel_id(a[0]) == 11]
     if halo:
         fl = sum(conv_flops(a[0]._obj) for _, a in halo)
         ms = _time_launches(lib, halo)
         tf = fl / (ms * 1e-3) / 1e12
-        res["others"].append({"bound": "mfma", "kernel": "conv3x3_halo_kernel<64|128>", "achieved": round(tf, 1),
+        res["others"].append({"bound": "mfma", "kernel": "conv3x3_halo_kernel<BN,TH>", "achieved": round(tf, 1),
                               "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4),
                               "traffic": traffic.get("conv3x3_halo_hbm_bytes_per_launch"),
                               "launches_per_forward": len(halo), "avg_launch_us": round(ms * 1e3 / len(halo), 2),
                               "alg_gflop_per_launch": round(fl / 1e9 / len(halo), 2),
                               "kernel_ms_per_forward": round(ms, 3)})
+    # depthwise 3x3 alone: args = (dtype, in, ld_in, off_in, w, bias, silu, out, ld_out, off_out, B, H, W, C, stream)
+    dws = [(n, a) for n, a in trace if n == "fd_dwconv3x3"]
+    if dws:
+        dw_bytes = sum(2.0 * a[10] * a[11] * a[12] * a[13] * esz for _, a in dws)
+        res["others"].append(hbm_entry("dwconv3x3_bf16_kernel", dws, dw_bytes, "dwconv3x3_bf16_hbm_bytes_per_launch"))
     return res
 
 

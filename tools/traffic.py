@@ -39,6 +39,7 @@ def fam(prefix):
 
 
 res = {"note": __doc__.strip(),
+       "pwdw_hbm_bytes_per_launch": fam("pwdw_kernel"),
        "dwconv3x3_bf16_hbm_bytes_per_launch": fam("dwconv3x3_bf16_kernel"),
        "conv3x3_halo_hbm_bytes_per_launch": fam("conv3x3_halo_kernel"),
        "per_kernel": per}
