@@ -2,7 +2,8 @@
 
 Restates, with every random draw passed in explicitly (CPU and GPU generators differ):
   ResidualDiffusion.model_predictions / q_posterior / p_sample / p_sample_loop / ddim_sample / sample
-      /root/reference/src/DADiff.py:1120-1380  (objective 'pred_res', condition=True, eta=0)
+      /root/reference/src/DADiff.py:1120-1380  (condition=True, eta=0; every objective of 1168-1207 and
+      the single / dual UNet dispatch of UnetRes.forward 817-836)
   GaussianDiffusion.model_predictions / p_sample / p_sample_loop / ddim_sample
       /root/reference/src/denoising_diffusion_pytorch.py:523-652
 Pinned by tests/golden/e2e_*.npz captured from the reference with its torch.randn patched to
@@ -17,8 +18,12 @@ from . import nets, schedule
 
 class ResidualOracle:
     def __init__(self, sd, prefix="model.unet0.", timesteps=1000, sampling_timesteps=None,
-                 sum_scale=0.01, after_init=True, scan_fn=None, hoist_cond=True):
+                 sum_scale=0.01, after_init=True, scan_fn=None, hoist_cond=True, objective="pred_res",
+                 test_res_or_noise="res", num_unet=1, prefix1="model.unet1."):
         self.sd = nets.SD(sd, prefix)
+        self.sd1 = nets.SD(sd, prefix1) if num_unet == 2 else None
+        self.objective, self.test, self.num_unet = objective, test_res_or_noise, num_unet
+        self._cond1 = None
         self.T = timesteps
         self.S = sampling_timesteps if sampling_timesteps is not None else timesteps
         self.sum_scale = sum_scale
@@ -27,25 +32,63 @@ class ResidualOracle:
         self.hoist_cond = hoist_cond  # the DA-CLIP branch is t-independent
         self._cond = None
 
-    def unet(self, x_t, x_in, t_idx):
-        """t_idx (B,) long -> raw model output (B,1,H,W)."""
-        time = self.sch["alphas_cumsum"][t_idx] * self.T
+    def unet(self, x_t, x_in, t_idx, which=0, time_sel=0):
+        """t_idx (B,) long -> raw output (B,1,H,W) of unet `which`; time_sel 0: alphas_cumsum[t]*T, 1:
+        betas_cumsum[t]*T -- the two entries of the time list model_predictions builds (1160-1163)."""
+        time = self.sch["alphas_cumsum" if time_sel == 0 else "betas_cumsum"][t_idx] * self.T
         x = torch.cat((x_t, x_in), dim=1)
+        sd = self.sd if which == 0 else self.sd1
+        cond = None
         if self.hoist_cond:
-            if self._cond is None:
-                self._cond = nets.da_unet_cond(self.sd, x_in)
-            cond = self._cond
-        else:
-            cond = None
-        return nets.da_unet(self.sd, x, time, cond, self.scan_fn)
+            if which == 0:
+                if self._cond is None:
+                    self._cond = nets.da_unet_cond(sd, x_in)
+                cond = self._cond
+            else:
+                if self._cond1 is None:
+                    self._cond1 = nets.da_unet_cond(sd, x_in)
+                cond = self._cond1
+        return nets.da_unet(sd, x, time, cond, self.scan_fn)
+
+    def model_outputs(self, x_in, x_t, t_idx):
+        """UnetRes.forward (817-836): which UNets run, and with which time entry."""
+        if self.num_unet == 2:
+            o0 = self.unet(x_t, x_in, t_idx, 0, 0) if self.test in ("res_noise", "res") else None
+            o1 = self.unet(x_t, x_in, t_idx, 1, 1) if self.test in ("res_noise", "noise") else None
+            return o0, o1
+        if self.objective == "pred_noise":
+            return self.unet(x_t, x_in, t_idx, 0, 1), None
+        return self.unet(x_t, x_in, t_idx, 0, 0), None
 
     def model_predictions(self, x_in, x_t, t_idx):
-        out = self.unet(x_t, x_in, t_idx)
-        pred_res = out.clamp(-1.0, 1.0)
+        """src/DADiff.py:1168-1207 with clip_denoised=True."""
+        o0, o1 = self.model_outputs(x_in, x_t, t_idx)
+        cl = lambda v: v.clamp(-1.0, 1.0)
         a = self.sch["alphas_cumsum"][t_idx].view(-1, 1, 1, 1)
         b = self.sch["betas_cumsum"][t_idx].view(-1, 1, 1, 1)
-        pred_noise = (x_t - x_in - (a - 1) * pred_res) / b
-        x_start = (x_in - pred_res).clamp(-1.0, 1.0)
+        oma = self.sch["one_minus_alphas_cumsum"][t_idx].view(-1, 1, 1, 1)
+        from_res = lambda pr: ((x_t - x_in - (a - 1) * pr) / b, cl(x_in - pr))        # 1120-1124, 1206
+        start_from_noise = lambda pn: cl((x_t - a * x_in - b * pn) / oma)             # 1126-1130
+        if self.objective == "pred_res_noise":
+            if self.test == "res_noise":
+                pred_res, pred_noise = cl(o0), o1
+                x_start = cl(x_t - a * pred_res - b * pred_noise)                     # 1132-1136
+            elif self.test == "res":
+                pred_res = cl(o0)
+                pred_noise, x_start = from_res(pred_res)
+            else:
+                pred_noise = o1
+                x_start = start_from_noise(pred_noise)
+                pred_res = cl(x_in - x_start)
+        elif self.objective == "pred_x0_noise":
+            pred_res, pred_noise, x_start = cl(x_in - o0), o1, cl(o0)
+        elif self.objective == "pred_noise":
+            pred_noise = o0
+            x_start = start_from_noise(pred_noise)
+            pred_res = cl(x_in - x_start)
+        else:
+            pred_res = cl(o0)
+            pred_noise, x_start = from_res(pred_res)
         return pred_res, pred_noise, x_start
 
     def q_posterior(self, pred_res, x_start, x_t, t_idx):
@@ -64,7 +107,7 @@ class ResidualOracle:
     def sample(self, x_input01, noise0, step_noise=None, trace=None, t_stop=0):
         """x_input01 (B,1,H,W) in [0,1]; noise0 the one randn(shape) draw; step_noise[t] for
         the ancestral loop.  Returns [x_T01, out01] like sample(last=True)."""
-        self._cond = None
+        self._cond = self._cond1 = None
         x_in = x_input01 * 2 - 1
         img = x_in + math.sqrt(self.sum_scale) * noise0
         start = img

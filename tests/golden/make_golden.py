@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generate tests/golden/*.npz by running the REFERENCE itself (CPU, this container only).
 
-    python tests/golden/make_golden.py [schedule|modules|e2e_da|e2e_vanilla|full64|all]
+    python tests/golden/make_golden.py [schedule|modules|e2e_da|e2e_variants|e2e_vanilla|full64|all]
 
 Each fixture is data only: seeded inputs, the reference's outputs, and the {key: shape} spec +
 seed from which founddiff_amd.synth regenerates the exact weights that were loaded into the
@@ -243,6 +243,56 @@ def g_e2e_da(D):
     save("e2e_da_tiny", spec=spec, **arrs)
 
 
+VARIANTS = {   # objectives / dual-UNet configurations the reference supports (src/DADiff.py:817-836, 1168-1207)
+    "pred_noise": dict(num_unet=1, objective="pred_noise", test="noise"),
+    "res_noise": dict(num_unet=2, objective="pred_res_noise", test="res_noise"),
+    "rn_noise": dict(num_unet=2, objective="pred_res_noise", test="noise"),
+    "rn_res": dict(num_unet=2, objective="pred_res_noise", test="res"),
+    "x0_noise": dict(num_unet=2, objective="pred_x0_noise", test="res_noise"),
+}
+
+
+def g_e2e_da_variants(D):
+    """The other objectives / the dual-UNet model on the tiny DA configuration: 4-step DDIM (every step),
+    one model_predictions call and 3 ancestral steps per variant; weights from founddiff_amd.synth."""
+    import unittest.mock as um
+    from founddiff_amd.synth import ct_phantom
+    _, ld = ct_phantom(1, 64, seed=10)
+    x_in = torch.from_numpy(ld)
+    g = torch.Generator().manual_seed(78)
+    noises = torch.randn(3, *x_in.shape, generator=g)
+    torch.manual_seed(10)
+    noise0 = torch.randn(x_in.shape)
+    arrs = {"x_input": x_in, "noise0": noise0, "anc.noise": noises}
+    spec_all = {}
+    for name, v in VARIANTS.items():
+        net = D.UnetRes(dim=32, dim_mults=(1, 2), num_unet=v["num_unet"], condition=True, objective=v["objective"],
+                        test_res_or_noise=v["test"])
+        dif = D.ResidualDiffusion(net, image_size=64, timesteps=1000, sampling_timesteps=4, objective=v["objective"],
+                                  loss_type="l2", condition=True, sum_scale=0.01, test_res_or_noise=v["test"]).eval()
+        spec = {k: s for k, s in synth.spec_of(dif.state_dict()).items() if k.startswith("model.")}
+        dif.load_state_dict(synth.synth_state_dict(spec, SEED_W), strict=False)
+        dif.init()
+        spec_all.update({k: s for k, s in spec.items() if ".clip_model." not in k or ".dose_encoder." in k})
+        torch.manual_seed(10)
+        outs = dif.sample([x_in.clone()], batch_size=1, last=False)
+        arrs[name + ".ddim.imgs"] = torch.stack(outs, 0)
+        xi = x_in * 2 - 1
+        xt = xi + 0.1 * noise0
+        tt = torch.full((1,), 979, dtype=torch.long)
+        pr = dif.model_predictions(xi, xt, tt)
+        arrs[name + ".mp.pred_res"], arrs[name + ".mp.pred_noise"], arrs[name + ".mp.x_start"] = \
+            pr.pred_res, pr.pred_noise, pr.pred_x_start
+        img, anc = xt.clone(), []
+        for i, t in enumerate(range(999, 996, -1)):
+            with um.patch.object(torch, "randn_like", lambda x, i=i: noises[i]):
+                img, _ = dif.p_sample(xi, img, t)
+            anc.append(img.clone())
+        arrs[name + ".anc.imgs"] = torch.stack(anc, 0)
+        print(name, "done")
+    save("e2e_da_variants", spec=spec_all, **arrs)
+
+
 def g_e2e_vanilla(D):
     from src import denoising_diffusion_pytorch as V
     net = V.Unet(32, dim_mults=(1, 2), channels=1)
@@ -312,5 +362,7 @@ if __name__ == "__main__":
             g_modules_vanilla(D)
         if what in ("e2e_da", "all"):
             g_e2e_da(D)
+        if what in ("e2e_variants", "all"):
+            g_e2e_da_variants(D)
         if what in ("e2e_vanilla", "all"):
             g_e2e_vanilla(D)

@@ -152,6 +152,42 @@ def test_e2e_da_tiny(golden):
     assert rel_err(xs0, g["anc.t0_xstart"]) < 1e-4
 
 
+VARIANTS = {   # name -> (num_unet, objective, test_res_or_noise); mirrors tests/golden/make_golden.py
+    "pred_noise": (1, "pred_noise", "noise"), "res_noise": (2, "pred_res_noise", "res_noise"),
+    "rn_noise": (2, "pred_res_noise", "noise"), "rn_res": (2, "pred_res_noise", "res"),
+    "x0_noise": (2, "pred_x0_noise", "res_noise"),
+}
+
+
+@pytest.mark.parametrize("name", sorted(VARIANTS))
+def test_e2e_da_variants(golden, name):
+    """The other objectives and the dual-UNet dispatch against the reference's own outputs."""
+    g = golden("e2e_da_variants")
+    nu, obj, tst = VARIANTS[name]
+    orc = sampler.ResidualOracle(g.weights(), sampling_timesteps=4, objective=obj, test_res_or_noise=tst, num_unet=nu)
+    x_in = g["x_input"]
+    xi = x_in * 2 - 1
+    xt = xi + 0.1 * g["noise0"]
+    tt = torch.full((1,), 979, dtype=torch.long)
+    pr, pn, xs = orc.model_predictions(xi, xt, tt)
+    # x_start from a noise prediction divides by one_minus_alphas_cumsum[t] (6.5e-3 at t=979): a 1e-6
+    # difference in the UNet output is amplified ~150x, hence the looser gate for those two variants
+    tol, tol_seq = (1e-3, 1e-3) if name in ("pred_noise", "rn_noise") else (1e-4, 2e-4)
+    assert rel_err(pr, g[name + ".mp.pred_res"]) < tol
+    assert rel_err(pn, g[name + ".mp.pred_noise"]) < 1e-4
+    assert rel_err(xs, g[name + ".mp.x_start"]) < tol
+    trace = {}
+    out = orc.sample(x_in, g["noise0"], trace=trace)
+    imgs = g[name + ".ddim.imgs"]
+    assert rel_err(out[0], imgs[0]) < 1e-6
+    for i, im in enumerate(trace["img"]):
+        assert rel_err((im + 1) * 0.5, imgs[i + 1]) < tol_seq, i
+    img = xt.clone()
+    for i, t in enumerate(range(999, 996, -1)):
+        img, _ = orc.p_sample(xi, img, t, g["anc.noise"][i])
+        assert rel_err(img, g[name + ".anc.imgs"][i]) < tol_seq, t
+
+
 def test_e2e_vanilla_tiny(golden):
     g = golden("e2e_vanilla_tiny")
     w = g.weights()
