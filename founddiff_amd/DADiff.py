@@ -153,7 +153,8 @@ class Unet(_ParamTree):
 
 
 class UnetRes(nn.Module):
-    """reference src/DADiff.py:743-836 (num_unet == 1 configurations)."""
+    """reference src/DADiff.py:743-836: one UNet, or two (residual + noise) for the objectives
+    'pred_res_noise' / 'pred_x0_noise'."""
 
     def __init__(self, dim, init_dim=None, out_dim=None, dim_mults=(1, 2, 4, 8), channels=1, self_condition=False,
                  resnet_block_groups=8, learned_variance=False, learned_sinusoidal_cond=False,
@@ -161,8 +162,8 @@ class UnetRes(nn.Module):
                  input_condition=False, objective="pred_res_noise", test_res_or_noise="res_noise",
                  precision=None, clip_cfg=None):
         super().__init__()
-        if num_unet != 1:
-            raise NotImplementedError("num_unet=2 (pred_res_noise / pred_x0_noise) is not built (SURVEY 8f-4)")
+        if num_unet not in (1, 2):
+            raise ValueError("num_unet must be 1 or 2")
         self.condition = condition
         self.input_condition = input_condition
         self.channels = channels
@@ -178,15 +179,32 @@ class UnetRes(nn.Module):
                           random_fourier_features=random_fourier_features,
                           learned_sinusoidal_dim=learned_sinusoidal_dim, condition=condition,
                           input_condition=input_condition, precision=precision, clip_cfg=clip_cfg)
+        if num_unet == 2:
+            self.unet1 = Unet(dim, init_dim=init_dim, out_dim=out_dim, dim_mults=dim_mults, channels=channels,
+                              self_condition=self_condition, resnet_block_groups=resnet_block_groups,
+                              learned_variance=learned_variance, learned_sinusoidal_cond=learned_sinusoidal_cond,
+                              random_fourier_features=random_fourier_features,
+                              learned_sinusoidal_dim=learned_sinusoidal_dim, condition=condition,
+                              input_condition=input_condition, precision=precision, clip_cfg=clip_cfg)
 
     def forward(self, x, time, x_self_cond=None, reuse_condition=False):
+        """src/DADiff.py:817-836.  time = [alphas_cumsum[t]*T, betas_cumsum[t]*T]."""
+        kw = dict(x_self_cond=x_self_cond, reuse_condition=reuse_condition)
+        if self.num_unet == 2:
+            if self.test_res_or_noise == "res_noise":
+                return self.unet0(x, time[0], **kw), self.unet1(x, time[1], **kw)
+            if self.test_res_or_noise == "res":
+                return self.unet0(x, time[0], **kw), 0
+            if self.test_res_or_noise == "noise":
+                return 0, self.unet1(x, time[1], **kw)
+            raise ValueError(f"test_res_or_noise={self.test_res_or_noise!r}")
         if self.objective == "pred_noise":
             time = time[1]
         elif self.objective == "pred_res":
             time = time[0]
         else:
-            raise NotImplementedError(f"objective {self.objective!r} needs num_unet=2")
-        return [self.unet0(x, time, x_self_cond=x_self_cond, reuse_condition=reuse_condition)]
+            raise ValueError(f"objective {self.objective!r} needs num_unet=2 (src/DADiff.py:826-831)")
+        return [self.unet0(x, time, **kw)]
 
 
 def residual_schedule(timesteps=1000, after_init=False):
@@ -232,9 +250,13 @@ class ResidualDiffusion(nn.Module):
         super().__init__()
         assert not (type(self) == ResidualDiffusion and model.channels != model.out_dim)
         assert not model.random_or_learned_sinusoidal_cond
-        if objective != "pred_res" or not condition or input_condition:
-            raise NotImplementedError("only objective='pred_res', condition=True, input_condition=False "
-                                      "(the shipped FoundDiff configuration) is built (SURVEY 8f-4)")
+        if objective not in ("pred_res", "pred_noise", "pred_res_noise", "pred_x0_noise"):
+            raise ValueError(f"unknown objective {objective!r}")
+        if not condition or input_condition:
+            raise NotImplementedError("condition=True, input_condition=False (every FoundDiff configuration) "
+                                      "is what the DA-CLIP conditioned Unet supports (SURVEY 8f-4)")
+        if objective in ("pred_res_noise", "pred_x0_noise") and getattr(model, "num_unet", 1) != 2:
+            raise ValueError(f"objective {objective!r} needs UnetRes(num_unet=2) (src/DADiff.py:826-831)")
         if timesteps != 1000:
             raise NotImplementedError("init() of the reference hard-codes 1000 timesteps (src/DADiff.py:1034)")
         self.model = model
@@ -269,7 +291,8 @@ class ResidualDiffusion(nn.Module):
         self._host_sched = None
 
     def load_state_dict(self, state_dict, strict=True, assign=False):
-        live = {k: v for k, v in state_dict.items() if not arch.is_dead_key(k, "model.unet0.")}
+        live = {k: v for k, v in state_dict.items()
+                if not (arch.is_dead_key(k, "model.unet0.") or arch.is_dead_key(k, "model.unet1."))}
         self._graph = None
         return super().load_state_dict(live, strict=strict, assign=assign)
 
@@ -288,6 +311,71 @@ class ResidualDiffusion(nn.Module):
         """raw model output for batched integer timesteps t_idx (B,) (src/DADiff.py:1160-1164)"""
         time = (self.alphas_cumsum[t_idx] * self.num_timesteps).float().contiguous()
         return self._eng().forward(x, x_input, time, out=out)
+
+    # ---- objectives other than the shipped 'pred_res' (SURVEY 8f-4)
+    def _plan(self):
+        """(mode of fd_res_step_obj, run unet0?, run unet1?, unet0's time entry) for this objective /
+        test_res_or_noise -- UnetRes.forward (src/DADiff.py:817-836) + model_predictions (1168-1207)."""
+        if getattr(self.model, "num_unet", 1) == 2:
+            tst = self.test_res_or_noise
+            if self.objective == "pred_x0_noise":
+                if tst != "res_noise":
+                    raise ValueError("pred_x0_noise reads both model outputs: test_res_or_noise must be 'res_noise'")
+                return 3, True, True, 0
+            if self.objective != "pred_res_noise":
+                raise ValueError(f"objective {self.objective!r} with num_unet=2")
+            return {"res_noise": (2, True, True, 0), "res": (0, True, False, 0), "noise": (1, False, True, 0)}[tst]
+        if self.objective == "pred_noise":
+            return 1, True, False, 1            # the single UNet predicts the noise, fed with time[1]
+        return 0, True, False, 0
+
+    def _is_shipped(self):
+        return self._plan() == (0, True, False, 0)
+
+    def _engines(self):
+        mode, r0, r1, _ = self._plan()
+        return ([self.model.unet0.engine()] if r0 else []) + ([self.model.unet1.engine()] if r1 else [])
+
+    def _encode_all(self, x_in):
+        for e in self._engines():
+            e.encode_condition(x_in)
+
+    def _outputs(self, x_in, x, t_idx):
+        """raw outputs (o0, o1) of the UNets this configuration evaluates (None where it does not)."""
+        mode, r0, r1, tsel0 = self._plan()
+        T = self.num_timesteps
+        t0 = ((self.alphas_cumsum if tsel0 == 0 else self.betas_cumsum)[t_idx] * T).float().contiguous()
+        t1 = (self.betas_cumsum[t_idx] * T).float().contiguous()
+        o0 = o1 = None
+        if mode == 1 and r0:                    # single-UNet pred_noise: its output plays the role of o1
+            o1 = self.model.unet0.engine().forward(x, x_in, t0).clone()
+        elif r0:
+            o0 = self.model.unet0.engine().forward(x, x_in, t0).clone()
+        if r1:
+            o1 = self.model.unet1.engine().forward(x, x_in, t1).clone()
+        return mode, o0, o1
+
+    def _par(self, t_idx, k=(0., 0., 0., 0.), flag=0.):
+        B = t_idx.shape[0]
+        par = torch.zeros(B, 8, device=t_idx.device, dtype=torch.float32)
+        par[:, 0], par[:, 1], par[:, 2] = self.alphas_cumsum[t_idx], self.betas_cumsum[t_idx], self.one_minus_alphas_cumsum[t_idx]
+        for i, v in enumerate(k):
+            par[:, 3 + i] = v
+        par[:, 7] = flag
+        return par.contiguous()
+
+    def _step_obj(self, step, x_in, x, t_idx, noise, k=(0., 0., 0., 0.), flag=0., want_preds=False, out=None):
+        mode, o0, o1 = self._outputs(x_in, x, t_idx)
+        par = self._par(t_idx, k, flag)
+        pr = pn = xs = None
+        if want_preds:
+            pr, pn, xs = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        else:
+            xs = torch.empty_like(x)
+        img = (out if out is not None else torch.empty_like(x)) if step else None
+        L.call("fd_res_step_obj", mode, step, _p(o0), _p(o1), _p(x), _p(x_in), _p(noise), _p(par), _p(pr), _p(pn),
+               _p(xs), _p(img), x.shape[0], x[0].numel(), _stream(x))
+        return img, pr, pn, xs
 
     def predict_noise_from_res(self, x_t, t, x_input, pred_res):
         B = x_t.shape[0]
@@ -317,10 +405,15 @@ class ResidualDiffusion(nn.Module):
     @torch.no_grad()
     def model_predictions(self, x_input, x, t, x_input_condition=0, x_self_cond=None, clip_denoised=True,
                           reuse_condition=False):
-        """src/DADiff.py:1153-1209, objective 'pred_res'."""
+        """src/DADiff.py:1153-1209."""
         assert clip_denoised, "clip_denoised=False is not built"
         x_input = x_input.contiguous().float()
         x = x.contiguous().float()
+        if not self._is_shipped():
+            if not reuse_condition:
+                self._encode_all(x_input)
+            _, pr, pn, xs = self._step_obj(0, x_input, x, t, None, want_preds=True)
+            return ModelResPrediction(pr, pn, xs)
         if not reuse_condition:
             self._eng().encode_condition(x_input)
         mo = self._unet(x_input, x, t)
@@ -342,10 +435,19 @@ class ResidualDiffusion(nn.Module):
         x_input = x_input.contiguous().float()
         x = x.contiguous().float()
         B = x.shape[0]
-        if not reuse_condition:
-            self._eng().encode_condition(x_input)
         hs = self._hs()
         t_idx = torch.full((B,), t, device=x.device, dtype=torch.long)
+        if not self._is_shipped():
+            if not reuse_condition:
+                self._encode_all(x_input)
+            if t > 0 and noise is None:
+                noise = torch.randn_like(x)
+            k = (float(hs["posterior_mean_coef1"][t]), float(hs["posterior_mean_coef2"][t]),
+                 float(hs["posterior_mean_coef3"][t]), float(hs["posterior_log_variance_clipped"][t]))
+            img, _, _, xs = self._step_obj(2, x_input, x, t_idx, noise if t > 0 else None, k=k, out=out)
+            return img, xs
+        if not reuse_condition:
+            self._eng().encode_condition(x_input)
         mo = self._unet(x_input, x, t_idx)
         coef = torch.tensor([[hs["posterior_mean_coef1"][t], hs["posterior_mean_coef2"][t],
                               hs["posterior_mean_coef3"][t], hs["posterior_log_variance_clipped"][t]]] * B,
@@ -399,6 +501,8 @@ class ResidualDiffusion(nn.Module):
     def p_sample_loop(self, x_input, shape, last=True, noise=None, step_noise=None):
         """src/DADiff.py:1233-1273.  `noise`: the initial randn(shape); `step_noise`: callable t -> tensor."""
         x_input = x_input[0].contiguous().float()
+        if not self._is_shipped():
+            return self._generic_loop(x_input, shape, last, noise, step_noise, ddim=False)
         x_in, img, mo, time_buf = self._loop_buffers(x_input, shape)
         eng = self._eng()
         eng.encode_condition(x_in)
@@ -435,6 +539,8 @@ class ResidualDiffusion(nn.Module):
     def ddim_sample(self, x_input, shape, last=True, noise=None):
         """src/DADiff.py:1276-1365 (eta = 0, type 'use_pred_noise')."""
         x_input = x_input[0].contiguous().float()
+        if not self._is_shipped():
+            return self._generic_loop(x_input, shape, last, noise, None, ddim=True)
         x_in, img, mo, time_buf = self._loop_buffers(x_input, shape)
         eng = self._eng()
         eng.encode_condition(x_in)
@@ -463,6 +569,41 @@ class ResidualDiffusion(nn.Module):
             img_list = [input_add_noise] + img_list
         else:
             img_list = [input_add_noise, img.clone()]
+        return unnormalize_to_zero_to_one(img_list)
+
+    def _generic_loop(self, x_in, shape, last, noise, step_noise, ddim):
+        """p_sample_loop / ddim_sample for the objectives other than 'pred_res' and for the dual-UNet
+        model: eager UNet forwards (one or two per step) + one fd_res_step_obj launch per step."""
+        self._encode_all(x_in)
+        B = shape[0]
+        if noise is None:
+            noise = torch.randn(shape, device=x_in.device)
+        img = torch.empty_like(x_in)
+        L.call("fd_axpy_f32", _p(x_in), _p(noise.contiguous()), math.sqrt(self.sum_scale), _p(img), img.numel(),
+               _stream(img))
+        input_add_noise = img.clone()
+        hs = self._hs()
+        T = self.num_timesteps
+        img_list = []
+        if ddim:
+            times = list(reversed(torch.linspace(-1, T - 1, steps=self.sampling_timesteps + 1).int().tolist()))
+            acs = hs["alphas_cumsum"]
+            for time, time_next in zip(times[:-1], times[1:]):
+                t_idx = torch.full((B,), time, device=x_in.device, dtype=torch.long)
+                lastf = time_next < 0
+                alpha = 0.0 if lastf else float(acs[time] - acs[time_next])
+                img = self._step_obj(1, x_in, img, t_idx, None, k=(alpha, 0., 0., 0.), flag=float(lastf))[0]
+                if not last:
+                    img_list.append(img.clone())
+        else:
+            for t in reversed(range(0, T)):
+                nz = None
+                if t > 0:
+                    nz = step_noise(t) if step_noise is not None else torch.randn(shape, device=x_in.device)
+                img, _ = self.p_sample(x_in, img, t, noise=nz, reuse_condition=True)
+                if not last:
+                    img_list.append(img.clone())
+        img_list = [input_add_noise] + img_list if not last else [input_add_noise, img.clone()]
         return unnormalize_to_zero_to_one(img_list)
 
     @torch.no_grad()

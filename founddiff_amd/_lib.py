@@ -75,6 +75,7 @@ SIGNATURES = {
     "fd_attnpool_core": (i32, [vp, i32, vp, i32, i32, i32, vp, i32, i32, i32, i32, vp]),
     "fd_res_predictions": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i64, vp]),
     "fd_res_ddim_step": (i32, [vp, vp, vp, vp, f32, f32, i32, vp, i64, vp]),
+    "fd_res_step_obj": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i64, vp]),
     "fd_res_posterior_step": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i64, vp]),
     "fd_gn_film_silu_apply": (i32, [i32, vp, vp, vp, vp, vp, vp, i32, vp, i32, i64, i32, i32, vp]),
     "fd_chan_ln": (i32, [i32, vp, vp, vp, vp, i64, i32, vp]),

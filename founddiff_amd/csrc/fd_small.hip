@@ -162,6 +162,61 @@ __global__ void res_posterior_kernel(const float *__restrict__ mo, const float *
     }
 }
 
+// General form of the three kernels above for the other objectives / the dual-UNet model
+// (src/DADiff.py:1168-1207).  mode: 0 o0 = residual; 1 o1 = noise (x_start through
+// predict_start_from_xinput_noise); 2 o0 = residual and o1 = noise; 3 o0 = x_0 and o1 = noise.
+// par[b] = {alphas_cumsum[t], betas_cumsum[t], one_minus_alphas_cumsum[t], k0, k1, k2, k3, flag};
+// step 0: predictions only; 1: DDIM update img - k0*pred_res + k1*noise, or x_start when flag != 0
+// (1317-1318, 1344); 2: posterior k0 x_t + k1 pred_res + k2 x_start + exp(k3/2) noise (1142-1151, 1226-1229).
+__global__ void res_step_obj_kernel(int mode, int step, const float *__restrict__ o0, const float *__restrict__ o1,
+                                    const float *__restrict__ xt, const float *__restrict__ xin,
+                                    const float *__restrict__ noise, const float *__restrict__ par, float *pred_res,
+                                    float *pred_noise, float *x_start, float *img_out, int64_t npix) {
+    const int b = blockIdx.y;
+    const float a = par[b * 8], bb = par[b * 8 + 1], oma = par[b * 8 + 2];
+    const float k0 = par[b * 8 + 3], k1 = par[b * 8 + 4], k2 = par[b * 8 + 5], k3 = par[b * 8 + 6];
+    const bool flag = par[b * 8 + 7] != 0.f;
+    const float sd = step == 2 ? expf(0.5f * k3) : 0.f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t j = (int64_t)b * npix + i;
+        const float x = xt[j], xi = xin[j];
+        float pr, pn, xs;
+        if (mode == 0) {
+            pr = clamp1(o0[j]);
+            pn = (x - xi - (a - 1.f) * pr) / bb;
+            xs = clamp1(xi - pr);
+        } else if (mode == 1) {
+            pn = o1[j];
+            xs = clamp1((x - a * xi - bb * pn) / oma);
+            pr = clamp1(xi - xs);
+        } else if (mode == 2) {
+            pr = clamp1(o0[j]);
+            pn = o1[j];
+            xs = clamp1(x - a * pr - bb * pn);
+        } else {
+            const float m0 = o0[j];
+            pr = clamp1(xi - m0);
+            pn = o1[j];
+            xs = clamp1(m0);
+        }
+        if (pred_res) pred_res[j] = pr;
+        if (pred_noise) pred_noise[j] = pn;
+        if (x_start) x_start[j] = xs;
+        if (step == 1) {
+            float v = xs;
+            if (!flag) {
+                v = x - k0 * pr;
+                if (noise) v += k1 * noise[j];
+            }
+            img_out[j] = v;
+        } else if (step == 2) {
+            float v = k0 * x + k1 * pr + k2 * xs;
+            if (noise) v += sd * noise[j];
+            img_out[j] = v;
+        }
+    }
+}
+
 unsigned g1(int64_t n) {
     int64_t g = (n + 255) / 256;
     return (unsigned)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
@@ -216,6 +271,18 @@ extern "C" int fd_res_predictions(const float *model_out, const float *x_t, cons
     hipLaunchKernelGGL(res_predictions_kernel, dim3(g1(npix), B), dim3(256), 0, (hipStream_t)stream, model_out, x_t,
                        x_in, ac, bc, pred_res, pred_noise, x_start, npix);
     FD_LAUNCH_OK("fd_res_predictions");
+    return FD_OK;
+}
+extern "C" int fd_res_step_obj(int mode, int step, const float *o0, const float *o1, const float *x_t, const float *x_in,
+                               const float *noise, const float *par, float *pred_res, float *pred_noise,
+                               float *x_start, float *img_out, int B, int64_t npix, void *stream) {
+    FD_REQUIRE(mode >= 0 && mode <= 3 && step >= 0 && step <= 2, "fd_res_step_obj: bad mode/step %d/%d", mode, step);
+    FD_REQUIRE(x_t && x_in && par, "fd_res_step_obj: null pointer");
+    FD_REQUIRE((mode == 1 || o0) && (mode == 0 || o1), "fd_res_step_obj: mode %d needs o0=%p o1=%p", mode, (const void *)o0, (const void *)o1);
+    FD_REQUIRE(step == 0 || img_out, "fd_res_step_obj: step %d needs img_out", step);
+    hipLaunchKernelGGL(res_step_obj_kernel, dim3(g1(npix), B), dim3(256), 0, (hipStream_t)stream, mode, step, o0, o1, x_t,
+                       x_in, noise, par, pred_res, pred_noise, x_start, img_out, npix);
+    FD_LAUNCH_OK("fd_res_step_obj");
     return FD_OK;
 }
 extern "C" int fd_res_ddim_step(const float *model_out, const float *img, const float *x_in, const float *noise,

@@ -233,6 +233,23 @@ int fd_res_predictions(const float *model_out, const float *x_t, const float *x_
 int fd_res_ddim_step(const float *model_out, const float *img, const float *x_in,
                      const float *noise, float alpha, float sigma, int last, float *img_out,
                      int64_t n, void *stream);
+/* fd_res_step_obj: the same three operations for every objective of model_predictions
+ *   (src/DADiff.py:1168-1207) and the dual-UNet model (817-836).
+ *   mode 0: o0 = residual (pred_res; pred_res_noise tested as "res")
+ *        1: o1 = noise    (pred_noise; pred_res_noise tested as "noise"): x_start =
+ *           clamp((x_t - ac x_in - bc o1)/omac), pred_res = clamp(x_in - x_start)      1126-1130
+ *        2: o0 = residual, o1 = noise: x_start = clamp(x_t - ac clamp(o0) - bc o1)     1132-1136
+ *        3: o0 = x_0, o1 = noise (pred_x0_noise): pred_res = clamp(x_in - o0)          1191-1195
+ *   par [B][8] = {ac, bc, omac, k0, k1, k2, k3, flag} (alphas_cumsum[t], betas_cumsum[t],
+ *        one_minus_alphas_cumsum[t] per batch element)
+ *   step 0: predictions only (any of pred_res / pred_noise / x_start may be NULL)
+ *        1: DDIM: img_out = flag ? x_start : x_t - k0 pred_res + k1 noise             1317-1318, 1344
+ *        2: posterior: img_out = k0 x_t + k1 pred_res + k2 x_start + exp(k3/2) noise  1142-1151, 1226-1229
+ *   noise may be NULL.                                                                        */
+int fd_res_step_obj(int mode, int step, const float *o0, const float *o1, const float *x_t,
+                    const float *x_in, const float *noise, const float *par, float *pred_res,
+                    float *pred_noise, float *x_start, float *img_out, int B, int64_t npix,
+                    void *stream);
 /* fd_res_posterior_step: mean = c1 x_t + c2 pred_res + c3 x_start; out = mean + exp(.5 lv) noise
  *   src/DADiff.py:1142-1151, 1226-1229.  coef: [B][4] = c1,c2,c3,logvar.  noise NULL at t=0. */
 int fd_res_posterior_step(const float *model_out, const float *x_t, const float *x_in,

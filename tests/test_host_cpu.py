@@ -69,7 +69,7 @@ def test_cabi_exports_every_declared_symbol():
     assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
     lib = L.lib()          # raises if the .so is missing or lacks a symbol
     assert lib.fd_version() >= 100
-    assert lib.fd_conv_mtiles(512, 512) == 2048
+    assert lib.fd_conv_mtiles(512, 512) == 4096      # 64-pixel GroupNorm bands
     assert lib.fd_chan_attn_nblk(512 * 512) == 256
     assert lib.fd_scan_ws_floats(1, 512, 512, 128, 4) > 0
 
