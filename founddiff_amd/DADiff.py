@@ -103,10 +103,11 @@ class Unet(_ParamTree):
                  learned_sinusoidal_cond=False, random_fourier_features=False, learned_sinusoidal_dim=16,
                  condition=False, input_condition=False, precision=None, clip_cfg=None):
         super().__init__()
-        if self_condition or input_condition or learned_variance or learned_sinusoidal_cond or \
+        if self_condition or learned_variance or learned_sinusoidal_cond or \
                 random_fourier_features or resnet_block_groups != 8 or (init_dim not in (None, dim)) or channels != 1:
-            raise NotImplementedError("only the shipped FoundDiff configuration of Unet is built "
-                                      "(channels=1, condition=True, no self/input condition; SURVEY 8f-4)")
+            raise NotImplementedError("Unet is built for channels=1, condition=True, no self-conditioning / learned "
+                                      "variance / learned sinusoidal embedding (SURVEY 8f-4)")
+        self.input_condition = input_condition
         self.channels = channels
         self.self_condition = self_condition
         self.dim, self.dim_mults = dim, tuple(dim_mults)
@@ -114,7 +115,7 @@ class Unet(_ParamTree):
         self.random_or_learned_sinusoidal_cond = False
         self.precision = precision or os.environ.get("FOUNDDIFF_PRECISION", "bf16")
         self.clip_cfg = clip_cfg or arch.RN50
-        _build_tree(self, arch.da_unet_spec(dim, self.dim_mults, channels, "", self.clip_cfg))
+        _build_tree(self, arch.da_unet_spec(dim, self.dim_mults, channels, "", self.clip_cfg, input_condition))
         self._engine = None
 
     # --- checkpoint handling: accept-and-ignore the dead weight a real checkpoint carries
@@ -143,13 +144,15 @@ class Unet(_ParamTree):
 
     @torch.no_grad()
     def forward(self, x, time, x_self_cond=None, reuse_condition=False):
-        """x (B,2,H,W) = cat(x_t, x_input); time (B,) float.  Returns (B,1,H,W) fp32."""
+        """x (B,2,H,W) = cat(x_t, x_input) -- (B,3,H,W) with the input_condition plane; time (B,) float.
+        Returns (B,1,H,W) fp32."""
         eng = self.engine()
         x = x.float()
         x_t, x_in = x[:, 0:1].contiguous(), x[:, 1:2].contiguous()
+        x_c2 = x[:, 2:3].contiguous() if self.input_condition else None
         if not reuse_condition:
             eng.encode_condition(x_in)
-        return eng.forward(x_t, x_in, time.float().contiguous()).clone()
+        return eng.forward(x_t, x_in, time.float().contiguous(), x_cond2=x_c2).clone()
 
 
 class UnetRes(nn.Module):
@@ -252,9 +255,9 @@ class ResidualDiffusion(nn.Module):
         assert not model.random_or_learned_sinusoidal_cond
         if objective not in ("pred_res", "pred_noise", "pred_res_noise", "pred_x0_noise"):
             raise ValueError(f"unknown objective {objective!r}")
-        if not condition or input_condition:
-            raise NotImplementedError("condition=True, input_condition=False (every FoundDiff configuration) "
-                                      "is what the DA-CLIP conditioned Unet supports (SURVEY 8f-4)")
+        if not condition:
+            raise NotImplementedError("condition=True is what the DA-CLIP conditioned Unet supports "
+                                      "(it reads x[:,1], src/DADiff.py:692)")
         if objective in ("pred_res_noise", "pred_x0_noise") and getattr(model, "num_unet", 1) != 2:
             raise ValueError(f"objective {objective!r} needs UnetRes(num_unet=2) (src/DADiff.py:826-831)")
         if timesteps != 1000:
@@ -330,7 +333,7 @@ class ResidualDiffusion(nn.Module):
         return 0, True, False, 0
 
     def _is_shipped(self):
-        return self._plan() == (0, True, False, 0)
+        return self._plan() == (0, True, False, 0) and not self.input_condition
 
     def _engines(self):
         mode, r0, r1, _ = self._plan()
@@ -347,13 +350,21 @@ class ResidualDiffusion(nn.Module):
         t0 = ((self.alphas_cumsum if tsel0 == 0 else self.betas_cumsum)[t_idx] * T).float().contiguous()
         t1 = (self.betas_cumsum[t_idx] * T).float().contiguous()
         o0 = o1 = None
+        c2 = self._xc2 if self.input_condition else None
         if mode == 1 and r0:                    # single-UNet pred_noise: its output plays the role of o1
-            o1 = self.model.unet0.engine().forward(x, x_in, t0).clone()
+            o1 = self.model.unet0.engine().forward(x, x_in, t0, x_cond2=c2).clone()
         elif r0:
-            o0 = self.model.unet0.engine().forward(x, x_in, t0).clone()
+            o0 = self.model.unet0.engine().forward(x, x_in, t0, x_cond2=c2).clone()
         if r1:
-            o1 = self.model.unet1.engine().forward(x, x_in, t1).clone()
+            o1 = self.model.unet1.engine().forward(x, x_in, t1, x_cond2=c2).clone()
         return mode, o0, o1
+
+    def _set_cond2(self, x_input_condition):
+        """third input plane (src/DADiff.py:1157-1158); already normalised by the caller / sample()."""
+        if self.input_condition:
+            if not torch.is_tensor(x_input_condition):
+                raise ValueError("input_condition=True needs x_input_condition (sample(x_input=[a, b]))")
+            self._xc2 = x_input_condition.contiguous().float()
 
     def _par(self, t_idx, k=(0., 0., 0., 0.), flag=0.):
         B = t_idx.shape[0]
@@ -410,6 +421,7 @@ class ResidualDiffusion(nn.Module):
         x_input = x_input.contiguous().float()
         x = x.contiguous().float()
         if not self._is_shipped():
+            self._set_cond2(x_input_condition)
             if not reuse_condition:
                 self._encode_all(x_input)
             _, pr, pn, xs = self._step_obj(0, x_input, x, t, None, want_preds=True)
@@ -438,6 +450,8 @@ class ResidualDiffusion(nn.Module):
         hs = self._hs()
         t_idx = torch.full((B,), t, device=x.device, dtype=torch.long)
         if not self._is_shipped():
+            if torch.is_tensor(x_input_condition):
+                self._set_cond2(x_input_condition)
             if not reuse_condition:
                 self._encode_all(x_input)
             if t > 0 and noise is None:
@@ -500,6 +514,8 @@ class ResidualDiffusion(nn.Module):
     @torch.no_grad()
     def p_sample_loop(self, x_input, shape, last=True, noise=None, step_noise=None):
         """src/DADiff.py:1233-1273.  `noise`: the initial randn(shape); `step_noise`: callable t -> tensor."""
+        if self.input_condition:
+            self._set_cond2(x_input[1])
         x_input = x_input[0].contiguous().float()
         if not self._is_shipped():
             return self._generic_loop(x_input, shape, last, noise, step_noise, ddim=False)
@@ -538,6 +554,8 @@ class ResidualDiffusion(nn.Module):
     @torch.no_grad()
     def ddim_sample(self, x_input, shape, last=True, noise=None):
         """src/DADiff.py:1276-1365 (eta = 0, type 'use_pred_noise')."""
+        if self.input_condition:
+            self._set_cond2(x_input[1])
         x_input = x_input[0].contiguous().float()
         if not self._is_shipped():
             return self._generic_loop(x_input, shape, last, noise, None, ddim=True)
@@ -609,7 +627,11 @@ class ResidualDiffusion(nn.Module):
     @torch.no_grad()
     def sample(self, x_input=0, batch_size=16, last=True, noise=None, step_noise=None):
         """src/DADiff.py:1368-1380: x_input = [ldct (B,1,H,W) in [0,1]] -> list of images in ~[0,1]."""
-        x_input = normalize_to_neg_one_to_one(list(x_input))
+        x_input = list(x_input)
+        if self.input_condition and self.input_condition_mask:     # src/DADiff.py:1372-1375
+            x_input[0] = normalize_to_neg_one_to_one(x_input[0])
+        else:
+            x_input = normalize_to_neg_one_to_one(x_input)
         batch_size, channels, h, w = x_input[0].shape
         size = (batch_size, channels, h, w)
         if self.is_ddim_sampling:

@@ -87,13 +87,13 @@ def clip_visual_spec(p, layers=RN50["layers"], width=RN50["width"], embed_dim=RN
     return spec
 
 
-def da_unet_spec(dim=64, dim_mults=(1, 2, 4, 8), channels=1, prefix="", clip=RN50):
+def da_unet_spec(dim=64, dim_mults=(1, 2, 4, 8), channels=1, prefix="", clip=RN50, input_condition=False):
     """Live parameters of DADiff.Unet (src/DADiff.py:530-683); `prefix` e.g. 'model.unet0.'."""
     spec = {}
     p = prefix
     time_dim = dim * 4
     spec[p + "prompt"] = (1, time_dim)
-    spec[p + "init_conv.weight"] = (dim, 2 * channels, 7, 7)
+    spec[p + "init_conv.weight"] = (dim, (3 if input_condition else 2) * channels, 7, 7)   # src/DADiff.py:553-555
     spec[p + "init_conv.bias"] = (dim,)
     spec[p + "time_mlp.1.weight"] = (time_dim, dim)
     spec[p + "time_mlp.1.bias"] = (time_dim,)

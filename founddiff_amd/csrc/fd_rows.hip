@@ -319,11 +319,11 @@ __global__ void avgpool_kernel(const T *__restrict__ in, T *__restrict__ out, in
 }
 
 template <typename T>
-__global__ void pack_planes_kernel(const float *__restrict__ p0, const float *__restrict__ p1, T *__restrict__ out,
-                                   int64_t npix, int cpad) {
+__global__ void pack_planes_kernel(const float *__restrict__ p0, const float *__restrict__ p1,
+                                   const float *__restrict__ p2, T *__restrict__ out, int64_t npix, int cpad) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < npix;
          i += (int64_t)gridDim.x * blockDim.x) {
-        float v[8] = {p0[i], p1 ? p1[i] : 0.f, 0, 0, 0, 0, 0, 0};
+        float v[8] = {p0[i], p1 ? p1[i] : 0.f, p2 ? p2[i] : 0.f, 0, 0, 0, 0, 0};
         store8(out + i * cpad, v);
         for (int c = 8; c < cpad; c += 8) {
             float zz[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -447,17 +447,21 @@ extern "C" int fd_avgpool(int dtype, const void *in, void *out, int B, int H, in
     return FD_OK;
 }
 
-extern "C" int fd_pack_planes(int dtype, const float *p0, const float *p1, void *out, int B, int64_t hw, int cpad,
-                              void *stream) {
+extern "C" int fd_pack_planes3(int dtype, const float *p0, const float *p1, const float *p2, void *out, int B,
+                               int64_t hw, int cpad, void *stream) {
     FD_REQUIRE(p0 && out && cpad >= 8 && cpad % 8 == 0, "fd_pack_planes: bad args");
     int64_t npix = (int64_t)B * hw;
     dim3 grid(grid1d(npix)), block(256);
     if (dtype == FD_BF16)
-        hipLaunchKernelGGL(pack_planes_kernel<bf16>, grid, block, 0, (hipStream_t)stream, p0, p1, (bf16 *)out, npix, cpad);
+        hipLaunchKernelGGL(pack_planes_kernel<bf16>, grid, block, 0, (hipStream_t)stream, p0, p1, p2, (bf16 *)out, npix, cpad);
     else
-        hipLaunchKernelGGL(pack_planes_kernel<float>, grid, block, 0, (hipStream_t)stream, p0, p1, (float *)out, npix, cpad);
+        hipLaunchKernelGGL(pack_planes_kernel<float>, grid, block, 0, (hipStream_t)stream, p0, p1, p2, (float *)out, npix, cpad);
     FD_LAUNCH_OK("fd_pack_planes");
     return FD_OK;
+}
+extern "C" int fd_pack_planes(int dtype, const float *p0, const float *p1, void *out, int B, int64_t hw, int cpad,
+                              void *stream) {
+    return fd_pack_planes3(dtype, p0, p1, nullptr, out, B, hw, cpad, stream);
 }
 
 extern "C" int fd_final_conv1(int dtype, const void *x, const float *w, const float *b, float *out, int64_t npix,

@@ -144,6 +144,7 @@ class DAEngine:
         self.dim = sd["init_conv.weight"].shape[0]
         self.time_dim = sd["time_mlp.1.weight"].shape[0]
         self.init_conv = self._convw(sd["init_conv.weight"], sd["init_conv.bias"], cin_pad=8)
+        self.in_planes = sd["init_conv.weight"].shape[1]          # 2, or 3 with input_condition
         self.tm = dict(w1=self._f(sd["time_mlp.1.weight"]), b1=self._f(sd["time_mlp.1.bias"]),
                        w2=self._f(sd["time_mlp.3.weight"]), b2=self._f(sd["time_mlp.3.bias"]))
         self.prompt = dict(
@@ -496,9 +497,13 @@ class DAEngine:
         self.mod_all = self.linear(tt, self.adaln_w, self.adaln_b,
                                    self._b("mod_all", (B, self.mod_total), torch.float32), pre_silu=True)
 
-    def forward(self, x_t, x_in, time, out=None):
+    def forward(self, x_t, x_in, time, out=None, x_cond2=None):
         """x_t, x_in: (B,1,H,W) fp32 device tensors in [-1,1]; time (B,) fp32.  Returns the raw
-        model output (B,1,H,W) fp32.  encode_condition(x_in) must have been called."""
+        model output (B,1,H,W) fp32.  encode_condition(x_in) must have been called.  x_cond2: the
+        third input plane of an input_condition model (src/DADiff.py:1157-1158)."""
+        if (x_cond2 is not None) != (self.in_planes == 3):
+            raise ValueError(f"this Unet's init_conv takes {self.in_planes} input planes "
+                             f"(input_condition={'True' if self.in_planes == 3 else 'False'})")
         B, _, H, W = x_t.shape
         nd = len(self.downs)
         div = 2 ** sum(1 for d in self.downs if d["stride"] == 2)
@@ -507,7 +512,7 @@ class DAEngine:
         s = self.stream
         self.time_cond(time)
         xin8 = self._b("unet_in", (B, H, W, 8))
-        L.call("fd_pack_planes", self.dt, _p(x_t), _p(x_in), _p(xin8), B, H * W, 8, s)
+        L.call("fd_pack_planes3", self.dt, _p(x_t), _p(x_in), _p(x_cond2), _p(xin8), B, H * W, 8, s)
         r = self._b("r", (B, H, W, self.dim))
         self.conv(self.init_conv, xin8, B, H, W, r)
         x, h, w = r, H, W

@@ -208,6 +208,10 @@ int fd_add_f32(const float *a, const float *b, float *out, int64_t n, void *stre
  *   (torch.cat((x, x_input), 1) src/DADiff.py:1160; x[:,1].repeat(1,3,..) 692 is folded).    */
 int fd_pack_planes(int dtype, const float *p0, const float *p1, void *out, int B, int64_t hw,
                    int cpad, void *stream);
+/* same with a third plane: torch.cat((x, x_input, x_input_condition), 1)  src/DADiff.py:1157-1158
+ * (p1, p2 may be NULL)                                                                        */
+int fd_pack_planes3(int dtype, const float *p0, const float *p1, const float *p2, void *out, int B,
+                    int64_t hw, int cpad, void *stream);
 /* final 1x1 conv to ONE channel (src/DADiff.py:683,740): out[b,p] = b0 + sum_c x[b,p,c] w[c] */
 int fd_final_conv1(int dtype, const void *x, const float *w, const float *b, float *out,
                    int64_t npix, int C, void *stream);

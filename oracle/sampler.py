@@ -19,11 +19,14 @@ from . import nets, schedule
 class ResidualOracle:
     def __init__(self, sd, prefix="model.unet0.", timesteps=1000, sampling_timesteps=None,
                  sum_scale=0.01, after_init=True, scan_fn=None, hoist_cond=True, objective="pred_res",
-                 test_res_or_noise="res", num_unet=1, prefix1="model.unet1."):
+                 test_res_or_noise="res", num_unet=1, prefix1="model.unet1.", input_condition=False,
+                 input_condition_mask=False):
         self.sd = nets.SD(sd, prefix)
         self.sd1 = nets.SD(sd, prefix1) if num_unet == 2 else None
         self.objective, self.test, self.num_unet = objective, test_res_or_noise, num_unet
         self._cond1 = None
+        self.input_condition, self.input_condition_mask = input_condition, input_condition_mask
+        self.x_cond2 = None           # third input plane (src/DADiff.py:1157-1158), set by sample() / the caller
         self.T = timesteps
         self.S = sampling_timesteps if sampling_timesteps is not None else timesteps
         self.sum_scale = sum_scale
@@ -36,7 +39,7 @@ class ResidualOracle:
         """t_idx (B,) long -> raw output (B,1,H,W) of unet `which`; time_sel 0: alphas_cumsum[t]*T, 1:
         betas_cumsum[t]*T -- the two entries of the time list model_predictions builds (1160-1163)."""
         time = self.sch["alphas_cumsum" if time_sel == 0 else "betas_cumsum"][t_idx] * self.T
-        x = torch.cat((x_t, x_in), dim=1)
+        x = torch.cat((x_t, x_in, self.x_cond2), dim=1) if self.input_condition else torch.cat((x_t, x_in), dim=1)
         sd = self.sd if which == 0 else self.sd1
         cond = None
         if self.hoist_cond:
@@ -104,10 +107,14 @@ class ResidualOracle:
         nz = noise if t > 0 else 0.0
         return mean + (0.5 * logvar).exp() * nz, x_start
 
-    def sample(self, x_input01, noise0, step_noise=None, trace=None, t_stop=0):
+    def sample(self, x_input01, noise0, step_noise=None, trace=None, t_stop=0, x_cond2_01=None):
         """x_input01 (B,1,H,W) in [0,1]; noise0 the one randn(shape) draw; step_noise[t] for
-        the ancestral loop.  Returns [x_T01, out01] like sample(last=True)."""
+        the ancestral loop.  Returns [x_T01, out01] like sample(last=True).  x_cond2_01: the second
+        list entry of sample(x_input=[a, b]) when input_condition (normalised unless
+        input_condition_mask, src/DADiff.py:1372-1375)."""
         self._cond = self._cond1 = None
+        if self.input_condition:
+            self.x_cond2 = x_cond2_01 if self.input_condition_mask else x_cond2_01 * 2 - 1
         x_in = x_input01 * 2 - 1
         img = x_in + math.sqrt(self.sum_scale) * noise0
         start = img

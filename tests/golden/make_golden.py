@@ -249,6 +249,8 @@ VARIANTS = {   # objectives / dual-UNet configurations the referen
     "rn_noise": dict(num_unet=2, objective="pred_res_noise", test="noise"),
     "rn_res": dict(num_unet=2, objective="pred_res_noise", test="res"),
     "x0_noise": dict(num_unet=2, objective="pred_x0_noise", test="res_noise"),
+    "incond": dict(num_unet=1, objective="pred_res", test="res", input_condition=True),   # third input plane (1157-1158)
+    "incond_mask": dict(num_unet=1, objective="pred_res", test="res", input_condition=True, mask=True),   # 1372-1373
 }
 
 
@@ -263,30 +265,41 @@ def g_e2e_da_variants(D):
     noises = torch.randn(3, *x_in.shape, generator=g)
     torch.manual_seed(10)
     noise0 = torch.randn(x_in.shape)
-    arrs = {"x_input": x_in, "noise0": noise0, "anc.noise": noises}
+    x_cond2 = torch.from_numpy(ct_phantom(1, 64, seed=11)[1])        # second condition plane (input_condition)
+    arrs = {"x_input": x_in, "x_cond2": x_cond2, "noise0": noise0, "anc.noise": noises}
     spec_all = {}
     for name, v in VARIANTS.items():
+        ic, mask = v.get("input_condition", False), v.get("mask", False)
         net = D.UnetRes(dim=32, dim_mults=(1, 2), num_unet=v["num_unet"], condition=True, objective=v["objective"],
-                        test_res_or_noise=v["test"])
+                        test_res_or_noise=v["test"], input_condition=ic)
         dif = D.ResidualDiffusion(net, image_size=64, timesteps=1000, sampling_timesteps=4, objective=v["objective"],
-                                  loss_type="l2", condition=True, sum_scale=0.01, test_res_or_noise=v["test"]).eval()
+                                  loss_type="l2", condition=True, sum_scale=0.01, test_res_or_noise=v["test"],
+                                  input_condition=ic, input_condition_mask=mask).eval()
         spec = {k: s for k, s in synth.spec_of(dif.state_dict()).items() if k.startswith("model.")}
         dif.load_state_dict(synth.synth_state_dict(spec, SEED_W), strict=False)
         dif.init()
-        spec_all.update({k: s for k, s in spec.items() if ".clip_model." not in k or ".dose_encoder." in k})
+        # the 3-plane init_conv of the input_condition variants gets its own key namespace in the fixture
+        ns = (lambda k: k.replace("model.", "model_ic.", 1)) if ic else (lambda k: k)
+        spec_all.update({ns(k): s for k, s in spec.items() if ".clip_model." not in k or ".dose_encoder." in k})
+        if ic:
+            new = synth.synth_state_dict({ns(k): s for k, s in spec.items()}, SEED_W)
+            dif.load_state_dict({k: new[ns(k)] for k in spec}, strict=False)
+            dif.init()
         torch.manual_seed(10)
-        outs = dif.sample([x_in.clone()], batch_size=1, last=False)
+        xs_in = [x_in.clone(), x_cond2.clone()] if ic else [x_in.clone()]
+        outs = dif.sample(xs_in, batch_size=1, last=False)
         arrs[name + ".ddim.imgs"] = torch.stack(outs, 0)
         xi = x_in * 2 - 1
         xt = xi + 0.1 * noise0
         tt = torch.full((1,), 979, dtype=torch.long)
-        pr = dif.model_predictions(xi, xt, tt)
+        xc2 = (x_cond2 if mask else x_cond2 * 2 - 1) if ic else 0
+        pr = dif.model_predictions(xi, xt, tt, xc2)
         arrs[name + ".mp.pred_res"], arrs[name + ".mp.pred_noise"], arrs[name + ".mp.x_start"] = \
             pr.pred_res, pr.pred_noise, pr.pred_x_start
         img, anc = xt.clone(), []
         for i, t in enumerate(range(999, 996, -1)):
             with um.patch.object(torch, "randn_like", lambda x, i=i: noises[i]):
-                img, _ = dif.p_sample(xi, img, t)
+                img, _ = dif.p_sample(xi, img, t, xc2)
             anc.append(img.clone())
         arrs[name + ".anc.imgs"] = torch.stack(anc, 0)
         print(name, "done")

@@ -258,7 +258,7 @@ def test_properties_512_bf16():
 VARIANTS = {   # name -> (num_unet, objective, test_res_or_noise); mirrors tests/golden/make_golden.py
     "pred_noise": (1, "pred_noise", "noise"), "res_noise": (2, "pred_res_noise", "res_noise"),
     "rn_noise": (2, "pred_res_noise", "noise"), "rn_res": (2, "pred_res_noise", "res"),
-    "x0_noise": (2, "pred_x0_noise", "res_noise"),
+    "x0_noise": (2, "pred_x0_noise", "res_noise"), "incond": (1, "pred_res", "res"), "incond_mask": (1, "pred_res", "res"),
 }
 
 
@@ -269,11 +269,16 @@ def test_objective_variants_fp32(golden, name):
     from founddiff_amd.DADiff import ResidualDiffusion, UnetRes
     g = golden("e2e_da_variants")
     nu, obj, tst = VARIANTS[name]
+    ic, mask = name.startswith("incond"), name == "incond_mask"
     net = UnetRes(dim=32, dim_mults=(1, 2), num_unet=nu, condition=True, objective=obj, test_res_or_noise=tst,
-                  precision="fp32", clip_cfg=TINY_CLIP)
+                  precision="fp32", clip_cfg=TINY_CLIP, input_condition=ic)
     dif = ResidualDiffusion(net, image_size=64, timesteps=1000, sampling_timesteps=4, objective=obj, loss_type="l2",
-                            condition=True, sum_scale=0.01, test_res_or_noise=tst)
-    w = {k: v for k, v in g.weights("model.").items() if nu == 2 or not k.startswith("model.unet1.")}
+                            condition=True, sum_scale=0.01, test_res_or_noise=tst, input_condition=ic,
+                            input_condition_mask=mask)
+    if ic:      # the 3-plane models were generated under their own key namespace
+        w = {k.replace("model_ic.", "model.", 1): v for k, v in g.weights("model_ic.").items()}
+    else:
+        w = {k: v for k, v in g.weights("model.").items() if nu == 2 or not k.startswith("model.unet1.")}
     missing, unexpected = dif.load_state_dict(w, strict=False)
     assert not [k for k in missing if k.startswith("model.")], missing[:5]
     assert not unexpected, unexpected[:5]
@@ -286,16 +291,18 @@ def test_objective_variants_fp32(golden, name):
     xi = x01 * 2 - 1
     xt = xi + 0.1 * g["noise0"].cuda()
     tt = torch.full((1,), 979, dtype=torch.long, device="cuda")
-    p = dif.model_predictions(xi, xt, tt)
+    c01 = g["x_cond2"].cuda()
+    xc2 = (c01 if mask else c01 * 2 - 1) if ic else 0
+    p = dif.model_predictions(xi, xt, tt, xc2)
     assert rel_err(p.pred_res.cpu(), g[name + ".mp.pred_res"]) < tol
     assert rel_err(p.pred_noise.cpu(), g[name + ".mp.pred_noise"]) < 1e-3
     assert rel_err(p.pred_x_start.cpu(), g[name + ".mp.x_start"]) < tol
-    outs = dif.sample([x01], batch_size=1, last=False, noise=g["noise0"].cuda())
+    outs = dif.sample([x01, c01] if ic else [x01], batch_size=1, last=False, noise=g["noise0"].cuda())
     ref = g[name + ".ddim.imgs"]
     assert len(outs) == ref.shape[0]
     for i, o in enumerate(outs):
         assert rel_err(o.cpu(), ref[i]) < tol, i
     img = xt.clone()
     for i, t in enumerate(range(999, 996, -1)):
-        img, _ = dif.p_sample(xi, img, t, noise=g["anc.noise"][i].cuda())
+        img, _ = dif.p_sample(xi, img, t, xc2, noise=g["anc.noise"][i].cuda())
         assert rel_err(img.cpu(), g[name + ".anc.imgs"][i]) < tol, t

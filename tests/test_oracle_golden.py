@@ -155,7 +155,7 @@ def test_e2e_da_tiny(golden):
 VARIANTS = {   # name -> (num_unet, objective, test_res_or_noise); mirrors tests/golden/make_golden.py
     "pred_noise": (1, "pred_noise", "noise"), "res_noise": (2, "pred_res_noise", "res_noise"),
     "rn_noise": (2, "pred_res_noise", "noise"), "rn_res": (2, "pred_res_noise", "res"),
-    "x0_noise": (2, "pred_x0_noise", "res_noise"),
+    "x0_noise": (2, "pred_x0_noise", "res_noise"), "incond": (1, "pred_res", "res"), "incond_mask": (1, "pred_res", "res"),
 }
 
 
@@ -164,8 +164,13 @@ def test_e2e_da_variants(golden, name):
     """The other objectives and the dual-UNet dispatch against the reference's own outputs."""
     g = golden("e2e_da_variants")
     nu, obj, tst = VARIANTS[name]
-    orc = sampler.ResidualOracle(g.weights(), sampling_timesteps=4, objective=obj, test_res_or_noise=tst, num_unet=nu)
+    ic, mask = name.startswith("incond"), name == "incond_mask"
+    orc = sampler.ResidualOracle(g.weights("model_ic." if ic else "model."), sampling_timesteps=4, objective=obj,
+                                 test_res_or_noise=tst, num_unet=nu, input_condition=ic, input_condition_mask=mask,
+                                 prefix="model_ic.unet0." if ic else "model.unet0.")
     x_in = g["x_input"]
+    if ic:
+        orc.x_cond2 = g["x_cond2"] if mask else g["x_cond2"] * 2 - 1
     xi = x_in * 2 - 1
     xt = xi + 0.1 * g["noise0"]
     tt = torch.full((1,), 979, dtype=torch.long)
@@ -177,7 +182,7 @@ def test_e2e_da_variants(golden, name):
     assert rel_err(pn, g[name + ".mp.pred_noise"]) < 1e-4
     assert rel_err(xs, g[name + ".mp.x_start"]) < tol
     trace = {}
-    out = orc.sample(x_in, g["noise0"], trace=trace)
+    out = orc.sample(x_in, g["noise0"], trace=trace, x_cond2_01=g["x_cond2"] if ic else None)
     imgs = g[name + ".ddim.imgs"]
     assert rel_err(out[0], imgs[0]) < 1e-6
     for i, im in enumerate(trace["img"]):
