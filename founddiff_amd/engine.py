@@ -99,6 +99,16 @@ class DAEngine:
             r["res"] = self._convw(s["res_conv.weight"], s["res_conv.bias"])
         return r
 
+    def _pack_init7(self, w):
+        """init_conv weight (Cout, C<=3, 7, 7) -> bf16 [Cout][7 kh][8 kw][4 c] (include/founddiff_hip.h:
+        fd_init_conv7): one filter row = one K32 MFMA step."""
+        co, c = w.shape[0], w.shape[1]
+        if self.tdt != torch.bfloat16 or c > 3 or tuple(w.shape[2:]) != (7, 7):
+            return None
+        p = torch.zeros(co, 7, 8, 4, dtype=torch.float32)
+        p[:, :, :7, :c] = w.detach().float().permute(0, 2, 3, 1)
+        return p.reshape(co, 224).contiguous().to(self.dev, torch.bfloat16)
+
     @staticmethod
     def _dw_masked(w9c):
         """[9][C] fp32 taps (tap = 3*dy + dx) -> [5][C] int32 words of bf16 pairs in the layout
@@ -145,6 +155,7 @@ class DAEngine:
         self.time_dim = sd["time_mlp.1.weight"].shape[0]
         self.init_conv = self._convw(sd["init_conv.weight"], sd["init_conv.bias"], cin_pad=8)
         self.in_planes = sd["init_conv.weight"].shape[1]          # 2, or 3 with input_condition
+        self.init_w7 = self._pack_init7(sd["init_conv.weight"])
         self.tm = dict(w1=self._f(sd["time_mlp.1.weight"]), b1=self._f(sd["time_mlp.1.bias"]),
                        w2=self._f(sd["time_mlp.3.weight"]), b2=self._f(sd["time_mlp.3.bias"]))
         self.prompt = dict(
@@ -511,10 +522,14 @@ class DAEngine:
             raise ValueError(f"H,W must be multiples of {2 * div} (got {H}x{W})")
         s = self.stream
         self.time_cond(time)
-        xin8 = self._b("unet_in", (B, H, W, 8))
-        L.call("fd_pack_planes3", self.dt, _p(x_t), _p(x_in), _p(x_cond2), _p(xin8), B, H * W, 8, s)
         r = self._b("r", (B, H, W, self.dim))
-        self.conv(self.init_conv, xin8, B, H, W, r)
+        if self.init_w7 is not None and L.lib().fd_init_conv7_ok(self.dt, self.dim, H, W):
+            L.call("fd_init_conv7", self.dt, _p(x_t), _p(x_in), _p(x_cond2), _p(self.init_w7), _p(self.init_conv.b),
+                   _p(r), B, H, W, self.dim, s)
+        else:
+            xin8 = self._b("unet_in", (B, H, W, 8))
+            L.call("fd_pack_planes3", self.dt, _p(x_t), _p(x_in), _p(x_cond2), _p(xin8), B, H * W, 8, s)
+            self.conv(self.init_conv, xin8, B, H, W, r)
         x, h, w = r, H, W
         skips = []
         for i, d in enumerate(self.downs):

@@ -208,6 +208,15 @@ int fd_add_f32(const float *a, const float *b, float *out, int64_t n, void *stre
  *   (torch.cat((x, x_input), 1) src/DADiff.py:1160; x[:,1].repeat(1,3,..) 692 is folded).    */
 int fd_pack_planes(int dtype, const float *p0, const float *p1, void *out, int B, int64_t hw,
                    int cpad, void *stream);
+/* fd_init_conv7: the UNet's init_conv (7x7, pad 3, bias) straight from the fp32 image planes
+ *   (src/DADiff.py:558, 704) -- bf16 mode, Cout in {32, 64}, H and W multiples of 16
+ *   (fd_init_conv7_ok; otherwise fd_pack_planes3 + fd_conv2d).
+ *   p0, p1, p2: [B,H,W] fp32 planes (x_t, x_input, x_input_condition; p1 / p2 may be NULL)
+ *   w_packed: bf16 [Cout][7 kh][8 kw][4 c], zero where kw = 7 or c >= number of planes
+ *   out: [B,H,W,Cout] bf16                                                                    */
+int fd_init_conv7_ok(int dtype, int Cout, int H, int W);
+int fd_init_conv7(int dtype, const float *p0, const float *p1, const float *p2, const void *w_packed,
+                  const float *bias, void *out, int B, int H, int W, int Cout, void *stream);
 /* same with a third plane: torch.cat((x, x_input, x_input_condition), 1)  src/DADiff.py:1157-1158
  * (p1, p2 may be NULL)                                                                        */
 int fd_pack_planes3(int dtype, const float *p0, const float *p1, const float *p2, void *out, int B,

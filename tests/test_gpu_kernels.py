@@ -508,3 +508,27 @@ def test_pw_dw3x3_fused(eng_factory, cfg):
         ref_z = F.silu(t[..., cdw:])
         assert rel_err(out_z[..., cz:2 * cz].float().cpu(), ref_z) < 1.2e-2
         assert float(out_z[..., :cz].float().abs().max()) == 0.0 and float(out_z[..., 2 * cz:].float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("cfg", [dict(cout=64, planes=2, hw=(48, 64)), dict(cout=32, planes=3, hw=(32, 32)),
+                                 dict(cout=64, planes=1, hw=(16, 32))])
+def test_init_conv7(eng_factory, cfg):
+    """Dedicated init_conv kernel (7x7 from the fp32 planes, bf16) vs F.conv2d on bf16-rounded operands."""
+    from founddiff_amd import _lib as L
+    e = eng_factory("bf16")
+    torch.manual_seed(41)
+    B, (H, W), co, c = 2, cfg["hw"], cfg["cout"], cfg["planes"]
+    x = torch.randn(B, c, H, W)
+    w = torch.randn(co, c, 7, 7) / (7 * c ** 0.5)
+    bias = torch.randn(co)
+    ref = F.conv2d(rq(x, "bf16"), rq(w, "bf16"), bias, padding=3)
+    assert L.lib().fd_init_conv7_ok(L.FD_BF16, co, H, W)
+    wp = e._pack_init7(w)
+    planes = [x[:, i].contiguous().cuda() for i in range(c)] + [None] * (3 - c)
+    out = torch.empty(B, H, W, co, device="cuda", dtype=torch.bfloat16)
+    bd = bias.cuda()
+    L.call("fd_init_conv7", L.FD_BF16, *[None if p is None else p.data_ptr() for p in planes], wp.data_ptr(),
+           bd.data_ptr(), out.data_ptr(), B, H, W, co, None)
+    torch.cuda.synchronize()
+    assert rel_err(nchw(out), ref) < 6e-3
+    assert rel_err(nchw(out)[:, :, :3], ref[:, :, :3]) < 8e-3 and rel_err(nchw(out)[..., -3:], ref[..., -3:]) < 8e-3
