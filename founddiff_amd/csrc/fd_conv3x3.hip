@@ -35,7 +35,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
     constexpr int NB = BN / 32, NT = BN / WNW / 16, MT = 4;
     constexpr int HALO_B = HP * ROWB;                 // 23040
     constexpr int WT_B = BN * ROWB;
-    constexpr int LOOP_B = HALO_B + 2 * WT_B;      // ONE halo buffer (the next slab waits in registers)
+    constexpr int NWB = 3;                         // weight-tile ring (LDS-DMA, two taps ahead)
+    constexpr int LOOP_B = HALO_B + NWB * WT_B;    // ONE halo buffer (the next slab waits in registers)
     constexpr int C_B = BM * BN * 4;
     constexpr int SM_B = LOOP_B > C_B ? LOOP_B : C_B;
     __shared__ __attribute__((aligned(16))) unsigned char smem[SM_B];
@@ -51,22 +52,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
     const bf16 *wgt = (const bf16 *)p.weight;
 
     // ---- halo loader: chunk ids hid = tid + 256*i -> (halo pixel, 16-byte channel chunk)
-    int hoff[HL];          // element offset of the source pixel inside the image, or -1
+    // Every load is issued (from a clamped in-image address, zeroed on the LDS store where it was
+    // padding): the s_waitcnt bookkeeping of the weight ring below counts wave-level VMEM instructions.
+    int hoff[HL];          // element offset of the (clamped) source pixel inside the image
+    uint32_t hvalid = 0;
 #pragma unroll
     for (int i = 0; i < HL; ++i) {
         const int hid = tid + 256 * i;
-        const int hp = hid >> 3;
-        hoff[i] = -1;
-        if (hp < HP) {
-            const int hy = hp / HX, hx = hp - hy * HX;
-            int y = ty0 + hy - 1, x = tx0 + hx - 1;
-            if (y >= 0 && y < Hs && x >= 0 && x < Ws) {
-                if (p.upsample) { y >>= 1; x >>= 1; }
-                hoff[i] = y * p.W + x;
-            }
-        }
+        const int hp = min(hid >> 3, HP - 1);
+        const int hy = hp / HX, hx = hp - hy * HX;
+        int y = ty0 + hy - 1, x = tx0 + hx - 1;
+        if (y >= 0 && y < Hs && x >= 0 && x < Ws) hvalid |= 1u << i;
+        y = min(max(y, 0), Hs - 1);
+        x = min(max(x, 0), Ws - 1);
+        if (p.upsample) { y >>= 1; x >>= 1; }
+        hoff[i] = y * p.W + x;
     }
-    u32x4 rh[HL], rb[NB];
+    u32x4 rh[HL];
     auto halo_gload = [&](int slab) {
         const int c = slab * 64 + (tid & 7) * 8;
         const bf16 *src;
@@ -74,43 +76,51 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
         if (c < p.c0) { src = in0; ld = p.ld0; cc = c; }
         else { src = in1; ld = p.ld1; cc = c - p.c0; }
 #pragma unroll
-        for (int i = 0; i < HL; ++i) {
-            u32x4 v = {0, 0, 0, 0};
-            if (hoff[i] >= 0) v = *(const u32x4 *)(src + (int64_t)hoff[i] * ld + cc);
-            rh[i] = v;
-        }
+        for (int i = 0; i < HL; ++i) rh[i] = *(const u32x4 *)(src + (int64_t)hoff[i] * ld + cc);
     };
     auto halo_lstore = [&]() {
         unsigned char *sH = smem;
 #pragma unroll
         for (int i = 0; i < HL; ++i) {
             const int hid = tid + 256 * i, hp = hid >> 3;
-            if (hp < HP) *(u32x4 *)(sH + hp * ROWB + swz(hp, tid & 7)) = rh[i];
+            const u32x4 z4 = {0, 0, 0, 0};
+            if (hp < HP) *(u32x4 *)(sH + hp * ROWB + swz(hp, tid & 7)) = ((hvalid >> i) & 1) ? rh[i] : z4;
         }
     };
-    // ---- weight tile loader: [BN rows][64 k] of tap t, slab s
-    const int chunk = tid & 7, rbase = tid >> 3;
-    // per-lane element offset of its weight row, computed once; a tap / slab only moves the wave-uniform
-    // base (rows beyond Cout read row Cout-1: their products land in columns the epilogue never stores)
-    unsigned woff[NB];
+    // ---- weight tiles ([BN rows][64 k] of tap t, slab s) by LDS-DMA (global_load_lds_dwordx4): no VGPR
+    // staging, no ds_write, and a ring of NWB = 3 tiles so that a tile is requested TWO taps before it is
+    // read.  (With the register-staged double buffer the request preceded the use by one tap, ~800 cycles:
+    // an L2 round trip under load is longer -- removing the per-tap weight traffic altogether made these
+    // convolutions 30 % faster, which is the stall this ring goes after.)
+    // A wave-instruction fills 1 KiB = 8 tile rows: lane -> (row 8m + lane/8, physical chunk lane%8); the XOR
+    // swizzle of the LDS image is applied on the SOURCE side (the lane fetches the logical chunk that
+    // belongs in its physical slot).  Rows beyond Cout read row Cout-1: columns the epilogue never stores.
+    unsigned goff[NB];      // per-lane BYTE offset inside the weight matrix, computed once
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-        const int n = min(nt * BN + rbase + 32 * i, p.Cout - 1);
-        woff[i] = (unsigned)(n * K + chunk * 8) * 2u;     // BYTE offset: (SGPR base + 32-bit VGPR offset) loads
+        const int r = 8 * (wave * NB + i) + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        const int n = min(nt * BN + r, p.Cout - 1);
+        goff[i] = (unsigned)(n * K + c * 8) * 2u;
     }
-    auto w_gload = [&](int slab, int tap) {
-        const bf16 *wb = wgt + (tap * Cin + slab * 64);
-#pragma unroll
-        for (int i = 0; i < NB; ++i) rb[i] = *(const u32x4 *)((const char *)wb + woff[i]);
-    };
-    auto w_lstore = [&](int buf) {
-        unsigned char *sB = smem + HALO_B + buf * WT_B;
+    // Issued through inline asm on purpose: for __builtin_amdgcn_global_load_lds on a plain LDS array the
+    // compiler's waitcnt pass (no alias scopes to tell the ring slots apart) inserts s_waitcnt vmcnt(0)
+    // before the next ds_read of ANY LDS address, i.e. right after the request -- the opposite of a
+    // prefetch.  The counted waits below are therefore manual.  (The compiler's own vmcnt accounting for the
+    // register halo loads stays safe: operations it does not know about only make its waits stricter.)
+    const unsigned lds_w = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)smem + HALO_B +
+                           __builtin_amdgcn_readfirstlane(wave) * NB * 1024;
+    auto w_dma = [&](int slab, int tap, int buf) {
+        const char *wb = (const char *)(wgt + (tap * Cin + slab * 64));
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const int r = rbase + 32 * i;
-            *(u32x4 *)(sB + r * ROWB + swz(r, chunk)) = rb[i];
+            const unsigned dst = lds_w + buf * WT_B + i * 1024;       // wave-uniform: M0
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                         : : "s"(dst), "v"(goff[i]), "s"(wb) : "memory");
         }
     };
+    // s_waitcnt vmcnt(n) alone (expcnt / lgkmcnt left at their maxima); gfx9 encoding
+#define FD_WAIT_VM(n) __builtin_amdgcn_s_waitcnt(((n) & 0xF) | (((n) >> 4) << 14) | (0x7 << 4) | (0xF << 8))
 
     const int wm = wave / WNW, wn = wave % WNW;
     const int fr = lane & 15, fg = lane >> 4;
@@ -139,21 +149,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
         boff[j] = r * ROWB + swz(r, fg);
     }
 
+    w_dma(0, 0, 0);
+    w_dma(0, 1, 1);
     halo_gload(0);
-    w_gload(0, 0);
-    halo_lstore();
-    w_lstore(0);
+    halo_lstore();                                   // consumes the youngest loads: everything above has landed
+    FD_WAIT_VM(0);
     __syncthreads();
-    int wbuf = 0;
     for (int slab = 0; slab < nslab; ++slab) {
-        if (slab + 1 < nslab) halo_gload(slab + 1);          // in flight during this slab's 9 taps
+        const bool has_next = slab + 1 < nslab;
         const unsigned char *sH = smem;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const bool last_tap = tap == 8;
-            const bool more = !(last_tap && slab + 1 == nslab);
-            if (more) w_gload(last_tap ? slab + 1 : slab, last_tap ? 0 : tap + 1);
-            const unsigned char *sB = smem + HALO_B + wbuf * WT_B;
+            // request tile q+2 into the buffer tile q-1 was read from (all waves are past that barrier)
+            const bool dma = tap + 2 < 9 || has_next;
+            if (dma) w_dma(tap + 2 < 9 ? slab : slab + 1, (tap + 2) % 9, (tap + 2) % NWB);
+            if (tap == 0 && has_next) halo_gload(slab + 1);       // in flight during this slab's 9 taps
+            const unsigned char *sB = smem + HALO_B + (tap % NWB) * WT_B;
             const int kh = tap / 3, kw = tap - kh * 3;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -169,15 +181,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
                     for (int j = 0; j < NT; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
             }
-            if (more) w_lstore(wbuf ^ 1);
+            // tile q+1 (requested one tap ago) must have landed before the barrier publishes it.  vmcnt retires
+            // in order: allow exactly the operations issued AFTER that request -- this tap's DMA (NB
+            // instructions) and, during the first two taps of a slab, the HL halo loads of the next slab.
+            const bool halo_young = tap < 2 && has_next;
+            if (dma) { if (halo_young) FD_WAIT_VM(NB + HL); else FD_WAIT_VM(NB); }
+            else FD_WAIT_VM(0);
             __syncthreads();
-            if (last_tap && slab + 1 < nslab) {     // every wave is done with this slab's halo
+            if (last_tap && has_next) {             // every wave is done with this slab's halo
                 halo_lstore();
                 __syncthreads();
             }
-            wbuf ^= 1;
         }
     }
+#undef FD_WAIT_VM
 
     // ---- stage accumulators, row r = tile pixel (ty = r >> 4, tx = r & 15)
     float *sC = (float *)smem;
