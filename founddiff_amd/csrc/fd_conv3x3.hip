@@ -163,8 +163,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
             const bool last_tap = tap == 8;
             // request tile q+2 into the buffer tile q-1 was read from (all waves are past that barrier)
             const bool dma = tap + 2 < 9 || has_next;
-            if (dma) w_dma(tap + 2 < 9 ? slab : slab + 1, (tap + 2) % 9, (tap + 2) % NWB);
             if (tap == 0 && has_next) halo_gload(slab + 1);       // in flight during this slab's 9 taps
+            if (dma) w_dma(tap + 2 < 9 ? slab : slab + 1, (tap + 2) % 9, (tap + 2) % NWB);
             const unsigned char *sB = smem + HALO_B + (tap % NWB) * WT_B;
             const int kh = tap / 3, kw = tap - kh * 3;
 #pragma unroll
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
             // tile q+1 (requested one tap ago) must have landed before the barrier publishes it.  vmcnt retires
             // in order: allow exactly the operations issued AFTER that request -- this tap's DMA (NB
             // instructions) and, during the first two taps of a slab, the HL halo loads of the next slab.
-            const bool halo_young = tap < 2 && has_next;
+            const bool halo_young = tap < 1 && has_next;
             if (dma) { if (halo_young) FD_WAIT_VM(NB + HL); else FD_WAIT_VM(NB); }
             else FD_WAIT_VM(0);
             __syncthreads();
