@@ -280,7 +280,7 @@ extern "C" int fd_conv_prologue_ok(const fd_conv_params *pp) {
         if (p.prologue == FD_PRO_LN_GATE && (!p.ln_z || p.ln_ldz % 8 || p.ln_offz % 8 || !p.ln_gamma || !p.ln_beta)) return 0;
         if (!p.ln_shift || (p.prologue == FD_PRO_LN_MOD && !p.ln_scale)) return 0;
     }
-    if ((int64_t)p.H * p.W < 32768) return 0;     // few pixels: the tiled kernel parallelises better
+    if ((int64_t)p.H * p.W < 16384) return 0;     // few pixels: the tiled kernel parallelises better
     return 1;
 }
 

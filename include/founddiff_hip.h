@@ -101,7 +101,7 @@ typedef struct fd_conv_params {
 #define FD_PRO_NONE 0
 #define FD_PRO_LN_MOD 1
 #define FD_PRO_LN_GATE 2
-/* 1 if this conv runs on the streaming row-GEMM kernel (1x1, bf16, Cin <= 256, >= 32768 pixels
+/* 1 if this conv runs on the streaming row-GEMM kernel (1x1, bf16, Cin <= 256, >= 16384 pixels
  * per image, weights fit LDS) and may therefore carry a fused LN prologue.                    */
 int fd_conv_prologue_ok(const fd_conv_params *p);
 
