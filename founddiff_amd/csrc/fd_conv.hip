@@ -194,6 +194,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const fd_conv_
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             int r = rbase + RPL * i;
+            // PW: channel c of a 32-channel group sits at row (c&4 ? 16 : 0) + 4*(c>>3) + (c&3), so that the
+            // transposed MFMA below leaves 8 CONSECUTIVE channels of one pixel in a lane (fd_gemm_rows.hip)
+            if constexpr (PW) r = (r & ~31) | ((r & 4) << 2) | (((r & 31) >> 3) << 2) | (r & 3);
             *(u32x4 *)(sB + r * ROWB + swz(r, chunk)) = rb[i];
         }
     };
@@ -233,7 +236,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const fd_conv_
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = PW ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0)
+                                       : __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
             } else {
                 // f32: lane group fg owns k = 8*fg .. 8*fg+7 of the 32-wide step; MFMA step e
                 // contracts the k-set {8g + e}: any consistent A/B k-permutation is a valid sum.
@@ -270,6 +274,75 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const fd_conv_
         __syncthreads();
     }
 
+    if constexpr (PW) {
+        // ---- pointwise epilogue straight from the accumulators (D^T: lane = pixel fr, 4 channels per tile,
+        // two permuted tiles = 8 consecutive channels): no LDS staging, no barrier.  The dispatcher only
+        // selects PW when Cout, strides and offsets are multiples of 8 and no GroupNorm sums are wanted.
+        static_assert(NT % 2 == 0, "pointwise epilogue pairs 16-channel tiles");
+        const int64_t obase_pw = 0;
+        (void)obase_pw;
+        const int cpg = p.gn_groups > 0 ? p.Cout / p.gn_groups : 1;
+#pragma unroll
+        for (int jp = 0; jp < NT / 2; ++jp) {
+            const int n0 = nt * BN + TNW * wn + 32 * jp + 8 * fg;
+            if (n0 >= p.Cout) continue;
+            float bias8[8], ev0[8], ev1[8], gm = 0.f, gr = 0.f;
+            if (p.bias) load8(p.bias + n0, bias8);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
+            }
+            if (p.epilogue == FD_EPI_GATE_RES) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ev0[e] = p.gate[(int64_t)b * p.gate_ld + n0 + e];
+            } else if (p.epilogue == FD_EPI_GNSILU_ADD) {
+                load8(p.gn_gamma + n0, ev0);
+                load8(p.gn_beta + n0, ev1);
+                const int g = n0 / cpg;             // channels-per-group is a multiple of 8 (dispatcher)
+                gm = p.gn_mean_rstd[((int64_t)b * p.gn_groups + g) * 2];
+                gr = p.gn_mean_rstd[((int64_t)b * p.gn_groups + g) * 2 + 1];
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int m = mt * BM + TMW * wm + 16 * i + fr;
+                if (m >= OHW) continue;
+                const int64_t pix = (int64_t)b * OHW + m;
+                float val[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    val[e] = acc[i][2 * jp][e] + bias8[e];
+                    val[4 + e] = acc[i][2 * jp + 1][e] + bias8[4 + e];
+                }
+                if (p.epilogue == FD_EPI_SILU_SPLIT) {
+                    if (n0 >= p.epi_split) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) val[e] = fd_silu(val[e]);
+                    }
+                } else if (p.epilogue == FD_EPI_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) val[e] = fmaxf(val[e], 0.f);
+                } else if (p.epilogue == FD_EPI_GATE_RES || p.epilogue == FD_EPI_RES_RELU) {
+                    float rs[8];
+                    load8((const T *)p.res + pix * p.ld_res + p.off_res + n0, rs);
+                    if (p.epilogue == FD_EPI_GATE_RES) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) val[e] = rs[e] + ev0[e] * val[e];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) val[e] = fmaxf(val[e] + rs[e], 0.f);
+                    }
+                } else if (p.epilogue == FD_EPI_GNSILU_ADD) {
+                    float hv[8];
+                    load8((const T *)p.h + pix * p.Cout + n0, hv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) val[e] += fd_silu((hv[e] - gm) * gr * ev0[e] + ev1[e]);
+                }
+                if (p.out_f32) store8((float *)p.out + pix * p.ldo + p.offo + n0, val);
+                else store8((T *)p.out + pix * p.ldo + p.offo + n0, val);
+            }
+        }
+        return;
+    }
     // ---- epilogue on 8-channel vectors, one wave row (TMW tile rows) per pass through LDS
     constexpr int VPR = BN / 8;          // vectors per row
     constexpr int RPP = NTHR / VPR;      // rows per pass step
@@ -552,7 +625,12 @@ extern "C" int fd_conv2d(const fd_conv_params *pp, void *stream) {
     // pointwise fast path (bf16): same tiles, same K order, same results -- only the address math differs
     const bool pw = p.dtype == FD_BF16 && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad_h == 0 && p.pad_w == 0 &&
                     !p.upsample && p.ndir == 1 && p.OH == p.H && p.OW == p.W && (p.c0 + p.c1) % 64 == 0 &&
-                    p.c0 % 64 == 0 && (int64_t)p.Cout * (p.c0 + p.c1) < (1ll << 31);
+                    p.c0 % 64 == 0 && (int64_t)p.Cout * (p.c0 + p.c1) < (1ll << 31) &&
+                    // its epilogue stores 8-channel vectors straight from the accumulators
+                    !p.stats_partial && p.Cout % 8 == 0 && p.ldo % 8 == 0 && p.offo % 8 == 0 &&
+                    (!p.res || (p.ld_res % 8 == 0 && p.off_res % 8 == 0)) && (!p.bias || ((uintptr_t)p.bias & 15) == 0) &&
+                    (p.epilogue != FD_EPI_SILU_SPLIT || p.epi_split % 8 == 0) &&
+                    (p.epilogue != FD_EPI_GNSILU_ADD || (p.Cout / p.gn_groups) % 8 == 0);
 #define FD_CONV_LAUNCH(T_, BM_, BN_, WM_, WN_, PW_) \
     hipLaunchKernelGGL((conv_igemm_kernel<T_, BM_, BN_, WM_, WN_, PW_>), grid, block, 0, s, p)
 #define FD_CONV_DISPATCH(T_, PW_)                                     \
