@@ -213,6 +213,11 @@ __global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 8 ? 5 : 1))) void scan_ch
 // Phase B: block = 64 channels x S segments.  Each segment composes its chunks, segments are
 // chained through LDS, then each segment rewrites H_c with the carry-in of chunk c.
 constexpr int SEG = 16;
+// PER = chunks per segment (compile-time bound): a thread keeps its segment's (decay, H) pairs in registers
+// between composing the segment and rewriting the carry-ins, so the chunk-state workspace is read ONCE and
+// written once (it was read twice: this kernel is bandwidth-bound on that fp32 workspace -- N x D floats per
+// chunk and direction, 540 us per batch-8 forward).
+template <int PER>
 __global__ __launch_bounds__(64 * SEG) void scan_carry_kernel(float *__restrict__ wsH, const float *__restrict__ wsS,
                                                              const float *__restrict__ A, float a_scale, int nch,
                                                              int N, int D) {
@@ -222,27 +227,71 @@ __global__ __launch_bounds__(64 * SEG) void scan_carry_kernel(float *__restrict_
     const int dblocks = D / 64;
     const int db = blockIdx.x % dblocks, n = (blockIdx.x / dblocks) % N, bk = blockIdx.x / (dblocks * N);
     const int d = db * 64 + lane;
-    const int per = (nch + SEG - 1) / SEG;
+    const int per = (nch + SEG - 1) / SEG;              // <= PER (launcher)
     const int c0 = seg * per, c1 = min(c0 + per, nch);
     const int64_t base = ((int64_t)bk * nch * N + n) * D + d;   // + c*N*D
     const int64_t cs = (int64_t)N * D;
     const float *sd = wsS + (int64_t)bk * nch * D + d;          // + c*D: sum of dt of chunk c
     const float a2 = A[((int64_t)(bk & 3) * D + d) * N + n] * a_scale;
+    if constexpr (PER == 0) {       // segments longer than 8 chunks (small state, N <= 8, or huge images): two passes over
+                                    // the workspace -- 2 x 32 register-held values do not fit a 1024-thread workgroup
+        float P = 1.f, Hh = 0.f;
+        for (int c = c0; c < c1; ++c) {
+            const float p = __builtin_amdgcn_exp2f(a2 * sd[(int64_t)c * D]), hh = wsH[base + c * cs];
+            Hh = p * Hh + hh;
+            P = p * P;
+        }
+        sP[seg][lane] = P;
+        sH[seg][lane] = Hh;
+        __syncthreads();
+        float carry = 0.f;
+        for (int s = 0; s < seg; ++s) carry = sP[s][lane] * carry + sH[s][lane];
+        for (int c = c0; c < c1; ++c) {
+            const float p = __builtin_amdgcn_exp2f(a2 * sd[(int64_t)c * D]), hh = wsH[base + c * cs];
+            wsH[base + c * cs] = carry;
+            carry = p * carry + hh;
+        }
+        return;
+    }
+    constexpr int PR = PER > 0 ? PER : 1;
+    float pv[PR], hv[PR];
+    // running pointers (one live address each): 2 x PER precomputed 64-bit addresses would not fit the
+    // 128 VGPRs of a 1024-thread workgroup
+    const float *ps = sd + (int64_t)c0 * D;
+    float *ph = wsH + base + c0 * cs;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        pv[u] = 0.f;
+        hv[u] = 0.f;
+        if (c0 + u < c1) {                              // wave-uniform
+            pv[u] = *ps;
+            hv[u] = *ph;
+        }
+        ps += D;
+        ph += cs;
+    }
     float P = 1.f, Hh = 0.f;
-    for (int c = c0; c < c1; ++c) {
-        const float p = __builtin_amdgcn_exp2f(a2 * sd[(int64_t)c * D]), hh = wsH[base + c * cs];
-        Hh = p * Hh + hh;
-        P = p * P;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        if (c0 + u < c1) {
+            pv[u] = __builtin_amdgcn_exp2f(a2 * pv[u]);
+            Hh = pv[u] * Hh + hv[u];
+            P = pv[u] * P;
+        }
     }
     sP[seg][lane] = P;
     sH[seg][lane] = Hh;
     __syncthreads();
     float carry = 0.f;
     for (int s = 0; s < seg; ++s) carry = sP[s][lane] * carry + sH[s][lane];
-    for (int c = c0; c < c1; ++c) {
-        const float p = __builtin_amdgcn_exp2f(a2 * sd[(int64_t)c * D]), hh = wsH[base + c * cs];
-        wsH[base + c * cs] = carry;
-        carry = p * carry + hh;
+    ph = wsH + base + c0 * cs;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        if (c0 + u < c1) {
+            *ph = carry;
+            carry = pv[u] * carry + hv[u];
+        }
+        ph += cs;
     }
 }
 
@@ -256,8 +305,14 @@ void launch_scan(const T *xc, const float *xdbl, const float *dtw, const float *
     const size_t lds = (size_t)g.CL * ((g.CD + 3) & ~3) * sizeof(float);
     hipLaunchKernelGGL((scan_chunk_kernel<T, N, R, false>), grid, block, lds, s, xc, xdbl, dtw, dtb, A, Ds, y, wsH, wsP, g);
     if (g.nch > 1)
-        hipLaunchKernelGGL(scan_carry_kernel, dim3(g.B * 4 * g.N * (g.D / 64)), dim3(64 * SEG), 0, s, wsH, wsP, A,
-                           sizeof(T) == 2 ? 1.f : 1.4426950408889634f, g.nch, g.N, g.D);
+    {
+        const int per = (g.nch + SEG - 1) / SEG;
+        const dim3 cgrid(g.B * 4 * g.N * (g.D / 64)), cblock(64 * SEG);
+        const float asc = sizeof(T) == 2 ? 1.f : 1.4426950408889634f;
+        if (per <= 2) hipLaunchKernelGGL(scan_carry_kernel<2>, cgrid, cblock, 0, s, wsH, wsP, A, asc, g.nch, g.N, g.D);
+        else if (per <= 8) hipLaunchKernelGGL(scan_carry_kernel<8>, cgrid, cblock, 0, s, wsH, wsP, A, asc, g.nch, g.N, g.D);
+        else hipLaunchKernelGGL(scan_carry_kernel<0>, cgrid, cblock, 0, s, wsH, wsP, A, asc, g.nch, g.N, g.D);
+    }
     else
         (void)hipMemsetAsync(wsH, 0, half * sizeof(float), s);
     hipLaunchKernelGGL((scan_chunk_kernel<T, N, R, true>), grid, block, lds, s, xc, xdbl, dtw, dtb, A, Ds, y, wsH, wsP, g);
