@@ -434,7 +434,8 @@ extern "C" int fd_dwconv3x3(int dtype, const void *in, int ld_in, int off_in, co
 }
 
 extern "C" int fd_avgpool(int dtype, const void *in, void *out, int B, int H, int W, int C, int k, void *stream) {
-    FD_REQUIRE(C % 8 == 0 && k > 0 && H % k == 0 && W % k == 0, "fd_avgpool: C%%8, H%%k, W%%k must be 0");
+    // floor semantics of nn.AvgPool2d (src/DACLIP.py:169,187,337): a trailing partial window is dropped
+    FD_REQUIRE(C % 8 == 0 && k > 0 && H >= k && W >= k, "fd_avgpool: C%%8 must be 0 and H, W >= k");
     int64_t total = (int64_t)B * (H / k) * (W / k) * (C / 8);
     dim3 grid(grid1d(total)), block(256);
     if (dtype == FD_BF16)

@@ -306,3 +306,30 @@ def test_objective_variants_fp32(golden, name):
     for i, t in enumerate(range(999, 996, -1)):
         img, _ = dif.p_sample(xi, img, t, xc2, noise=g["anc.noise"][i].cuda())
         assert rel_err(img.cpu(), g[name + ".anc.imgs"][i]) < tol, t
+
+
+def test_odd_size_floor_pooling_fp32():
+    """48 x 80: the RN50 tower ends on a 3 x 5 map that its last stride-2 AvgPool2d floors to 1 x 2
+    (nn.AvgPool2d semantics, src/DACLIP.py:187) and no 3x3 conv meets the halo kernel's tiling -- HIP path
+    (fp32 mode) against the CPU oracle on one model_predictions call."""
+    from founddiff_amd import arch, synth
+    from founddiff_amd.DADiff import ResidualDiffusion, UnetRes
+    from oracle import sampler
+    H, W = 48, 80
+    spec = arch.da_unet_spec(32, (1, 2), prefix="model.unet0.", clip=TINY_CLIP)
+    w = synth.synth_state_dict(spec, seed=0)
+    g = torch.Generator().manual_seed(5)
+    x_in = torch.rand(1, 1, H, W, generator=g) * 2 - 1
+    x_t = x_in + 0.1 * torch.randn(1, 1, H, W, generator=g)
+    tt = torch.full((1,), 700, dtype=torch.long)
+    ref = sampler.ResidualOracle(w, prefix="model.unet0.", sampling_timesteps=2).model_predictions(x_in, x_t, tt)
+    net = UnetRes(dim=32, dim_mults=(1, 2), num_unet=1, condition=True, objective="pred_res", test_res_or_noise="res",
+                  precision="fp32", clip_cfg=TINY_CLIP)
+    dif = ResidualDiffusion(net, image_size=H, timesteps=1000, sampling_timesteps=2, objective="pred_res", loss_type="l2",
+                            condition=True, sum_scale=0.01, test_res_or_noise="res")
+    dif.load_state_dict(w, strict=False)
+    dif = dif.to("cuda")
+    dif.init()
+    p = dif.model_predictions(x_in.cuda(), x_t.cuda(), tt.cuda())
+    assert rel_err(p.pred_res.cpu(), ref[0]) < 1e-3
+    assert rel_err(p.pred_x_start.cpu(), ref[2]) < 1e-3
