@@ -283,6 +283,7 @@ class ResidualDiffusion(nn.Module):
         for k, v in residual_schedule(timesteps, after_init=False).items():
             self.register_buffer(k, v)
         self._graph = None
+        self._loop_graph = None
         self._host_sched = None
 
     def init(self):
@@ -292,11 +293,13 @@ class ResidualDiffusion(nn.Module):
             setattr(self, k, v.to(dev))
         self.num_timesteps = 1000
         self._host_sched = None
+        self._loop_graph = None
 
     def load_state_dict(self, state_dict, strict=True, assign=False):
         live = {k: v for k, v in state_dict.items()
                 if not (arch.is_dead_key(k, "model.unet0.") or arch.is_dead_key(k, "model.unet1."))}
         self._graph = None
+        self._loop_graph = None
         return super().load_state_dict(live, strict=strict, assign=assign)
 
     # ---- helpers
@@ -574,15 +577,34 @@ class ResidualDiffusion(nn.Module):
         hs = self._hs()
         acs = hs["alphas_cumsum"]
         img_list = []
-        for time, time_next in time_pairs:
-            time_buf.fill_(float(acs[time] * T))
-            self._step_forward(x_in, img, time_buf, mo)
-            lastf = time_next < 0
-            alpha = 0.0 if lastf else float(acs[time] - acs[time_next])
-            L.call("fd_res_ddim_step", _p(mo), _p(img), _p(x_in), None, alpha, 0.0, int(lastf), _p(img),
-                   img.numel(), _stream(img))
-            if not last:
-                img_list.append(img.clone())
+
+        def run_steps(forward):
+            for time, time_next in time_pairs:
+                time_buf.fill_(float(acs[time] * T))
+                forward()
+                lastf = time_next < 0
+                alpha = 0.0 if lastf else float(acs[time] - acs[time_next])
+                L.call("fd_res_ddim_step", _p(mo), _p(img), _p(x_in), None, alpha, 0.0, int(lastf), _p(img),
+                       img.numel(), _stream(img))
+                if not last:
+                    img_list.append(img.clone())
+
+        if self.use_graph and last and os.environ.get("FOUNDDIFF_LOOP_GRAPH", "1") != "0":
+            # the whole S-step loop as ONE HIP graph (S x (time fill + 141 kernels + DDIM update), every
+            # scheduler constant baked into its node): replayed per sample() on the persistent loop buffers
+            key = ("ddim", tuple(shape), eng.mode, id(eng), S, T)
+            if self._loop_graph is None or self._loop_graph[0] != key:
+                start = img.clone()
+                eng.forward(img, x_in, time_buf, out=mo)          # warm-up: every workspace buffer exists
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    run_steps(lambda: eng.forward(img, x_in, time_buf, out=mo))
+                self._loop_graph = (key, g)
+                img.copy_(start)                                   # capture does not execute: restore x_T
+            self._loop_graph[1].replay()
+        else:
+            run_steps(lambda: self._step_forward(x_in, img, time_buf, mo))
         if not last:
             img_list = [input_add_noise] + img_list
         else:
