@@ -108,6 +108,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
     // before the next ds_read of ANY LDS address, i.e. right after the request -- the opposite of a
     // prefetch.  The counted waits below are therefore manual.  (The compiler's own vmcnt accounting for the
     // register halo loads stays safe: operations it does not know about only make its waits stricter.)
+    // M0 (the DMA's LDS base) is written inside the asm without a clobber -- hipcc rejects "m0" in clobber
+    // lists as a reserved register; nothing else in this kernel uses M0 (gfx9+ ds_* instructions do not, and
+    // there is no dynamic register indexing, GWS or message traffic here).
     const unsigned lds_w = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)smem + HALO_B +
                            __builtin_amdgcn_readfirstlane(wave) * NB * 1024;
     auto w_dma = [&](int slab, int tap, int buf) {
