@@ -528,22 +528,33 @@ __global__ void gn_silu_apply_kernel(const T *__restrict__ h, const float *__res
                                      const float *__restrict__ gamma, const float *__restrict__ beta,
                                      const T *__restrict__ res, T *__restrict__ out, int64_t hw, int C,
                                      int groups, int64_t nvec_per_img) {
+    // A thread's 8-channel vector index advances by gridDim.x*blockDim.x per iteration; both are multiples
+    // of C/8 on the host side, so the channel vector (and with it gamma / beta / the group statistics) is
+    // loop-invariant: scale = rstd*gamma, shift = beta - mean*rstd*gamma are computed ONCE per thread.
+    // (Per element per iteration -- an integer division and four scalar loads each -- this kernel ran
+    // VALU-bound: PMC VALU busy 82 % at 4.2 TB/s.)
     const int b = blockIdx.y;
     const int cpg = C / groups;
     const int vpr = C / 8;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvec_per_img;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        int c0 = (int)(i % vpr) * 8;
+    const int64_t i0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int c0 = (int)(i0 % vpr) * 8;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = c0 + e, g = c / cpg;
+        const float mean = mean_rstd[((int64_t)b * groups + g) * 2];
+        const float rstd = mean_rstd[((int64_t)b * groups + g) * 2 + 1];
+        sc[e] = rstd * gamma[c];
+        sh[e] = beta[c] - mean * sc[e];
+    }
+    for (int64_t i = i0; i < nvec_per_img; i += (int64_t)gridDim.x * blockDim.x) {
         int64_t off = (int64_t)b * hw * C + i * 8;
         float hv[8], rv[8], o[8];
         load8(h + off, hv);
         if (res) load8(res + off, rv);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            int c = c0 + e, g = c / cpg;
-            float mean = mean_rstd[((int64_t)b * groups + g) * 2];
-            float rstd = mean_rstd[((int64_t)b * groups + g) * 2 + 1];
-            float y = fd_silu((hv[e] - mean) * rstd * gamma[c] + beta[c]);
+            float y = fd_silu(hv[e] * sc[e] + sh[e]);
             o[e] = res ? y + rv[e] : y;
         }
         store8(out + off, o);
@@ -666,7 +677,16 @@ extern "C" int fd_gn_silu_apply(int dtype, const void *h, const float *mean_rstd
                                 int C, int groups, void *stream) {
     FD_REQUIRE(C % 8 == 0 && C % groups == 0, "fd_gn_silu_apply: C=%d must be a multiple of 8 and of groups", C);
     int64_t nvec = hw * C / 8;
-    dim3 grid((unsigned)((nvec + 255) / 256 > 2048 ? 2048 : (nvec + 255) / 256), B), block(256);
+    // grid stride (gridDim.x * 256 threads) must be a multiple of the vectors per pixel row (C/8) so that a
+    // thread keeps its channel vector: round the block count to a multiple of C/8 / gcd(C/8, 256)
+    const int vpr = C / 8;
+    int gcd = vpr, t = 256;
+    while (t) { int r = gcd % t; gcd = t; t = r; }
+    const int step = vpr / gcd;
+    int64_t nb = (nvec + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    nb = (nb + step - 1) / step * step;
+    dim3 grid((unsigned)nb, B), block(256);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == FD_BF16)
         hipLaunchKernelGGL(gn_silu_apply_kernel<bf16>, grid, block, 0, s, (const bf16 *)h, mean_rstd, gamma, beta,
