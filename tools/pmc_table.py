@@ -46,5 +46,5 @@ for k, c in ctr.items():
 rows.sort(reverse=True)
 print("| kernel | launches | avg us | waves/SIMD | VALU busy | MFMA busy | wave time parked | LDS active | LDS conflict share |")
 print("|---|---|---|---|---|---|---|---|---|")
-for _, k, n, us, occ, valu, mfma, wait, ldsc, ldsa in rows[:24]:
+for _, k, n, us, occ, valu, mfma, wait, ldsc, ldsa in rows[:int(__import__("os").environ.get("PMC_ROWS", "24"))]:
     print(f"| `{k[:64]}` | {n} | {us:.1f} | {occ:.1f} | {valu:.0%} | {mfma:.0%} | {wait:.0%} | {ldsa:.0%} | {ldsc:.0%} |")
