@@ -56,6 +56,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const fd_conv_
     constexpr int AR = BM / RPL, NB = BN / RPL;
     constexpr int TMW = BM / WM, TNW = BN / WN;
     constexpr int MT = TMW / 16, NT = TNW / 16;
+    constexpr bool PWE = PW && (NT % 2 == 0);     // transposed issue + direct epilogue need pairs of 16-channel tiles
     constexpr int CH = TT<T>::CH;
     constexpr int BK = ROWB / (int)sizeof(T);
     constexpr int AB_BYTES = 2 * (BM + BN) * ROWB;
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const fd_conv_
             int r = rbase + RPL * i;
             // PW: channel c of a 32-channel group sits at row (c&4 ? 16 : 0) + 4*(c>>3) + (c&3), so that the
             // transposed MFMA below leaves 8 CONSECUTIVE channels of one pixel in a lane (fd_gemm_rows.hip)
-            if constexpr (PW) r = (r & ~31) | ((r & 4) << 2) | (((r & 31) >> 3) << 2) | (r & 3);
+            if constexpr (PWE) r = (r & ~31) | ((r & 4) << 2) | (((r & 31) >> 3) << 2) | (r & 3);
             *(u32x4 *)(sB + r * ROWB + swz(r, chunk)) = rb[i];
         }
     };
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const fd_conv_
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
-                        acc[i][j] = PW ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0)
+                        acc[i][j] = PWE ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0)
                                        : __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
             } else {
                 // f32: lane group fg owns k = 8*fg .. 8*fg+7 of the 32-wide step; MFMA step e
@@ -274,11 +275,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const fd_conv_
         __syncthreads();
     }
 
-    if constexpr (PW) {
+    if constexpr (PWE) {
         // ---- pointwise epilogue straight from the accumulators (D^T: lane = pixel fr, 4 channels per tile,
         // two permuted tiles = 8 consecutive channels): no LDS staging, no barrier.  The dispatcher only
         // selects PW when Cout, strides and offsets are multiples of 8 and no GroupNorm sums are wanted.
-        static_assert(NT % 2 == 0, "pointwise epilogue pairs 16-channel tiles");
         const int64_t obase_pw = 0;
         (void)obase_pw;
         const int cpg = p.gn_groups > 0 ? p.Cout / p.gn_groups : 1;
@@ -571,7 +571,7 @@ int fd_conv3x3_ok(const fd_conv_params &p);
 int fd_conv3x3_launch(const fd_conv_params &p, hipStream_t s);
 
 // Which kernel fd_conv2d dispatches `p` to: 10 streaming row-GEMM, 11 halo-tiled 3x3, else the
-// implicit-GEMM tile variant 0 <128,128>, 1 <128,64>, 2 <64,128>, 3 <64,64>, 4 <128,256>, 5 <256,256> (BM, BN).
+// implicit-GEMM tile variant 0 <128,128>, 1 <128,64>, 2 <64,128>, 3 <64,64>, 4 <128,256>, 5 <256,256>, 6 <128,32> (BM, BN).
 extern "C" int fd_conv_kernel_id(const fd_conv_params *pp) {
     if (fd_conv_prologue_ok(pp)) return 10;
     if (fd_conv3x3_ok(*pp)) return 11;
@@ -594,6 +594,9 @@ extern "C" int fd_conv_kernel_id(const fd_conv_params *pp) {
         const int64_t wgs = (int64_t)pp->B * pp->ndir * cdiv((int64_t)pp->OH * pp->OW, 128) * cdiv(pp->Cout, 256);
         if (wgs >= 192 || getenv("FD_CONV_BIG_TILE")) return 4;
     }
+    // very narrow outputs (x_proj: Cout = dt_rank + 2 d_state = 12..40 at the high-resolution levels): a
+    // 32-column tile halves the wasted B-side work of the 64-column one and fits more workgroups per CU
+    if (tall && pp->Cout <= 32) return 6;
     return (tall ? 0 : 2) + (wide ? 0 : 1);
 }
 
@@ -630,8 +633,8 @@ extern "C" int fd_conv2d(const fd_conv_params *pp, void *stream) {
     FD_REQUIRE((int64_t)p.H * p.W * (p.ld0 > p.ld1 ? p.ld0 : p.ld1) < (1ll << 31),
                "fd_conv2d: one image of a source must hold < 2^31 elements");
     const int kid = fd_conv_kernel_id(pp);
-    const int BMs[6] = {128, 128, 64, 64, 128, 256}, BNs[6] = {128, 64, 128, 64, 256, 256};
-    dim3 grid(cdiv((int64_t)p.OH * p.OW, BMs[kid]), cdiv(p.Cout, BNs[kid]), p.B * p.ndir), block(kid >= 4 ? 512 : 256);
+    const int BMs[7] = {128, 128, 64, 64, 128, 256, 128}, BNs[7] = {128, 64, 128, 64, 256, 256, 32};
+    dim3 grid(cdiv((int64_t)p.OH * p.OW, BMs[kid]), cdiv(p.Cout, BNs[kid]), p.B * p.ndir), block(kid == 4 || kid == 5 ? 512 : 256);
     hipStream_t s = (hipStream_t)stream;
     // pointwise fast path (bf16): same tiles, same K order, same results -- only the address math differs
     const bool pw = p.dtype == FD_BF16 && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad_h == 0 && p.pad_w == 0 &&
@@ -651,6 +654,7 @@ extern "C" int fd_conv2d(const fd_conv_params *pp, void *stream) {
     case 2: FD_CONV_LAUNCH(T_, 64, 128, 2, 2, PW_); break;            \
     case 3: FD_CONV_LAUNCH(T_, 64, 64, 2, 2, PW_); break;             \
     case 5: FD_CONV_LAUNCH(T_, 256, 256, 4, 2, PW_); break;           \
+    case 6: FD_CONV_LAUNCH(T_, 128, 32, 2, 2, PW_); break;            \
     default: FD_CONV_LAUNCH(T_, 128, 256, 2, 4, PW_); break;          \
     }
     if (p.dtype == FD_BF16) {

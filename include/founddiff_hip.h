@@ -106,8 +106,8 @@ typedef struct fd_conv_params {
 int fd_conv_prologue_ok(const fd_conv_params *p);
 
 int fd_conv_mtiles(int OH, int OW);         /* number of m-tiles per image (for workspaces)  */
-/* kernel fd_conv2d will run for p: 10 row-GEMM, 11 halo 3x3, 0..5 implicit-GEMM <BM,BN> =
- * <128,128>, <128,64>, <64,128>, <64,64>, <128,256>, <256,256> (profiling / roofline
+/* kernel fd_conv2d will run for p: 10 row-GEMM, 11 halo 3x3, 0..6 implicit-GEMM <BM,BN> =
+ * <128,128>, <128,64>, <64,128>, <64,64>, <128,256>, <256,256>, <128,32> (profiling / roofline
  * bookkeeping; ids 4 and 5 depend on the batch size but give bitwise identical outputs)      */
 int fd_conv_kernel_id(const fd_conv_params *p);
 int fd_conv2d(const fd_conv_params *p, void *stream);
