@@ -460,6 +460,14 @@ def test_conv3x3_halo(eng_factory, cfg):
     s = part.sum(1).cpu()
     assert rel_err(s[..., 0], ref.sum((2, 3))) < 5e-3
     assert rel_err(s[..., 1], (ref ** 2).sum((2, 3))) < 5e-3
+    # the weight ring's s_waitcnt bookkeeping is manual: a tile read before its DMA landed would show up as
+    # run-to-run differences -- 16 more launches must reproduce the first one bit for bit
+    first, first_part = out.clone(), part.clone()
+    for _ in range(16):
+        out.zero_()
+        e.conv(cw, xa, B, H, W, out, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(out, first) and torch.equal(part, first_part)
 
 
 @pytest.mark.parametrize("cfg", [dict(cdw=128, cz=128, silu=1, bias=True, affine=True, hw=(128, 256)),     # SS2D in_proj + conv2d
