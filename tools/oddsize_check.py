@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT)
 import torch
 import bench
 from founddiff_amd import synth
-for (H, W) in ((144, 176), (256, 256), (208, 512), (512, 128)):
+for (H, W) in ((144, 176), (256, 256), (208, 512), (512, 128), (512, 512), (384, 384)):
     outs = {}
     for prec in ("fp32", "bf16"):
         dif, w = bench.build_model(torch.device("cuda"), size=H, steps=50, precision=prec)
