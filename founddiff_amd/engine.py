@@ -107,6 +107,8 @@ class DAEngine:
             return None
         p = torch.zeros(co, 7, 8, 4, dtype=torch.float32)
         p[:, :, :7, :c] = w.detach().float().permute(0, 2, 3, 1)
+        if c <= 2:      # free slots 2, 3 take the rounding residuals of planes 0, 1 (fd_init_conv7)
+            p[:, :, :7, 2:2 + c] = p[:, :, :7, :c]
         return p.reshape(co, 224).contiguous().to(self.dev, torch.bfloat16)
 
     @staticmethod

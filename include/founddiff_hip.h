@@ -212,7 +212,9 @@ int fd_pack_planes(int dtype, const float *p0, const float *p1, void *out, int B
  *   (src/DADiff.py:558, 704) -- bf16 mode, Cout in {32, 64}, H and W multiples of 16
  *   (fd_init_conv7_ok; otherwise fd_pack_planes3 + fd_conv2d).
  *   p0, p1, p2: [B,H,W] fp32 planes (x_t, x_input, x_input_condition; p1 / p2 may be NULL)
- *   w_packed: bf16 [Cout][7 kh][8 kw][4 c], zero where kw = 7 or c >= number of planes
+ *   w_packed: bf16 [Cout][7 kh][8 kw][4 c], zero where kw = 7 or c >= number of planes -- except
+ *             that with p2 == NULL slots c = 2, 3 must repeat the weights of planes 0, 1: the kernel
+ *             feeds them the bf16 rounding residuals of the two planes (hi + lo split)
  *   out: [B,H,W,Cout] bf16                                                                    */
 int fd_init_conv7_ok(int dtype, int Cout, int H, int W);
 int fd_init_conv7(int dtype, const float *p0, const float *p1, const float *p2, const void *w_packed,

@@ -529,7 +529,8 @@ def test_init_conv7(eng_factory, cfg):
     x = torch.randn(B, c, H, W)
     w = torch.randn(co, c, 7, 7) / (7 * c ** 0.5)
     bias = torch.randn(co)
-    ref = F.conv2d(rq(x, "bf16"), rq(w, "bf16"), bias, padding=3)
+    # with <= 2 planes the kernel carries the planes as bf16 hi + lo pairs: the image is NOT rounded to bf16
+    ref = F.conv2d(x if c <= 2 else rq(x, "bf16"), rq(w, "bf16"), bias, padding=3)
     assert L.lib().fd_init_conv7_ok(L.FD_BF16, co, H, W)
     wp = e._pack_init7(w)
     planes = [x[:, i].contiguous().cuda() for i in range(c)] + [None] * (3 - c)
@@ -538,5 +539,5 @@ def test_init_conv7(eng_factory, cfg):
     L.call("fd_init_conv7", L.FD_BF16, *[None if p is None else p.data_ptr() for p in planes], wp.data_ptr(),
            bd.data_ptr(), out.data_ptr(), B, H, W, co, None)
     torch.cuda.synchronize()
-    assert rel_err(nchw(out), ref) < 6e-3
-    assert rel_err(nchw(out)[:, :, :3], ref[:, :, :3]) < 8e-3 and rel_err(nchw(out)[..., -3:], ref[..., -3:]) < 8e-3
+    assert rel_err(nchw(out), ref) < 4e-3          # output rounding to bf16 only
+    assert rel_err(nchw(out)[:, :, :3], ref[:, :, :3]) < 6e-3 and rel_err(nchw(out)[..., -3:], ref[..., -3:]) < 6e-3
