@@ -31,14 +31,14 @@ ALG_GFLOP_PER_FORWARD = 575.5  # SURVEY.md section 8(d), 512x512, B=1
 
 def build_model(device, size=SIZE, steps=S_DDIM, precision="bf16", seed=0):
     from founddiff_amd import arch, synth
-    from founddiff_amd.DADiff import ResidualDiffusion, UnetRes
+    from founddiff_amd.DADiff import ResidualDiffusion, UnetRes, load_weights
     spec = arch.da_unet_spec(DIM, MULTS, prefix="model.unet0.")
     w = synth.synth_state_dict(spec, seed=seed)
     net = UnetRes(dim=DIM, dim_mults=MULTS, num_unet=1, condition=True, objective="pred_res",
                   test_res_or_noise="res", precision=precision)
     dif = ResidualDiffusion(net, image_size=size, timesteps=1000, sampling_timesteps=steps, objective="pred_res",
                             loss_type="l2", condition=True, sum_scale=0.01, test_res_or_noise="res")
-    dif.load_state_dict(w, strict=False)
+    load_weights(dif, w, "synthetic weights")
     dif = dif.to(device)
     dif.init()
     return dif, w
@@ -130,9 +130,10 @@ def roofline_leg(dif, x, noise):
     return res
 
 
-def cpu_baseline_leg(w, x_in01, noise):
-    """CPU oracle (PyTorch-CPU + C/OpenMP scan) on the host cores: DA-CLIP encode + ONE of the 50
-    UNet forwards of one 512x512 slice, extrapolated x50."""
+def cpu_baseline_leg(w, x_in01, noise, n_forwards=3):
+    """CPU oracle (PyTorch-CPU + C/OpenMP scan) on the host cores: DA-CLIP encode + `n_forwards` of the 50
+    UNet forwards of one 512x512 slice (three different timesteps), extrapolated to 50 (BASELINE.md section 3:
+    >= 3 steps at config 3)."""
     from oracle import nets, sampler
     # 32 threads: on the 256-core GPU box PyTorch-CPU is SLOWER with all cores (oversubscribed
     # intra-op pools: 134 s for the same sample at 256 threads); `cores` reports what was used
@@ -145,12 +146,51 @@ def cpu_baseline_leg(w, x_in01, noise):
     t0 = time.time()
     orc._cond = nets.da_unet_cond(orc.sd, xi)
     t1 = time.time()
-    orc.unet(xt, xi, torch.full((1,), 999, dtype=torch.long))
-    t2 = time.time()
-    per_slice = (t1 - t0) + S_DDIM * (t2 - t1)
+    per_fwd = []
+    for t in (999, 499, 19)[:n_forwards]:
+        ts = time.time()
+        orc.unet(xt, xi, torch.full((1,), t, dtype=torch.long))
+        per_fwd.append(time.time() - ts)
+    fwd = sum(per_fwd) / len(per_fwd)
+    per_slice = (t1 - t0) + S_DDIM * fwd
     return {"value": round(1.0 / per_slice, 6), "unit": "slices/s", "cores": nthr, "kind": "port",
-            "sample": f"1 slice: DA-CLIP encode ({t1 - t0:.1f}s) + 1 of {S_DDIM} UNet forwards ({t2 - t1:.1f}s) "
-                      f"at 512x512 fp32, extrapolated x{S_DDIM}"}
+            "sample": f"1 slice: DA-CLIP encode ({t1 - t0:.1f}s) + {len(per_fwd)} of {S_DDIM} UNet forwards "
+                      f"({', '.join('%.1f' % v for v in per_fwd)} s) at 512x512 fp32, extrapolated to {S_DDIM}"}
+
+
+def fp32_parity_leg(dev, x, noise, steps=1):
+    """Throughput of the fp32 parity mode (the mode that carries the 1e-3 gate against the CPU reference) on the
+    same workload, outside the timed region: `steps` complete 50-step sample() calls of the same batch."""
+    dif, _ = build_model(dev, precision="fp32")
+    B = x.shape[0]
+    dif.sample([x], batch_size=B, noise=noise)          # warm-up: workspaces + graph capture
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        dif.sample([x], batch_size=B, noise=noise)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    del dif
+    torch.cuda.empty_cache()
+    return {"value": round(B / dt, 4), "unit": "slices/s", "ms_per_step": round(dt * 1e3, 2),
+            "ms_per_unet_forward_per_slice": round(dt / S_DDIM / B * 1e3, 3), "steps": steps, "batch": B,
+            "dtype": "f32 storage, exact-f32 MFMA"}
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` from a bare shell: start the N ranks as a CHILD torch.distributed.run (this
+    process never touches a GPU), relay its output and exit with its code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
 def main():
@@ -161,13 +201,16 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="slices per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-fp32-leg", action="store_true")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "RANK" not in os.environ and (a.gpus > 1 or os.environ.get("FOUNDDIFF_BENCH_FORCE_LAUNCH") == "1"):
+        self_launch(a)
     if a.gpus > 1 and world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -223,6 +266,8 @@ def main():
         }
         if not a.no_roofline:
             res["roofline"] = roofline_leg(dif, x, noise)
+        if world == 1 and not a.no_fp32_leg:
+            res["fp32_parity_mode"] = fp32_parity_leg(dev, x, noise)
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline_leg(w, x, noise)
         print(json.dumps(res), flush=True)

@@ -128,15 +128,25 @@ class Unet(_ParamTree):
         self._engine = None
         return super()._load_from_state_dict(*a, **k)
 
+    def _apply(self, fn, *a, **k):
+        # .to(device) / .cuda() / dtype casts move the parameters: the packed weights of the engine are stale
+        self._engine = None
+        return super()._apply(fn, *a, **k)
+
     def engine(self, precision=None):
+        """The packed-weight HIP engine of this UNet for `precision` (default: self.precision); one per
+        precision is kept (the samplers run their last step(s) on the fp32 engine, see ResidualDiffusion)."""
         prec = precision or self.precision
-        if self._engine is None or self._engine.mode != prec:
+        if self._engine is None:
+            self._engine = {}
+        eng = self._engine.get(prec)
+        if eng is None:
             dev = next(self.parameters()).device
             if dev.type != "cuda":
                 raise L.FoundDiffHipError("founddiff_amd runs on MI355X only: move the model to a ROCm device "
                                           "(`.to('cuda')`); there is no CPU path")
-            self._engine = DAEngine(self.state_dict(), "", dev, prec)
-        return self._engine
+            eng = self._engine[prec] = DAEngine(self.state_dict(), "", dev, prec)
+        return eng
 
     @torch.no_grad()
     def encode_condition(self, x_cond):
@@ -238,6 +248,22 @@ def residual_schedule(timesteps=1000, after_init=False):
     return {k: v.to(torch.float32) for k, v in out.items()}
 
 
+def load_weights(module, state_dict, what="checkpoint"):
+    """`load_state_dict` the way the reference's strict `Trainer.load` does (src/DADiff.py:1655-1663) for every
+    key that is live on the sampling path: dead weight is dropped by the modules' own `load_state_dict`, the
+    12 schedule buffers may be absent (they are re-derived by `init()`), anything else missing or unexpected
+    raises -- a checkpoint of another dim / dim_mults / num_unet / input_condition must not leave zero-
+    initialised weights behind silently."""
+    res = module.load_state_dict(state_dict, strict=False)
+    sched = set(residual_schedule(1000).keys())
+    missing = [k for k in res.missing_keys if k not in sched]
+    unexpected = list(res.unexpected_keys)
+    if missing or unexpected:
+        raise RuntimeError(f"{what} does not match this model: {len(missing)} live keys missing "
+                           f"(e.g. {missing[:3]}), {len(unexpected)} unexpected (e.g. {unexpected[:3]})")
+    return res
+
+
 class ResidualDiffusion(nn.Module):
     """Residual (RDDM-style) diffusion sampler, reference src/DADiff.py:908-1380.
 
@@ -249,7 +275,7 @@ class ResidualDiffusion(nn.Module):
     def __init__(self, model, *, image_size, timesteps=1000, sampling_timesteps=None, loss_type="l1",
                  objective="pred_res_noise", ddim_sampling_eta=0., condition=False, sum_scale=None,
                  input_condition=False, input_condition_mask=False, test_res_or_noise="None",
-                 use_graph=True):
+                 use_graph=True, final_fp32_steps=None):
         super().__init__()
         assert not (type(self) == ResidualDiffusion and model.channels != model.out_dim)
         assert not model.random_or_learned_sinusoidal_cond
@@ -280,9 +306,16 @@ class ResidualDiffusion(nn.Module):
         self.is_ddim_sampling = self.sampling_timesteps < timesteps
         self.ddim_sampling_eta = ddim_sampling_eta
         self.use_graph = use_graph
+        # precision schedule of the bf16 mode: the last `final_fp32_steps` UNet forwards of a sampling loop run
+        # on the fp32 (parity-mode) engine.  The returned image is clamp(x_input - pred_res) of the LAST forward
+        # (src/DADiff.py:1317-1318, 1206), so its rounding error reaches the output undamped while the earlier
+        # steps' errors only enter through x_t, weighted by their alpha increments.
+        if final_fp32_steps is None:
+            final_fp32_steps = int(os.environ.get("FOUNDDIFF_FINAL_FP32_STEPS", "0"))
+        self.final_fp32_steps = int(final_fp32_steps)
         for k, v in residual_schedule(timesteps, after_init=False).items():
             self.register_buffer(k, v)
-        self._graph = None
+        self._graph = {}
         self._loop_graph = None
         self._host_sched = None
 
@@ -298,7 +331,7 @@ class ResidualDiffusion(nn.Module):
     def load_state_dict(self, state_dict, strict=True, assign=False):
         live = {k: v for k, v in state_dict.items()
                 if not (arch.is_dead_key(k, "model.unet0.") or arch.is_dead_key(k, "model.unet1."))}
-        self._graph = None
+        self._graph = {}
         self._loop_graph = None
         return super().load_state_dict(live, strict=strict, assign=assign)
 
@@ -478,21 +511,33 @@ class ResidualDiffusion(nn.Module):
         return pred_img, x_start
 
     # ---- the per-step hot loop: graph-captured UNet forward + one scheduler kernel
-    def _step_forward(self, x_in, img, time_buf, mo):
-        eng = self._eng()
-        key = (tuple(img.shape), eng.mode, id(eng))
+    def _tail_engine(self, eng):
+        """(K, fp32 engine or None): the engine of the last K steps of a loop (final_fp32_steps)."""
+        K = self.final_fp32_steps if eng.mode != "fp32" else 0
+        if K <= 0:
+            return 0, None
+        e32 = self.model.unet0.engine("fp32")
+        e32.share_condition(eng)
+        return K, e32
+
+    def _step_forward(self, x_in, img, time_buf, mo, eng=None):
+        eng = eng or self._eng()
+        key = (tuple(img.shape), eng.mode, eng.gen)
         if not self.use_graph:
             eng.forward(img, x_in, time_buf, out=mo)
             return
-        if self._graph is None or self._graph[0] != key:
+        ent = self._graph.get(key)
+        if ent is None:
             # warm-up (allocates every workspace buffer), then capture
             eng.forward(img, x_in, time_buf, out=mo)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 eng.forward(img, x_in, time_buf, out=mo)
-            self._graph = (key, g, (x_in, img, time_buf, mo))
-        _, g, (gx, gi, gt, gm) = self._graph
+            for k in [k for k in self._graph if k[1] == eng.mode]:     # one graph per engine mode
+                del self._graph[k]
+            ent = self._graph[key] = (g, (x_in, img, time_buf, mo))
+        g, (gx, gi, gt, gm) = ent
         if gx.data_ptr() != x_in.data_ptr():
             gx.copy_(x_in)
         if gi.data_ptr() != img.data_ptr():
@@ -537,9 +582,10 @@ class ResidualDiffusion(nn.Module):
                              hs["posterior_log_variance_clipped"]], 1).to(x_in.device)      # (T,4)
         times = (hs["alphas_cumsum"] * T).float().to(x_in.device)
         img_list = []
+        K, e32 = self._tail_engine(eng)
         for t in reversed(range(0, T)):
             time_buf.fill_(float(times[t]))
-            self._step_forward(x_in, img, time_buf, mo)
+            self._step_forward(x_in, img, time_buf, mo, e32 if t < K else eng)
             coef = coefs[t:t + 1].expand(B, 4).contiguous()
             nz = None
             if t > 0:
@@ -578,10 +624,12 @@ class ResidualDiffusion(nn.Module):
         acs = hs["alphas_cumsum"]
         img_list = []
 
+        K, e32 = self._tail_engine(eng)
+
         def run_steps(forward):
-            for time, time_next in time_pairs:
+            for i, (time, time_next) in enumerate(time_pairs):
                 time_buf.fill_(float(acs[time] * T))
-                forward()
+                forward(e32 if i >= S - K else eng)
                 lastf = time_next < 0
                 alpha = 0.0 if lastf else float(acs[time] - acs[time_next])
                 L.call("fd_res_ddim_step", _p(mo), _p(img), _p(x_in), None, alpha, 0.0, int(lastf), _p(img),
@@ -592,19 +640,21 @@ class ResidualDiffusion(nn.Module):
         if self.use_graph and last and os.environ.get("FOUNDDIFF_LOOP_GRAPH", "1") != "0":
             # the whole S-step loop as ONE HIP graph (S x (time fill + 141 kernels + DDIM update), every
             # scheduler constant baked into its node): replayed per sample() on the persistent loop buffers
-            key = ("ddim", tuple(shape), eng.mode, id(eng), S, T)
+            key = ("ddim", tuple(shape), eng.mode, eng.gen, S, T, K, e32.gen if e32 else 0)
             if self._loop_graph is None or self._loop_graph[0] != key:
                 start = img.clone()
-                eng.forward(img, x_in, time_buf, out=mo)          # warm-up: every workspace buffer exists
+                for e in (eng, e32):
+                    if e is not None:
+                        e.forward(img, x_in, time_buf, out=mo)    # warm-up: every workspace buffer exists
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
-                    run_steps(lambda: eng.forward(img, x_in, time_buf, out=mo))
+                    run_steps(lambda e: e.forward(img, x_in, time_buf, out=mo))
                 self._loop_graph = (key, g)
                 img.copy_(start)                                   # capture does not execute: restore x_T
             self._loop_graph[1].replay()
         else:
-            run_steps(lambda: self._step_forward(x_in, img, time_buf, mo))
+            run_steps(lambda e: self._step_forward(x_in, img, time_buf, mo, e))
         if not last:
             img_list = [input_add_noise] + img_list
         else:
@@ -686,9 +736,11 @@ class _EMAView:
         self.ema_model.to(device)
         return self
 
-    def load_state_dict(self, sd, strict=False):
+    def load_state_dict(self, sd, strict=True):
         live = {k[len("ema_model."):]: v for k, v in sd.items() if k.startswith("ema_model.")}
-        return self.ema_model.load_state_dict(live, strict=strict)
+        if strict:
+            return load_weights(self.ema_model, live, "ema state")
+        return self.ema_model.load_state_dict(live, strict=False)
 
 
 class Trainer(object):
@@ -735,13 +787,13 @@ class Trainer(object):
         if not path.exists():
             return
         data = torch.load(str(path), map_location="cpu", weights_only=False)
-        self.model.load_state_dict(data["model"], strict=False)
+        load_weights(self.model, data["model"], f"{path}['model']")
         self.step = data.get("step", 0)
         ema = data.get("ema")
         if ema:
             live = {k[len("ema_model."):]: v for k, v in ema.items() if k.startswith("ema_model.")}
             if live:
-                self.model.load_state_dict(live, strict=False)
+                load_weights(self.model, live, f"{path}['ema']")
         self.model.to(self.device)
         print("load model - " + str(path))
 

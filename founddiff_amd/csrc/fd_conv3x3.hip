@@ -108,9 +108,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
     // before the next ds_read of ANY LDS address, i.e. right after the request -- the opposite of a
     // prefetch.  The counted waits below are therefore manual.  (The compiler's own vmcnt accounting for the
     // register halo loads stays safe: operations it does not know about only make its waits stricter.)
-    // M0 (the DMA's LDS base) is written inside the asm without a clobber -- hipcc rejects "m0" in clobber
-    // lists as a reserved register; nothing else in this kernel uses M0 (gfx9+ ds_* instructions do not, and
-    // there is no dynamic register indexing, GWS or message traffic here).
+    // M0 (the DMA's LDS base) is written inside the asm -- hipcc rejects "m0" in clobber lists as a reserved
+    // register, so each request saves and restores it.  The counted waits (FD_WAIT_VM below) assume exactly NB
+    // DMA instructions per wave and tap and HL register halo loads per wave and slab.
     const unsigned lds_w = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)smem + HALO_B +
                            __builtin_amdgcn_readfirstlane(wave) * NB * 1024;
     auto w_dma = [&](int slab, int tap, int buf) {
@@ -118,8 +118,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const unsigned dst = lds_w + buf * WT_B + i * 1024;       // wave-uniform: M0
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                         : : "s"(dst), "v"(goff[i]), "s"(wb) : "memory");
+            // M0 is saved and restored around the request, so the compiler may keep its own value live in it
+            // (a future dynamic-indexing / readlane use) -- hipcc does not accept "m0" as a clobber
+            unsigned m0_saved;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\t"
+                         "s_mov_b32 m0, %0"
+                         : "=&s"(m0_saved) : "s"(dst), "v"(goff[i]), "s"(wb) : "memory");
         }
     };
     // s_waitcnt vmcnt(n) alone (expcnt / lgkmcnt left at their maxima); gfx9 encoding

@@ -12,7 +12,9 @@ constexpr int MH = MT + 2 * MR; // halo tile
 __device__ __forceinline__ int reflect(int i, int n) {
     if (i < 0) i = -i;
     if (i >= n) i = 2 * n - 2 - i;
-    return i;
+    // halo positions of tiles that hang over a small image (n < 11) can reflect twice: they only feed
+    // masked-out outputs, but the load must stay inside the buffer
+    return min(max(i, 0), n - 1);
 }
 
 __global__ __launch_bounds__(256) void metrics_partial_kernel(const float *__restrict__ pred,

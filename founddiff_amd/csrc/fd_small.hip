@@ -129,9 +129,11 @@ __global__ void res_predictions_kernel(const float *__restrict__ mo, const float
     }
 }
 
-__global__ void res_ddim_kernel(const float *__restrict__ mo, const float *__restrict__ img,
+// img / out (and xt / out below) may be the SAME buffer -- the samplers update the image in place -- so
+// neither carries __restrict__; every thread reads index i before it writes index i.
+__global__ void res_ddim_kernel(const float *__restrict__ mo, const float *img,
                                 const float *__restrict__ xin, const float *__restrict__ noise, float alpha,
-                                float sigma, int last, float *__restrict__ out, int64_t n) {
+                                float sigma, int last, float *out, int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float pr = clamp1(mo[i]);
         float v;
@@ -144,9 +146,9 @@ __global__ void res_ddim_kernel(const float *__restrict__ mo, const float *__res
     }
 }
 
-__global__ void res_posterior_kernel(const float *__restrict__ mo, const float *__restrict__ xt,
+__global__ void res_posterior_kernel(const float *__restrict__ mo, const float *xt,
                                      const float *__restrict__ xin, const float *__restrict__ noise,
-                                     const float *__restrict__ coef, float *__restrict__ out,
+                                     const float *__restrict__ coef, float *out,
                                      float *__restrict__ xs_out, int64_t npix) {
     const int b = blockIdx.y;
     const float c1 = coef[b * 4], c2 = coef[b * 4 + 1], c3 = coef[b * 4 + 2];
@@ -169,7 +171,7 @@ __global__ void res_posterior_kernel(const float *__restrict__ mo, const float *
 // step 0: predictions only; 1: DDIM update img - k0*pred_res + k1*noise, or x_start when flag != 0
 // (1317-1318, 1344); 2: posterior k0 x_t + k1 pred_res + k2 x_start + exp(k3/2) noise (1142-1151, 1226-1229).
 __global__ void res_step_obj_kernel(int mode, int step, const float *__restrict__ o0, const float *__restrict__ o1,
-                                    const float *__restrict__ xt, const float *__restrict__ xin,
+                                    const float *xt, const float *__restrict__ xin,
                                     const float *__restrict__ noise, const float *__restrict__ par, float *pred_res,
                                     float *pred_noise, float *x_start, float *img_out, int64_t npix) {
     const int b = blockIdx.y;

@@ -70,9 +70,13 @@ class _Sub:
 
 class DAEngine:
     """DA-conditioned U-Net denoiser (reference `Unet`, src/DADiff.py:530-740) on HIP kernels."""
+    _GEN = 0        # every engine gets a unique generation number: captured HIP graphs are keyed on it
+    probe = None    # development hook: probe(tag, tensor) after each stage (tools/drift_table.py, stage_times.py)
 
     def __init__(self, state_dict, prefix="", device="cuda", mode="bf16"):
         L.lib()  # fail loudly if the HIP library is missing
+        DAEngine._GEN += 1
+        self.gen = DAEngine._GEN
         if mode not in _T:
             raise ValueError(f"mode must be 'fp32' or 'bf16', got {mode!r}")
         self.mode = mode
@@ -245,6 +249,10 @@ class DAEngine:
             self.buf[key] = t
         return t
 
+    def _pr(self, tag, t):
+        if self.probe is not None:
+            self.probe(tag, t)
+
     @property
     def stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
@@ -326,6 +334,7 @@ class DAEngine:
         part = self._b("gn_part", (B, mt, Co, 2), torch.float32)
         mr = self._b("gn_mr", (B, 8, 2), torch.float32)
         self.conv(cw, in0, B, H, W, hraw, c0=c0, in1=in1, c1=c1, stats=part)
+        self._pr(tag + ".conv3", hraw)
         L.call("fd_gn_finalize", _p(part), B, mt, Co, 8, hw, 1e-5, _p(mr), self.stream)
         out = self._b(tag, (B, H, W, Co))
         if r["res"] is not None:
@@ -335,6 +344,7 @@ class DAEngine:
             assert in1 is None
             L.call("fd_gn_silu_apply", self.dt, _p(hraw), _p(mr), _p(r["gamma"]), _p(r["beta"]), _p(in0), _p(out),
                    B, hw, Co, 8, self.stream)
+        self._pr(tag, out)
         return out
 
     def mamba_block(self, m, x, B, H, W, tag):
@@ -371,16 +381,20 @@ class DAEngine:
         if not fused:
             L.call("fd_dwconv3x3", self.dt, _p(xz), 2 * D, 0, _p(m["dw_w"]), _p(m["dw_b"]), 1, _p(xc), D, 0,
                    B, H, W, D, s)
+        self._pr(tag + ".xc", xc)
+        self._pr(tag + ".z", xz[..., D:])
         Lq = (H // 2) * (W // 2)
         xdbl = self._b("xdbl", (4, B, Lq, CD), torch.float32)
         self.conv(None, xc, B, H, W, xdbl, c0=D, weight=m["x_proj"], bias=None, Cout=CD, KH=1, KW=1, stride=2,
                   pad=0, ndir=4, w_dir_stride=CD * D, out_dir_stride=B * Lq * CD, out_f32=True,
                   OH=H // 2, OW=W // 2)
+        self._pr(tag + ".xdbl", xdbl)
         nws = L.lib().fd_scan_ws_floats(B, H, W, D, N)
         ws = self._b("scan_ws", (nws,), torch.float32)
         y = self._b("scan_y", (B, H, W, D))
         L.call("fd_selective_scan", self.dt, _p(xc), _p(xdbl), _p(m["dtw"]), _p(m["dtb"]), _p(m["A"]),
                _p(m["Ds"]), _p(y), _p(ws), B, H, W, D, N, R, s)
+        self._pr(tag + ".y", y)
         loc = C.c_void_p(self.local_all.data_ptr() + m["loc_off"] * f4)
         x1 = self._b(tag + ".x1", (B, H, W, Cc))
         lng = dict(prologue=L.PRO_LN_GATE, ln_gamma=m["onw"], ln_beta=m["onb"], ln_eps=1e-5, ln_shift=loc,
@@ -393,6 +407,7 @@ class DAEngine:
             L.call("fd_ln_gate", self.dt, _p(y), _p(m["onw"]), _p(m["onb"]), 1e-5, _p(xz), 2 * D, D, loc,
                    self.loc_total, _p(yz), B, hw, D, s)
             self.conv(m["out_proj"], yz, B, H, W, x1, **ep1)
+        self._pr(tag + ".x1", x1)
         # --- channel attention branch
         qkv2 = self._b("qkv2", (B, H, W, 3 * Cc))
         ln2 = dict(prologue=L.PRO_LN_MOD, ln_eps=1e-6, ln_shift=mp(3), ln_scale=mp(4), ln_ld=ml)
@@ -410,14 +425,17 @@ class DAEngine:
                 self.conv(m["qkv"], xm2, B, H, W, qkv)
             L.call("fd_dwconv3x3", self.dt, _p(qkv), 3 * Cc, 0, _p(m["qdw_w"]), None, 0, _p(qkv2), 3 * Cc, 0,
                    B, H, W, 3 * Cc, s)
+        self._pr(tag + ".qkv2", qkv2)
         nblk = L.lib().fd_chan_attn_nblk(hw)
         part = self._b("gram", (B, m["heads"], nblk, 1024 + 64), torch.float32)
         L.call("fd_chan_attn_gram", self.dt, _p(qkv2), B, hw, Cc, _p(part), s)
         weff = self._b("weff", (B, Cc, Cc))
         L.call("fd_chan_attn_weff", self.dt, _p(part), nblk, _p(m["temp"]), _p(m["wproj"]), _p(weff), B, Cc, s)
+        self._pr(tag + ".weff", weff)
         x2 = self._b(tag + ".x2", (B, H, W, Cc))
         self.conv(None, qkv2, B, H, W, x2, c0=Cc, ld0=3 * Cc, off0=2 * Cc, weight=weff, w_batch_stride=Cc * Cc,
                   bias=None, Cout=Cc, KH=1, KW=1, epi=L.EPI_GATE_RES, res=x1, gate=mp(5), gate_ld=ml)
+        self._pr(tag, x2)
         return x2
 
     # ------------------------------------------------------------------ conditioning (once per slice)
@@ -494,6 +512,16 @@ class DAEngine:
         self.dose_emb, self.ctx_emb = dose, ctx
         return dose, ctx
 
+    def share_condition(self, other):
+        """Take the t-independent conditioning (prompt embedding, per-block `local` vectors: fp32 in every
+        mode) from another engine of the same weights instead of running the DA-CLIP tower again."""
+        B = other.prompt_emb.shape[0]
+        self.prompt_emb = self._b("prompt_emb", (B, self.time_dim), torch.float32)
+        self.local_all = self._b("local_all", (B, self.loc_total), torch.float32)
+        self.prompt_emb.copy_(other.prompt_emb)
+        self.local_all.copy_(other.local_all)
+        self.dose_emb, self.ctx_emb = other.dose_emb, other.ctx_emb
+
     # ------------------------------------------------------------------ one denoiser forward
     def time_cond(self, time):
         """time (B,) fp32 device -> adaLN vectors of all blocks (src/DADiff.py:703,709,484)."""
@@ -532,6 +560,7 @@ class DAEngine:
             xin8 = self._b("unet_in", (B, H, W, 8))
             L.call("fd_pack_planes3", self.dt, _p(x_t), _p(x_in), _p(x_cond2), _p(xin8), B, H * W, 8, s)
             self.conv(self.init_conv, xin8, B, H, W, r)
+        self._pr("init", r)
         x, h, w = r, H, W
         skips = []
         for i, d in enumerate(self.downs):
@@ -547,6 +576,7 @@ class DAEngine:
                 o = self._b(f"d{i}s", (B, h, w, cw.Cout))
                 self.conv(cw, x, B, h, w, o)
             x = o
+            self._pr(f"d{i}s", x)
         x = self.res_block(self.mid_res, x, x.shape[-1], None, 0, B, h, w, "midr")
         x = self.mamba_block(self.mid_mamba, x, B, h, w, "midm")
         for i, u in enumerate(self.ups):
@@ -563,9 +593,11 @@ class DAEngine:
                 o = self._b(f"u{i}s", (B, h, w, cw.Cout))
                 self.conv(cw, x, B, h, w, o)
             x = o
+            self._pr(f"u{i}s", x)
         x = self.res_block(self.final_res, x, x.shape[-1], r, r.shape[-1], B, h, w, "finr")
         if out is None:
             out = self._b("model_out", (B, 1, H, W), torch.float32)
         L.call("fd_final_conv1", self.dt, _p(x), _p(self.final_w), _p(self.final_b), _p(out), B * H * W,
                x.shape[-1], s)
+        self._pr("out", out)
         return out

@@ -1,0 +1,49 @@
+"""Worker of tests/test_gpu_dist.py: launched by torch.distributed.run (one rank per GPU, nccl = RCCL).
+Runs the PRODUCT sampler through founddiff_amd.parallel.sample_volume and writes the gathered volume."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+TINY_CLIP = dict(layers=(2, 1, 1, 1), width=16, embed_dim=1024)
+
+
+def build(dev):
+    from founddiff_amd import arch, synth
+    from founddiff_amd.DADiff import ResidualDiffusion, UnetRes, load_weights
+    spec = arch.da_unet_spec(32, (1, 2), prefix="model.unet0.", clip=TINY_CLIP)
+    w = synth.synth_state_dict(spec, seed=0)
+    net = UnetRes(dim=32, dim_mults=(1, 2), num_unet=1, condition=True, objective="pred_res",
+                  test_res_or_noise="res", precision="bf16", clip_cfg=TINY_CLIP)
+    dif = ResidualDiffusion(net, image_size=64, timesteps=1000, sampling_timesteps=3, objective="pred_res",
+                            loss_type="l2", condition=True, sum_scale=0.01, test_res_or_noise="res")
+    load_weights(dif, w)
+    dif = dif.to(dev)
+    dif.init()
+    return dif
+
+
+def main():
+    out_path, n = sys.argv[1], int(sys.argv[2])
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist.init_process_group("nccl", device_id=dev)
+    from founddiff_amd import parallel, synth
+    _, ld = synth.ct_phantom(n, 64, seed=10)
+    vol = parallel.sample_volume(build(dev), torch.from_numpy(ld), world=world, rank=rank, noise_seed=100, batch=2)
+    # the gather itself, ragged: rank r contributes r + 1 rows
+    rag = parallel.gather_volume(torch.full((rank + 1, 1, 4, 4), float(rank), device=dev), world)
+    assert rag.shape[0] == world * (world + 1) // 2
+    dist.barrier()
+    if rank == 0:
+        torch.save(vol.cpu(), out_path)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,58 @@
+"""The N>1 path with the REAL sampler over nccl (RCCL): tests/_dist_worker.py under torch.distributed.run with
+as many ranks as the box has GPUs (1 on the test box), against the single-process run -- bitwise equal, since a
+slice's result depends on nothing but its own inputs and noise is keyed by the global slice index.  The
+world_size-2 logic (ragged shards, gather order) is covered on CPU by tests/test_parallel_cpu.py (gloo)."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_sample_volume_over_nccl(tmp_path):
+    sys.path.insert(0, HERE)
+    import _dist_worker as wk
+    from founddiff_amd import parallel, synth
+    n = 5
+    world = max(1, min(torch.cuda.device_count(), 2))
+    out = tmp_path / "vol.pt"
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(HERE, "_dist_worker.py"), str(out), str(n)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    got = torch.load(out)
+    _, ld = synth.ct_phantom(n, 64, seed=10)
+    ref = parallel.sample_volume(wk.build(torch.device("cuda")), torch.from_numpy(ld), world=1, rank=0, noise_seed=100,
+                                 batch=2).cpu()
+    assert got.shape == ref.shape == (n, 1, 64, 64)
+    assert torch.equal(got, ref)
+
+
+def test_bench_self_launch_single_rank():
+    """`python bench.py --gpus N` must work from a bare shell (bench.self_launch); exercised here with N = 1 ranks
+    forced through the launcher path (RANK unset, FOUNDDIFF_BENCH_FORCE_LAUNCH=1)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["FOUNDDIFF_BENCH_FORCE_LAUNCH"] = "1"
+    cmd = [sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0",
+           "--batch", "1", "--no-roofline", "--no-cpu-baseline", "--no-fp32-leg"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    import json
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 1 and res["value"] > 0

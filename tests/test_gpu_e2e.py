@@ -87,7 +87,7 @@ def test_mamba_block(golden, mode, tol, tag):
 
 
 def _tiny_model(golden, precision, S=10):
-    from founddiff_amd.DADiff import ResidualDiffusion, UnetRes
+    from founddiff_amd.DADiff import ResidualDiffusion, UnetRes, load_weights
     g = golden("e2e_da_tiny")
     net = UnetRes(dim=32, dim_mults=(1, 2), num_unet=1, condition=True, objective="pred_res",
                   test_res_or_noise="res", precision=precision, clip_cfg=TINY_CLIP)
@@ -182,7 +182,7 @@ def test_full_arch_64(golden):
     from conftest import GOLDEN
     if not os.path.exists(os.path.join(GOLDEN, "full_arch_64.npz")):
         pytest.skip("full_arch_64.npz not generated")
-    from founddiff_amd.DADiff import ResidualDiffusion, UnetRes
+    from founddiff_amd.DADiff import ResidualDiffusion, UnetRes, load_weights
     g = golden("full_arch_64")
     net = UnetRes(dim=64, dim_mults=(1, 2, 4, 8), num_unet=1, condition=True, objective="pred_res",
                   test_res_or_noise="res", precision="fp32")
@@ -207,7 +207,7 @@ def test_full_arch_64(golden):
 def test_vs_oracle_random_256(golden):
     """Full architecture at 256x256 (config 2 geometry), 2 DDIM steps: HIP fp32 vs the CPU oracle."""
     from founddiff_amd import arch, synth
-    from founddiff_amd.DADiff import ResidualDiffusion, UnetRes
+    from founddiff_amd.DADiff import ResidualDiffusion, UnetRes, load_weights
     from oracle import sampler
     spec = arch.da_unet_spec(64, (1, 2, 4, 8), prefix="model.unet0.")
     w = synth.synth_state_dict(spec, seed=3)
@@ -215,7 +215,7 @@ def test_vs_oracle_random_256(golden):
                   test_res_or_noise="res", precision="fp32")
     dif = ResidualDiffusion(net, image_size=256, timesteps=1000, sampling_timesteps=2, objective="pred_res",
                             loss_type="l2", condition=True, sum_scale=0.01, test_res_or_noise="res")
-    dif.load_state_dict(w, strict=False)
+    load_weights(dif, w)
     dif = dif.to("cuda")
     dif.init()
     _, ld = synth.ct_phantom(1, 256, seed=10)
@@ -233,14 +233,14 @@ def test_properties_512_bf16():
     does not depend on what else is in the batch -> sharding over GPUs cannot change it),
     finite and in range."""
     from founddiff_amd import arch, synth
-    from founddiff_amd.DADiff import ResidualDiffusion, UnetRes
+    from founddiff_amd.DADiff import ResidualDiffusion, UnetRes, load_weights
     spec = arch.da_unet_spec(64, (1, 2, 4, 8), prefix="model.unet0.")
     w = synth.synth_state_dict(spec, seed=0)
     net = UnetRes(dim=64, dim_mults=(1, 2, 4, 8), num_unet=1, condition=True, objective="pred_res",
                   test_res_or_noise="res", precision="bf16")
     dif = ResidualDiffusion(net, image_size=512, timesteps=1000, sampling_timesteps=3, objective="pred_res",
                             loss_type="l2", condition=True, sum_scale=0.01, test_res_or_noise="res")
-    dif.load_state_dict(w, strict=False)
+    load_weights(dif, w)
     dif = dif.to("cuda")
     dif.init()
     _, ld = synth.ct_phantom(2, 512, seed=10)
@@ -266,7 +266,7 @@ VARIANTS = {   # name -> (num_unet, objective, test_res_or_noise); mirrors tests
 def test_objective_variants_fp32(golden, name):
     """the other objectives and the dual-UNet model, HIP path (fp32 mode) against the
     reference's own outputs: model_predictions, every step of a 4-step DDIM, 3 ancestral steps."""
-    from founddiff_amd.DADiff import ResidualDiffusion, UnetRes
+    from founddiff_amd.DADiff import ResidualDiffusion, UnetRes, load_weights
     g = golden("e2e_da_variants")
     nu, obj, tst = VARIANTS[name]
     ic, mask = name.startswith("incond"), name == "incond_mask"
@@ -313,7 +313,7 @@ def test_odd_size_floor_pooling_fp32():
     (nn.AvgPool2d semantics, src/DACLIP.py:187) and no 3x3 conv meets the halo kernel's tiling -- HIP path
     (fp32 mode) against the CPU oracle on one model_predictions call."""
     from founddiff_amd import arch, synth
-    from founddiff_amd.DADiff import ResidualDiffusion, UnetRes
+    from founddiff_amd.DADiff import ResidualDiffusion, UnetRes, load_weights
     from oracle import sampler
     H, W = 48, 80
     spec = arch.da_unet_spec(32, (1, 2), prefix="model.unet0.", clip=TINY_CLIP)
@@ -327,7 +327,7 @@ def test_odd_size_floor_pooling_fp32():
                   precision="fp32", clip_cfg=TINY_CLIP)
     dif = ResidualDiffusion(net, image_size=H, timesteps=1000, sampling_timesteps=2, objective="pred_res", loss_type="l2",
                             condition=True, sum_scale=0.01, test_res_or_noise="res")
-    dif.load_state_dict(w, strict=False)
+    load_weights(dif, w)
     dif = dif.to("cuda")
     dif.init()
     p = dif.model_predictions(x_in.cuda(), x_t.cuda(), tt.cuda())
@@ -345,7 +345,7 @@ def test_vs_oracle_512_one_forward():
     weights amplify bf16 rounding much more on this input (6.7e-2), so that comparison is a coarse sanity
     bound that only a broken kernel would violate."""
     from founddiff_amd import arch, synth
-    from founddiff_amd.DADiff import ResidualDiffusion, UnetRes
+    from founddiff_amd.DADiff import ResidualDiffusion, UnetRes, load_weights
     from oracle import sampler
     spec = arch.da_unet_spec(64, (1, 2, 4, 8), prefix="model.unet0.")
     w = synth.synth_state_dict(spec, seed=0)
@@ -364,7 +364,7 @@ def test_vs_oracle_512_one_forward():
                       test_res_or_noise="res", precision=prec)
         dif = ResidualDiffusion(net, image_size=512, timesteps=1000, sampling_timesteps=50, objective="pred_res",
                                 loss_type="l2", condition=True, sum_scale=0.01, test_res_or_noise="res")
-        dif.load_state_dict(w, strict=False)
+        load_weights(dif, w)
         dif = dif.to("cuda")
         dif.init()
         p = dif.model_predictions(x_in.cuda(), x_t.cuda(), tt.cuda())

@@ -53,6 +53,32 @@ def test_module_state_dict_layout(golden):
     dif.load_state_dict(w, strict=True)
 
 
+def test_load_weights_is_strict_on_live_keys(golden):
+    """a checkpoint of another geometry / with renamed keys must raise, not leave zero weights
+    (the reference's Trainer.load is a strict load_state_dict, src/DADiff.py:1655-1663)."""
+    from founddiff_amd.DADiff import ResidualDiffusion, UnetRes, load_weights
+    g = golden("e2e_da_tiny")
+    clip = dict(layers=(2, 1, 1, 1), width=16, embed_dim=1024)
+
+    def make(dim):
+        net = UnetRes(dim=dim, dim_mults=(1, 2), num_unet=1, condition=True, objective="pred_res",
+                      test_res_or_noise="res", clip_cfg=clip)
+        return ResidualDiffusion(net, image_size=64, timesteps=1000, sampling_timesteps=10, objective="pred_res",
+                                 loss_type="l2", condition=True, sum_scale=0.01)
+    w = g.weights()
+    sched = {"betas", "alphas_cumsum"}
+    load_weights(make(32), {k: v for k, v in w.items() if k not in sched})      # schedule buffers may be absent
+    renamed = dict(w)
+    renamed["model.unet0.init_conv_RENAMED.weight"] = renamed.pop("model.unet0.init_conv.weight")
+    with pytest.raises(RuntimeError, match="live keys missing"):
+        load_weights(make(32), renamed)
+    dropped = {k: v for k, v in w.items() if "mid_attn.mamba.A_logs" not in k}
+    with pytest.raises(RuntimeError, match="A_logs"):
+        load_weights(make(32), dropped)
+    with pytest.raises(RuntimeError):                                            # other dim: shape mismatch
+        load_weights(make(64), w)
+
+
 def test_product_schedule_matches_reference(golden):
     from founddiff_amd.DADiff import residual_schedule
     g = golden("schedule")
@@ -91,3 +117,32 @@ def test_product_does_not_import_oracle():
         if fn.endswith(".py"):
             src = open(os.path.join(pkg, fn)).read()
             assert "oracle" not in src.replace("CPU oracle", ""), fn
+
+
+def test_bench_self_launch_command(monkeypatch):
+    """`python bench.py --gpus N` from a bare shell spawns torch.distributed.run as a child
+    (the parent never touches a GPU) and exits with the child's code."""
+    import subprocess
+    import sys as _sys
+    import types
+    sys_path0 = list(_sys.path)
+    _sys.path.insert(0, ROOT)
+    try:
+        import bench
+    finally:
+        _sys.path[:] = sys_path0
+    seen = {}
+
+    def fake_run(cmd, env=None, **k):
+        seen["cmd"], seen["env"] = cmd, env
+        return types.SimpleNamespace(returncode=7)
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(_sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    with pytest.raises(SystemExit) as ei:
+        bench.self_launch(types.SimpleNamespace(gpus=4))
+    assert ei.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
