@@ -133,6 +133,25 @@ class Unet(_ParamTree):
         self._engine = None
         return super()._apply(fn, *a, **k)
 
+    def load_dose_clip(self, path_or_state="Dose-CLIP.pth"):
+        """The reference builds its dose encoder from a separate file at construction time:
+        `clipiqa.load_state_dict(torch.load('Dose-CLIP.pth'), strict=True)` (src/DADiff.py:595-596).  A
+        `model-N.pt` checkpoint carries the same tensors under `dose_encoder.*`, so this is only needed for a
+        model that is not loaded from a checkpoint.  Strict on every key that is live on the sampling path (the
+        RN50 visual tower + head1 / head2); the text tower and prompt learner of the file are dead weight."""
+        sd = path_or_state
+        if not isinstance(sd, dict):
+            sd = torch.load(str(sd), map_location="cpu", weights_only=False)
+        mine = {k for k in self.state_dict() if k.startswith("dose_encoder.")}
+        live = {"dose_encoder." + k: v for k, v in sd.items() if "dose_encoder." + k in mine}
+        missing = sorted(mine - set(live))
+        if missing:
+            raise RuntimeError(f"Dose-CLIP state_dict lacks {len(missing)} live keys, e.g. {[m[len('dose_encoder.'):] for m in missing[:3]]}")
+        res = super().load_state_dict(live, strict=False)
+        assert not res.unexpected_keys
+        self._engine = None
+        return res
+
     def engine(self, precision=None):
         """The packed-weight HIP engine of this UNet for `precision` (default: self.precision); one per
         precision is kept (the samplers run their last step(s) on the fp32 engine, see ResidualDiffusion)."""
@@ -310,8 +329,10 @@ class ResidualDiffusion(nn.Module):
         # on the fp32 (parity-mode) engine.  The returned image is clamp(x_input - pred_res) of the LAST forward
         # (src/DADiff.py:1317-1318, 1206), so its rounding error reaches the output undamped while the earlier
         # steps' errors only enter through x_t, weighted by their alpha increments.
+        # Default 1: measured at 512x512 / 50 DDIM steps, bf16 alone drifts 1.08e-2 L2 (50.0 dB) from the fp32
+        # engine, with the last step in fp32 4.4e-3 (57.8 dB) for +5..7 % time; a second fp32 step buys nothing.
         if final_fp32_steps is None:
-            final_fp32_steps = int(os.environ.get("FOUNDDIFF_FINAL_FP32_STEPS", "0"))
+            final_fp32_steps = int(os.environ.get("FOUNDDIFF_FINAL_FP32_STEPS", "1"))
         self.final_fp32_steps = int(final_fp32_steps)
         for k, v in residual_schedule(timesteps, after_init=False).items():
             self.register_buffer(k, v)
@@ -802,49 +823,125 @@ class Trainer(object):
 
     save = train
 
+    # anatomy groups of the reference's 2020 test list, in item order: (name, slices per dose level); each holds
+    # 4 dose levels back to back (src/DADiff.py:1918-1950).  "head" is taken from the END of the list, as there.
+    test_groups = (("ab", 290), ("lung", 637), ("head", 159))
+
     @torch.no_grad()
     def sample(self, milestone, last=True, FID=False):
-        """Preview grid of [NDCT, LDCT, x_T, output] in the HU display window
-        (src/DADiff.py:1765-1815) written as `<results>/sample-N.npy`."""
-        from .data import hu_window
+        """Preview grid of [NDCT, LDCT, x_T, output] in the HU display window, `<results>/sample-N.png`
+        (src/DADiff.py:1765-1815); with FID, one PNG per generated image, `milestone` advancing."""
+        from .data import hu_window, save_image
         n = min(self.num_samples, len(self.sample_dataset))
         items = [self.sample_dataset[i] for i in range(n)]
         show = [torch.stack([it[j] for it in items]).to(self.device) for j in range(len(items[0]))]
         outs = list(self.model.sample(show[1:], batch_size=n, last=last))
-        all_images = hu_window(torch.cat(show + outs, dim=0))
-        file_name = f"sample-{milestone}"
-        np.save(self.results_folder + "/" + file_name, all_images.detach().cpu().numpy())
+        all_images_list = show + outs
+        all_images = hu_window(torch.cat(all_images_list, dim=0))
+        nrow = int(math.sqrt(self.num_samples)) if last else all_images.shape[0]
+        if FID:
+            for i in range(n):
+                file_name = f"sample-{milestone}.png"
+                save_image(all_images_list[0][i].unsqueeze(0), os.path.join(self.results_folder, file_name), nrow=1)
+                milestone += 1
+                if milestone >= getattr(self, "total_n_samples", 50000):
+                    break
+        else:
+            file_name = f"sample-{milestone}.png"
+            save_image(all_images, self.results_folder + "/" + file_name, nrow=nrow)
         print("sampe-save " + file_name)
         return milestone
+
+    @staticmethod
+    def image_file_name(file_name):
+        """PNG name of a result (src/DADiff.py:1904-1907): quarter-dose files keep the part before the first
+        dot, simulated-dose files (`...-0.25-0012.npy`) keep the dose fraction's dot."""
+        if "quarter" in file_name:
+            return file_name.split(".")[0] + ".png"
+        return file_name.split(".")[0] + "." + file_name.split(".")[1] + ".png"
+
+    def _log_groups(self):
+        """Per-anatomy and per-dose means of the running metrics (src/DADiff.py:1918-1950), same slicing rule
+        and log lines; groups the evaluated list does not reach log nan, as np.mean of an empty slice does."""
+        def mean(v):
+            return float(np.mean(v)) if len(v) else float("nan")
+        P, S, R = self.test_running_psnr, self.test_running_ssim, self.test_running_rmse
+        out, off = {}, 0
+        for gi, (name, length) in enumerate(self.test_groups):
+            if gi == len(self.test_groups) - 1:
+                sl = slice(-length * 4, None)
+            else:
+                sl = slice(off, off + length * 4)
+            gp, gs, gr = P[sl], S[sl], R[sl]
+            self.train_logger.info("(%s average mean: psnr: %.4f, ssim: %.4f,rmse: %.4f)" % (name, mean(gp), mean(gs), mean(gr)))
+            out[name] = {"mean": (mean(gp), mean(gs), mean(gr)), "dose": []}
+            for i in range(4):
+                d = slice(int(i * length), int((i + 1) * length))
+                row = (mean(gp[d]), mean(gs[d]), mean(gr[d]))
+                out[name]["dose"].append(row)
+                self.train_logger.info("(%s\u2014\u2014\u2014\u2014dose: %2d,average: psnr: %.4f, ssim: %.4f,rmse: %.4f)" % ((name, i) + row))
+            off += length * 4
+        return out
 
     @torch.no_grad()
     def test(self, sample=False, last=True, FID=False, batch_size=1):
         """Evaluation loop of src/DADiff.py:1817-1966: init() the schedule, denoise every slice,
-        PSNR/SSIM/RMSE vs NDCT (on device), np.save each output in [0,1].  `batch_size` > 1
-        batches independent slices (the reference uses 1)."""
+        PSNR/SSIM/RMSE vs NDCT (on device), np.save each output in [0,1], per-anatomy / per-dose means.
+        `batch_size` > 1 batches independent slices (the reference uses 1).  `sample=True` keeps the
+        reference's branch that returns inputs + outputs without metrics; without `condition` the loop is the
+        reference's unconditional `self.sample` rounds (100, or up to 50000 images with FID)."""
         from .metrics import compute_metrics
         self.model.init()
         print("test start")
+        if not self.condition:
+            if FID:
+                import glob
+                self.total_n_samples = 50000
+                img_id = len(glob.glob(f"{self.results_folder}/*"))
+                n_rounds = (self.total_n_samples - img_id) // self.num_samples + 1
+            else:
+                n_rounds = 100
+            for i in range(n_rounds):
+                if FID:
+                    i = img_id
+                img_id = self.sample(i, last=last, FID=FID)
+            print("test end")
+            return None
         self.test_running_psnr, self.test_running_ssim, self.test_running_rmse = [], [], []
+        self.test_image_names = []
         ds = self.sample_dataset
         for s in range(0, len(ds), batch_size):
             idx = list(range(s, min(s + batch_size, len(ds))))
             items = [ds[i] for i in idx]
             y = torch.stack([it[0] for it in items]).to(self.device)
-            x = torch.stack([it[1] for it in items]).to(self.device)
-            outs = list(self.model.sample([x], batch_size=len(idx), last=last))
-            y_pred = outs[-1]
-            m = compute_metrics(y_pred, y).cpu().numpy()
+            xs = [torch.stack([it[k] for it in items]).to(self.device) for k in range(1, len(items[0]))]
+            if sample:
+                all_images_list = [y] + xs + list(self.model.sample(xs, batch_size=len(idx)))
+                y_pred = all_images_list[-1]
+            else:
+                y_pred = list(self.model.sample(xs, batch_size=len(idx), last=last))[-1]
+                if self.crop_patch:
+                    pad = [ds.get_pad_size(i + 1) for i in idx]         # the reference indexes with the NEXT item (1875)
+                    assert len(set(map(tuple, pad))) == 1, "crop_patch needs one pad size per batch"
+                    h, w = y_pred.shape[-2:]
+                    y_pred = y_pred[:, :, 0:h - pad[0][0], 0:w - pad[0][1]]
+                m = compute_metrics(y_pred, y).cpu().numpy()
             for j, i in enumerate(idx):
                 file_name = ds.load_name(i, sub_dir=self.sub_dir)
-                self.test_running_psnr.append(m[j, 0])
-                self.test_running_ssim.append(m[j, 1])
-                self.test_running_rmse.append(m[j, 2])
-                print("(psnr: %.4f, ssim: %.4f,rmse:.%.4f) " % (m[j, 0], m[j, 1], m[j, 2]))
-                if not getattr(self.opt, "is_train", False):
+                self.test_image_names.append(self.image_file_name(file_name))
+                if not sample:
+                    self.test_running_psnr.append(m[j, 0])
+                    self.test_running_ssim.append(m[j, 1])
+                    self.test_running_rmse.append(m[j, 2])
+                    print("(psnr: %.4f, ssim: %.4f,rmse:.%.4f) " % (m[j, 0], m[j, 1], m[j, 2]))
+                if not getattr(self.opt, "is_train", False) and not sample:
                     h, w = y_pred.shape[-2:]
                     np.save(self.results_folder + "/" + file_name[:-4], y_pred[j].detach().cpu().numpy().reshape(h, w))
                     print("test-save " + file_name)
+        if sample:
+            print("test end")
+            return None
+        self.test_group_means = self._log_groups()
         self.train_logger.info("test_psnr: {:.4f}, test_ssim: {:.4f},test_rmse:{:.4f}".format(
             np.mean(self.test_running_psnr), np.mean(self.test_running_ssim), np.mean(self.test_running_rmse)))
         print("test end")

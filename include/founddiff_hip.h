@@ -174,6 +174,21 @@ int fd_selective_scan(int dtype, const void *xc, const float *xdbl, const float 
                       const float *dtb, const float *A, const float *Ds, void *y, float *ws,
                       int B, int H, int W, int D, int N, int R, void *stream);
 
+/* ---- The reference's own native-op interface (the only one it has):
+ *     out, x, *rest = selective_scan_cuda_core.fwd(u, delta, A, B, C, D, delta_bias, delta_softplus, nrows)
+ * /root/reference/src/emamba2.py:154, layout asserted at 124-149.  All tensors fp32, contiguous in the last dim:
+ *   u, delta [batch,KD,L]   A [KD,N]   B, C [batch,K,N,L] (K groups, channel d uses group d / (KD/K))
+ *   D, delta_bias [KD] (either may be NULL)      out [batch,KD,L]
+ *   x_last [batch,KD,N] or NULL: the state after the last position (the extension's second return value holds
+ *   the chunk states its backward pass needs; this library is forward-only and returns the final state instead)
+ * nrows is the extension's rows-per-block tuning knob: validated like the reference does (1..4, KD % (K*nrows)
+ * == 0, src/emamba2.py:129-130) and otherwise without effect.  Python shim with the extension's module and
+ * function name: founddiff_amd/selective_scan_cuda_core.py.                                                 */
+int fd_selective_scan_fwd_f32(const float *u, const float *delta, const float *A, const float *B,
+                              const float *C, const float *D, const float *delta_bias, int delta_softplus,
+                              int nrows, int batch, int KD, int K, int N, int64_t L, float *out, float *x_last,
+                              void *stream);
+
 /* ---- channel ("transposed") attention, src/DADiff.py:263-285 ------------------------------
  * fd_chan_attn_gram: per (b, head) partial 32x32 Gram q^T k and sums of squares over pixel
  *   blocks.  qkv [B,HW,3C] (dtype).  partial: fp32 [B][heads][nblk][32*32+64].

@@ -53,3 +53,39 @@ void fd_oracle_selective_scan(const float *u, const float *delta, const float *A
         }
     }
 }
+
+/* The same recurrence in double precision (inputs fp32, state and arithmetic fp64): the yardstick for the
+ * long-sequence case (one L = 65 536 case against fp64). */
+void fd_oracle_selective_scan_f64(const float *u, const float *delta, const float *A, const float *Bm,
+                                  const float *Cm, const float *D, const float *dbias, int softplus,
+                                  double *y, int b, int KD, int K, int N, long L)
+{
+    const int Dg = KD / K;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int ib = 0; ib < b; ++ib) {
+        for (int d = 0; d < KD; ++d) {
+            const int g = d / Dg;
+            const float *ur = u + ((long)ib * KD + d) * L;
+            const float *dr = delta + ((long)ib * KD + d) * L;
+            double *yr = y + ((long)ib * KD + d) * L;
+            const float *Br = Bm + ((long)ib * K + g) * N * L;
+            const float *Cr = Cm + ((long)ib * K + g) * N * L;
+            const float *Ar = A + (long)d * N;
+            double h[256];
+            for (int n = 0; n < N; ++n) h[n] = 0.0;
+            const double bias = dbias ? dbias[d] : 0.0;
+            const double Dd = D ? D[d] : 0.0;
+            for (long t = 0; t < L; ++t) {
+                double dt = (double)dr[t] + bias;
+                if (softplus) dt = dt > 20.0 ? dt : log1p(exp(dt));
+                const double ut = ur[t];
+                double acc = 0.0;
+                for (int n = 0; n < N; ++n) {
+                    h[n] = exp(dt * (double)Ar[n]) * h[n] + dt * (double)Br[(long)n * L + t] * ut;
+                    acc += h[n] * (double)Cr[(long)n * L + t];
+                }
+                yr[t] = acc + Dd * ut;
+            }
+        }
+    }
+}

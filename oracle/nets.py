@@ -57,6 +57,21 @@ def selective_scan(u, delta, A, B, C, D, delta_bias, softplus=True):
     return y
 
 
+def selective_scan_f64(u, delta, A, B, C, D, delta_bias, softplus=True):
+    """Same arguments (fp32 tensors), state and arithmetic in fp64 -> y float64.  C kernel."""
+    u, delta, A, B, C, D, delta_bias = [t.contiguous().float() for t in (u, delta, A, B, C, D, delta_bias)]
+    b, KD, L = u.shape
+    K, N = B.shape[1], A.shape[1]
+    assert N <= 256
+    y = torch.empty(u.shape, dtype=torch.float64)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    fn = _lib().fd_oracle_selective_scan_f64
+    fn.restype = None
+    fn(p(u), p(delta), p(A), p(B), p(C), p(D), p(delta_bias), ctypes.c_int(1 if softplus else 0), p(y),
+       ctypes.c_int(b), ctypes.c_int(KD), ctypes.c_int(K), ctypes.c_int(N), ctypes.c_long(L))
+    return y
+
+
 def selective_scan_torch(u, delta, A, B, C, D, delta_bias, softplus=True):
     """Same recurrence in plain torch (slow; cross-checks the C kernel on small cases)."""
     b, KD, L = u.shape

@@ -154,13 +154,122 @@ def test_ddim_tiny_fp32(golden, use_graph):
     assert torch.equal(out[-1], imgs[-1])          # deterministic, graph or not
 
 
+def psnr(a, b):
+    return float(10 * torch.log10(1.0 / ((a.double() - b.double()) ** 2).mean()))
+
+
 def test_ddim_tiny_bf16_drift(golden):
+    """config 1 in the production mode (bf16 kernels, last step on the fp32 engine) against the REFERENCE's own
+    output: the drift gate of SURVEY section 7 (L2 <= 1e-2, >= 45 dB); the pure-bf16 loop (final_fp32_steps=0)
+    keeps the looser bound the reference's own autocast(bf16) run sits at (7.4e-3 L2 / 49 dB)."""
     g, dif = _tiny_model(golden, "bf16")
-    out = dif.sample([g["x_input"].cuda()], batch_size=2, last=True, noise=g["ddim.noise0"].cuda())
+    assert dif.final_fp32_steps == 1
     ref = g["ddim.out"]
-    assert l2rel(out[-1].cpu(), ref) < 2e-2
-    mse = float(((out[-1].cpu() - ref) ** 2).mean())
-    assert 10 * torch.log10(torch.tensor(1.0 / mse)) > 40.0
+    out = dif.sample([g["x_input"].cuda()], batch_size=2, last=True, noise=g["ddim.noise0"].cuda())[-1].cpu()
+    assert l2rel(out, ref) < 1e-2 and psnr(out, ref) > 45.0
+    again = dif.sample([g["x_input"].cuda()], batch_size=2, last=True, noise=g["ddim.noise0"].cuda())[-1].cpu()
+    assert torch.equal(out, again)
+    eager = dif.sample([g["x_input"].cuda()], batch_size=2, last=False, noise=g["ddim.noise0"].cuda())[-1].cpu()
+    assert torch.equal(out, eager)                     # whole-loop graph == per-step graphs, both engines
+    dif.final_fp32_steps = 0
+    pure = dif.sample([g["x_input"].cuda()], batch_size=2, last=True, noise=g["ddim.noise0"].cuda())[-1].cpu()
+    assert l2rel(pure, ref) < 2e-2 and psnr(pure, ref) > 40.0
+    assert l2rel(out, ref) < l2rel(pure, ref)
+
+
+def test_p_sample_loop_tiny_fp32(golden):
+    """a6: the ancestral loop DRIVER (src/DADiff.py:1233-1273), all 1000 steps of config 1's model through
+    p_sample_loop itself; the first 20 steps and x_T against the reference's goldens (noise supplied per step)."""
+    g, dif = _tiny_model(golden, "fp32", S=1000)
+    assert not dif.is_ddim_sampling
+    nz = {999 - i: g["anc.noise"][i].cuda() for i in range(20)}
+    gen = torch.Generator(device="cuda").manual_seed(0)
+
+    def step_noise(t):
+        return nz[t] if t in nz else torch.randn((2, 1, 64, 64), device="cuda", generator=gen)
+    outs = dif.sample([g["x_input"].cuda()], batch_size=2, last=False, noise=g["ddim.noise0"].cuda(), step_noise=step_noise)
+    assert len(outs) == 1001
+    xi = g["x_input"] * 2 - 1
+    assert rel_err(outs[0].cpu() * 2 - 1, xi + 0.1 * g["ddim.noise0"]) < 1e-5
+    for i in range(20):
+        assert rel_err(outs[1 + i].cpu() * 2 - 1, g["anc.imgs"][i]) < 1e-3, i
+    fin = outs[-1]
+    assert torch.isfinite(fin).all() and float(fin.min()) >= 0.0 and float(fin.max()) <= 1.0
+    # last=True returns [x_T, final] and equals the last=False run given the same noise stream
+    gen.manual_seed(0)
+    two = dif.sample([g["x_input"].cuda()], batch_size=2, last=True, noise=g["ddim.noise0"].cuda(), step_noise=step_noise)
+    assert len(two) == 2 and torch.equal(two[-1], fin)
+
+
+def test_config2_256_bf16_50step_drift():
+    """BASELINE configs[1] (256x256, 50-step DDIM, full architecture + DA-CLIP, bf16) in the production mode against
+    the fp32 parity engine: L2 <= 1e-2, >= 45 dB (5.0e-3 / 56.9 dB measured); the pure-bf16 loop is reported with
+    the looser bound it sits at (1.2e-2 / 49.4 dB)."""
+    from founddiff_amd import synth
+    import bench
+    dev = torch.device("cuda")
+    _, ld = synth.ct_phantom(2, 256, seed=10)
+    x = torch.from_numpy(ld).to(dev)
+    nz = torch.randn(2, 1, 256, 256, generator=torch.Generator().manual_seed(7)).to(dev)
+    outs = {}
+    for tag, prec, k in (("fp32", "fp32", 0), ("prod", "bf16", 1), ("pure", "bf16", 0)):
+        dif, _ = bench.build_model(dev, 256, 50, prec)
+        dif.final_fp32_steps = k
+        outs[tag] = dif.sample([x], batch_size=2, noise=nz)[-1].float().cpu()
+        del dif
+        torch.cuda.empty_cache()
+    assert l2rel(outs["prod"], outs["fp32"]) < 1e-2 and psnr(outs["prod"], outs["fp32"]) > 45.0
+    assert l2rel(outs["pure"], outs["fp32"]) < 2e-2 and psnr(outs["pure"], outs["fp32"]) > 45.0
+
+
+def test_config3_512_bf16_50step_drift():
+    """BASELINE configs[2], the benchmarked workload itself (512x512, 50 steps): production mode vs the fp32 engine,
+    L2 <= 1e-2 and >= 45 dB (4.4e-3 / 57.8 dB measured; pure bf16 1.08e-2 / 50.0 dB)."""
+    from founddiff_amd import synth
+    import bench
+    dev = torch.device("cuda")
+    _, ld = synth.ct_phantom(2, 512, seed=10)
+    x = torch.from_numpy(ld).to(dev)
+    nz = torch.randn(2, 1, 512, 512, generator=torch.Generator().manual_seed(7)).to(dev)
+    outs = {}
+    for tag, prec, k in (("fp32", "fp32", 0), ("prod", "bf16", 1), ("pure", "bf16", 0)):
+        dif, _ = bench.build_model(dev, 512, 50, prec)
+        dif.final_fp32_steps = k
+        outs[tag] = dif.sample([x], batch_size=2, noise=nz)[-1].float().cpu()
+        del dif
+        torch.cuda.empty_cache()
+    assert l2rel(outs["prod"], outs["fp32"]) < 1e-2 and psnr(outs["prod"], outs["fp32"]) > 45.0
+    assert l2rel(outs["pure"], outs["fp32"]) < 2e-2 and psnr(outs["pure"], outs["fp32"]) > 45.0
+
+
+def test_config4_512_ancestral_bf16_properties():
+    """BASELINE configs[3] geometry (512x512, 1000-step ancestral, full architecture, bf16): the first three steps of
+    the loop through p_sample -- deterministic, finite, batch-invariant (what sharding 64 slices over 8 GPUs relies
+    on), and the t = 0 step returns x_start."""
+    import bench
+    from founddiff_amd import synth
+    dev = torch.device("cuda")
+    dif, _ = bench.build_model(dev, 512, 1000, "bf16")
+    assert not dif.is_ddim_sampling
+    _, ld = synth.ct_phantom(2, 512, seed=10)
+    xi = torch.from_numpy(ld).to(dev) * 2 - 1
+    g = torch.Generator().manual_seed(3)
+    x_t = xi + 0.1 * torch.randn(2, 1, 512, 512, generator=g).to(dev)
+    nzs = [torch.randn(2, 1, 512, 512, generator=g).to(dev) for _ in range(3)]
+
+    def run(sl):
+        img = x_t[sl].clone()
+        for i, t in enumerate((999, 998, 997)):
+            img, xs = dif.p_sample(xi[sl], img, t, noise=nzs[i][sl], reuse_condition=i > 0)
+        return img, xs
+    a, xs = run(slice(0, 2))
+    b, _ = run(slice(0, 2))
+    assert torch.equal(a, b) and torch.isfinite(a).all() and float(xs.abs().max()) <= 1.0
+    s0, _ = run(slice(0, 1))
+    s1, _ = run(slice(1, 2))
+    assert torch.equal(a[0:1], s0) and torch.equal(a[1:2], s1)
+    img0, xs0 = dif.p_sample(xi, a, 0)
+    assert torch.equal(img0, xs0)                       # coef3 = 1, coef1 = coef2 = 0, no noise at t = 0
 
 
 def test_ancestral_steps_fp32(golden):
@@ -201,7 +310,7 @@ def test_full_arch_64(golden):
     assert rel_err(res[-1].cpu(), g["ddim2.out"]) < 1e-3
     net.unet0.precision = "bf16"
     res16 = dif.sample([g["x_input"].cuda()], batch_size=1, last=True, noise=g["noise0"].cuda())
-    assert l2rel(res16[-1].cpu(), g["ddim2.out"]) < 2e-2
+    assert l2rel(res16[-1].cpu(), g["ddim2.out"]) < 1e-2      # production mode: the second of the two steps runs in fp32
 
 
 def test_vs_oracle_random_256(golden):
@@ -339,11 +448,13 @@ def test_vs_oracle_512_one_forward():
     """BASELINE configs[2] geometry (512x512, full architecture), ONE model_predictions call.
     fp32 mode against the CPU oracle: the 1e-3 parity gate at the bench size.
     bf16 mode -- the only place every production fast path runs together (fused LN->1x1->depthwise, LDS-DMA
-    halo conv, row-GEMM prologues, 256x256 tiles, buffer-addressed scan) -- against (a) the fp32 engine, which
-    runs the generic kernels, on a uniform-noise image: the documented drift gate L2 <= 2e-2 (1.1e-2 measured
-    at every size from 144x176 to 512x512, tools/oddsize_check.py); (b) the oracle on the CT phantom: random
-    weights amplify bf16 rounding much more on this input (6.7e-2), so that comparison is a coarse sanity
-    bound that only a broken kernel would violate."""
+    halo conv, row-GEMM prologues, 256x256 tiles, buffer-addressed scan) -- one forward, so the precision schedule
+    of the sampling loops does not apply: (a) against the fp32 engine on a uniform-noise image, L2 <= 1.5e-2
+    (1.1e-2 measured at every size from 144x176 to 512x512, tools/oddsize_check.py); (b) against the oracle on the
+    CT phantom, L2 <= 3.5e-2 of the raw residual (3.27e-2 measured; profiles/r02_drift_table.md: 29 % of that
+    variance is the bf16 rounding of the weights, the rest is spread evenly over ~100 activation roundings, and
+    this seed's final 64 -> 1 projection amplifies the 1.1e-2 relative error of its input threefold) and
+    <= 6e-3 of x_start = clamp(x_in - residual), the quantity the samplers return."""
     from founddiff_amd import arch, synth
     from founddiff_amd.DADiff import ResidualDiffusion, UnetRes, load_weights
     from oracle import sampler
@@ -359,7 +470,7 @@ def test_vs_oracle_512_one_forward():
     torch.set_num_threads(min(32, torch.get_num_threads()))
     ref = sampler.ResidualOracle(w, prefix="model.unet0.", sampling_timesteps=50).model_predictions(x_in, x_t, tt)
     raw = {}
-    for prec, tol in (("fp32", 1e-3), ("bf16", 1e-1)):
+    for prec in ("fp32", "bf16"):
         net = UnetRes(dim=64, dim_mults=(1, 2, 4, 8), num_unet=1, condition=True, objective="pred_res",
                       test_res_or_noise="res", precision=prec)
         dif = ResidualDiffusion(net, image_size=512, timesteps=1000, sampling_timesteps=50, objective="pred_res",
@@ -368,10 +479,14 @@ def test_vs_oracle_512_one_forward():
         dif = dif.to("cuda")
         dif.init()
         p = dif.model_predictions(x_in.cuda(), x_t.cuda(), tt.cuda())
-        assert rel_err(p.pred_res.cpu(), ref[0]) < tol, prec
-        assert rel_err(p.pred_x_start.cpu(), ref[2]) < tol, prec
+        if prec == "fp32":
+            assert rel_err(p.pred_res.cpu(), ref[0]) < 1e-3
+            assert rel_err(p.pred_x_start.cpu(), ref[2]) < 1e-3
+        else:
+            assert l2rel(p.pred_res.cpu(), ref[0]) < 3.5e-2
+            assert l2rel(p.pred_x_start.cpu(), ref[2]) < 6e-3
         eng = dif._eng()
         eng.encode_condition(u_in.cuda())
         raw[prec] = eng.forward(u_t.cuda().contiguous(), u_in.cuda().contiguous(), torch.full((1,), 500.0, device="cuda")).cpu()
         del dif, net, eng
-    assert rel_err(raw["bf16"], raw["fp32"]) < 2e-2
+    assert l2rel(raw["bf16"], raw["fp32"]) < 1.5e-2

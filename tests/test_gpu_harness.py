@@ -70,5 +70,64 @@ def test_trainer_load_test_sample(tmp_path):
         assert rel_err(torch.from_numpy(out), ref[0, 0]) < 1e-3
         ps.append(float(om.psnr(ref, y[None])))
     assert abs(psnr - float(np.mean(ps))) < 0.05
-    tr.sample(1)
-    assert os.path.exists(os.path.join(tr.results_folder, "sample-1.npy"))
+    # per-anatomy / per-dose means of the log tail (src/DADiff.py:1918-1952), with groups sized for 3 items
+    assert set(tr.test_group_means) == {"ab", "lung", "head"}
+    assert tr.test_image_names == [f"synthetic-quarter-{i:04d}.png" for i in range(3)]      # name rule, 1904-1907
+    tr.test_groups = (("ab", 1), ("head", 0))
+    g = tr._log_groups()
+    assert abs(g["ab"]["mean"][0] - psnr) < 1e-4 and abs(g["ab"]["dose"][1][0] - tr.test_running_psnr[1]) < 1e-6
+    # same seed -> same run (the loop re-initialises the schedule and the running lists); a batched pass runs too
+    one = list(tr.test_running_psnr)
+    torch.manual_seed(3)
+    tr.test(last=True, batch_size=1)
+    assert np.allclose(tr.test_running_psnr, one, atol=1e-4)
+    assert len(tr.test(last=True, batch_size=2)) == 3 and len(tr.test_running_psnr) == 3
+    # sample=True: inputs + outputs, no metrics, nothing saved (src/DADiff.py:1863-1866)
+    assert tr.test(sample=True) is None and tr.test_running_psnr == []
+    # preview grid: PNG in the HU window, like torchvision's save_image (1792-1812); FID: one PNG per image
+    from PIL import Image
+    assert tr.sample(1) == 1
+    im = np.asarray(Image.open(os.path.join(tr.results_folder, "sample-1.png")))
+    assert im.shape == (4 * 66 + 2, 66 + 2, 3)                       # [NDCT, LDCT, x_T, output] x 1 sample, nrow 1
+    tr.total_n_samples = 50000
+    assert tr.sample(10, FID=True) == 11 and os.path.exists(os.path.join(tr.results_folder, "sample-10.png"))
+    # a checkpoint of another geometry must not load silently
+    bad = {k: v for k, v in w.items() if "mid_attn" not in k}
+    torch.save({"step": 1, "model": bad, "opt0": {}, "ema": None, "scaler": None}, ck / "model-7.pt")
+    with pytest.raises(RuntimeError, match="live keys missing"):
+        tr.load(7)
+
+
+def test_dose_clip_file_and_ema_layout(tmp_path):
+    """f3: (i) `Dose-CLIP.pth` (the CLIPIQA state_dict the reference loads strictly at construction,
+    src/DADiff.py:595-596) through Unet.load_dose_clip; (ii) the `ema` entry in ema-pytorch 0.0.10's layout
+    (install.yaml:186): online_model.* / ema_model.* / initted / step -- the ema_model copy wins."""
+    from founddiff_amd import arch, synth
+    from founddiff_amd.DADiff import ResidualDiffusion, Unet, UnetRes, _EMAView
+    spec = arch.da_unet_spec(32, (1, 2), prefix="", clip=TINY_CLIP)
+    w = synth.synth_state_dict(spec, seed=9)
+    iqa = {k[len("dose_encoder."):]: v for k, v in w.items() if k.startswith("dose_encoder.")}
+    iqa["prompt_learner.ctx"] = torch.zeros(2, 16, 512)              # dead weight of the real file: ignored
+    torch.save(iqa, tmp_path / "Dose-CLIP.pth")
+    u = Unet(32, dim_mults=(1, 2), precision="fp32", clip_cfg=TINY_CLIP)
+    u.load_dose_clip(str(tmp_path / "Dose-CLIP.pth"))
+    for k, v in u.state_dict().items():
+        if k.startswith("dose_encoder."):
+            assert torch.equal(v, w[k]), k
+    broken = dict(iqa)
+    broken.pop("head1.0.weight")
+    with pytest.raises(RuntimeError, match="head1.0.weight"):
+        u.load_dose_clip(broken)
+    # ema-pytorch 0.0.10 state_dict
+    net = UnetRes(dim=32, dim_mults=(1, 2), num_unet=1, condition=True, objective="pred_res", test_res_or_noise="res",
+                  precision="fp32", clip_cfg=TINY_CLIP)
+    dif = ResidualDiffusion(net, image_size=64, timesteps=1000, sampling_timesteps=2, objective="pred_res",
+                            loss_type="l2", condition=True, sum_scale=0.01, test_res_or_noise="res")
+    full = {"model.unet0." + k: v for k, v in w.items()}
+    ema = {"ema_model." + k: v for k, v in full.items()}
+    ema.update({"online_model." + k: torch.zeros_like(v) for k, v in full.items()})
+    ema["initted"], ema["step"] = torch.Tensor([True]), torch.tensor([400000])
+    _EMAView(dif).load_state_dict(ema)
+    assert torch.equal(dif.state_dict()["model.unet0.init_conv.weight"], full["model.unet0.init_conv.weight"])
+    with pytest.raises(RuntimeError):
+        _EMAView(dif).load_state_dict({k: v for k, v in ema.items() if "final_conv" not in k})
