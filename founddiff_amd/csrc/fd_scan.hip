@@ -33,7 +33,12 @@ __device__ __forceinline__ void scan_pos(const ScanGeom &g, int k, int l, int &l
 // chunk's x_dbl rows (dt_r | B | C, shared by every channel) are staged once in LDS and read
 // back as wave-uniform broadcasts; each lane prefetches U of its u values per group so U
 // global loads are in flight per wave while the recurrence of the previous group runs.
-template <typename T, int N, int R, bool FINAL>
+// ODD: H or W is odd.  The reference pads the image to even sizes with zeros before the gather and crops after the
+// merge (src/emamba2.py:191-199, 253-260): the padded positions take part in the recurrence with u = 0 and a zero
+// x_dbl row (x_proj has no bias), i.e. the state only decays by exp(softplus(dt_bias) A) there, and their outputs
+// are dropped.  Here they are positions whose pixel lies outside the image: u := 0, no store; the x_dbl rows of
+// those positions are zeros written by the x_proj launch (its gather zero-fills out-of-range pixels).
+template <typename T, int N, int R, bool FINAL, bool ODD>
 __global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 8 ? 5 : 1))) void scan_chunk_kernel(const T *__restrict__ xc, const float *__restrict__ xdbl,
                                                         const float *__restrict__ dtw, const float *__restrict__ dtb,
                                                         const float *__restrict__ A, const float *__restrict__ Ds,
@@ -109,6 +114,7 @@ __global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 8 ? 5 : 1))) void scan_ch
     const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void *)(FINAL ? yb : (T *)ub), 0, img_bytes, 0x00020000);
     const int voff = d * (int)sizeof(T);
     auto ld_u = [&](int soff) -> float {
+        if (ODD && soff < 0) return 0.f;               // padded position (wave-uniform)
         if constexpr (sizeof(T) == 2) {
             const unsigned short r = __builtin_amdgcn_raw_buffer_load_b16(rs_u, voff, soff, 0);
             return __builtin_bit_cast(float, (uint32_t)r << 16);
@@ -117,6 +123,7 @@ __global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 8 ? 5 : 1))) void scan_ch
         }
     };
     auto st_y = [&](int soff, float v) {
+        if (ODD && soff < 0) return;
         if constexpr (sizeof(T) == 2) {
             const bf16 hv = (bf16)v;
             __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hv), rs_y, voff, soff, 0);
@@ -134,6 +141,11 @@ __global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 8 ? 5 : 1))) void scan_ch
     int ci = __builtin_amdgcn_readfirstlane(l0 % NI);
     int pixc = __builtin_amdgcn_readfirstlane(ph * g.W + pw + (l0 % NI) * s_i + (l0 / NI) * s_o);
     const int wrap_fix = s_o - NI * s_i;
+    // ODD: the last fast / slow index of a sub-grid whose parity offset falls outside the image is padding
+    const int NO = odd ? g.W2 : g.H2;
+    const bool padF = ODD && (odd ? ((g.H & 1) && ph) : ((g.W & 1) && pw));
+    const bool padS = ODD && (odd ? ((g.W & 1) && pw) : ((g.H & 1) && ph));
+    int co = __builtin_amdgcn_readfirstlane(l0 / NI);
     __syncthreads();
 
     auto step = [&](const float *xr, float u, int soff) {
@@ -157,11 +169,13 @@ __global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 8 ? 5 : 1))) void scan_ch
         }
         if (FINAL) st_y(soff, acc2.x + acc2.y + Dd * u);
     };
-    auto advance = [&](int &soff) {            // -> byte offset of the pixel's row inside the image
+    auto advance = [&](int &soff) {            // -> byte offset of the pixel's row inside the image (-1: padding)
         soff = pixc * rowb;
+        if (ODD && ((padF && ci == NI - 1) || (padS && co == NO - 1))) soff = -1;
         ++ci;
         const bool wrap = ci == NI;
         ci = wrap ? 0 : ci;
+        if (ODD) co += wrap ? 1 : 0;
         pixc += s_i + (wrap ? wrap_fix : 0);
     };
     constexpr int U = (N >= 16) ? 8 : 16;  // steps per group
@@ -295,7 +309,7 @@ __global__ __launch_bounds__(64 * SEG) void scan_carry_kernel(float *__restrict_
     }
 }
 
-template <typename T, int N, int R>
+template <typename T, int N, int R, bool ODD>
 void launch_scan(const T *xc, const float *xdbl, const float *dtw, const float *dtb, const float *A,
                  const float *Ds, T *y, float *ws, const ScanGeom &g, hipStream_t s) {
     const int64_t half = (int64_t)g.B * 4 * g.nch * g.N * g.D;
@@ -303,7 +317,7 @@ void launch_scan(const T *xc, const float *xdbl, const float *dtw, const float *
     const int nw = g.D >= 256 ? 4 : g.D / 64;          // waves (64-channel groups) per workgroup
     dim3 grid(g.nch * (g.D / (64 * nw)), g.B * 4), block(64 * nw);
     const size_t lds = (size_t)g.CL * ((g.CD + 3) & ~3) * sizeof(float);
-    hipLaunchKernelGGL((scan_chunk_kernel<T, N, R, false>), grid, block, lds, s, xc, xdbl, dtw, dtb, A, Ds, y, wsH, wsP, g);
+    hipLaunchKernelGGL((scan_chunk_kernel<T, N, R, false, ODD>), grid, block, lds, s, xc, xdbl, dtw, dtb, A, Ds, y, wsH, wsP, g);
     if (g.nch > 1)
     {
         const int per = (g.nch + SEG - 1) / SEG;
@@ -315,19 +329,22 @@ void launch_scan(const T *xc, const float *xdbl, const float *dtw, const float *
     }
     else
         (void)hipMemsetAsync(wsH, 0, half * sizeof(float), s);
-    hipLaunchKernelGGL((scan_chunk_kernel<T, N, R, true>), grid, block, lds, s, xc, xdbl, dtw, dtb, A, Ds, y, wsH, wsP, g);
+    hipLaunchKernelGGL((scan_chunk_kernel<T, N, R, true, ODD>), grid, block, lds, s, xc, xdbl, dtw, dtb, A, Ds, y, wsH, wsP, g);
 }
 
 template <typename T, int N>
 int dispatch_r(const T *xc, const float *xdbl, const float *dtw, const float *dtb, const float *A,
                const float *Ds, T *y, float *ws, const ScanGeom &g, hipStream_t s) {
+    const bool oddsz = (g.H | g.W) & 1;
+#define FD_SCAN_R(RR)                                                                            \
+    case RR:                                                                                     \
+        if (oddsz) launch_scan<T, N, RR, true>(xc, xdbl, dtw, dtb, A, Ds, y, ws, g, s);          \
+        else launch_scan<T, N, RR, false>(xc, xdbl, dtw, dtb, A, Ds, y, ws, g, s);               \
+        return 0;
     switch (g.R) {
-    case 2: launch_scan<T, N, 2>(xc, xdbl, dtw, dtb, A, Ds, y, ws, g, s); return 0;
-    case 4: launch_scan<T, N, 4>(xc, xdbl, dtw, dtb, A, Ds, y, ws, g, s); return 0;
-    case 8: launch_scan<T, N, 8>(xc, xdbl, dtw, dtb, A, Ds, y, ws, g, s); return 0;
-    case 16: launch_scan<T, N, 16>(xc, xdbl, dtw, dtb, A, Ds, y, ws, g, s); return 0;
-    case 32: launch_scan<T, N, 32>(xc, xdbl, dtw, dtb, A, Ds, y, ws, g, s); return 0;
+        FD_SCAN_R(2) FD_SCAN_R(4) FD_SCAN_R(8) FD_SCAN_R(16) FD_SCAN_R(32)
     }
+#undef FD_SCAN_R
     return -1;
 }
 
@@ -357,7 +374,7 @@ int chunk_len(int L, int D) {
 ScanGeom make_geom(int B, int H, int W, int D, int N, int R) {
     ScanGeom g;
     g.B = B; g.H = H; g.W = W; g.D = D; g.N = N; g.R = R; g.CD = R + 2 * N;
-    g.H2 = H / 2; g.W2 = W / 2; g.L = g.H2 * g.W2;
+    g.H2 = (H + 1) / 2; g.W2 = (W + 1) / 2; g.L = g.H2 * g.W2;     // odd sizes: padded sub-grids (src/emamba2.py:191-199)
     g.CL = chunk_len(g.L, D);
     g.nch = (g.L + g.CL - 1) / g.CL;
     return g;
@@ -374,7 +391,7 @@ extern "C" int fd_selective_scan(int dtype, const void *xc, const float *xdbl, c
                                  const float *dtb, const float *A, const float *Ds, void *y, float *ws,
                                  int B, int H, int W, int D, int N, int R, void *stream) {
     FD_REQUIRE(xc && xdbl && dtw && dtb && A && Ds && y && ws, "fd_selective_scan: null pointer");
-    FD_REQUIRE(H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "fd_selective_scan: H,W must be even (got %d,%d)", H, W);
+    FD_REQUIRE(H > 0 && W > 0, "fd_selective_scan: bad image size %d x %d", H, W);
     FD_REQUIRE(D % 64 == 0, "fd_selective_scan: d_inner=%d must be a multiple of 64", D);
     FD_REQUIRE((int64_t)H * W * D * 4 < (1ll << 31), "fd_selective_scan: one image must stay below 2^31 bytes");
     ScanGeom g = make_geom(B, H, W, D, N, R);

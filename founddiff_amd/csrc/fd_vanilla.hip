@@ -150,37 +150,176 @@ __global__ void softmax_heads_kernel(T *__restrict__ x, int ld, int off, int hea
     for (int c = 0; c < 32; ++c) st1(p + c, v[c] * inv);
 }
 
-// Softmax attention, dim_head 32: one lane per query, keys/values streamed wave-uniformly with an
-// online softmax (fp32).  qkv [B, n, 3*hidden]; out [B, n, hidden].
+// Softmax attention, dim_head 32 (src/denoising_diffusion_pytorch.py:257-279), flash-style on the matrix cores:
+//   * a workgroup owns 128 queries of one (batch, head): 4 waves x 2 blocks of 16 queries; the scaled Q fragments
+//     stay in registers for the whole kernel;
+//   * K / V stream through LDS in tiles of 64 keys shared by the 4 waves: K as [key][32 d] rows (the A operand of
+//     S^T = K Q^T is a plain 16-byte row read), V TRANSPOSED as [d][key] (the A operand of O^T = V^T P^T is two
+//     8-byte reads of 4 consecutive keys);
+//   * everything is computed transposed -- S^T[key][query] and O^T[d][query] -- so that a lane's accumulator
+//     column is ONE query (l % 16) in both products: the online-softmax statistics (running max, sum, rescale)
+//     are per-lane scalars, the 4 lane groups of a query are combined with two xor-shuffles, and the
+//     exponentiated scores are already laid out as the B operand of the second product (the key order inside a
+//     32-key step is the accumulator order, applied to the V^T reads as well): P never moves between lanes;
+//   * bf16: v_mfma_f32_16x16x32_bf16, P rounded to bf16, fp32 accumulation and statistics;
+//     fp32 (parity mode): v_mfma_f32_16x16x4_f32, exact fp32 products.
+// qkv [B, n, 3*hidden]; out [B, n, hidden].
+constexpr int AT_KT = 64, AT_QW = 32, AT_QB = AT_QW / 16;           // key tile, queries per wave, 16-query blocks
+
 template <typename T>
-__global__ __launch_bounds__(64) void attention_rows_kernel(const T *__restrict__ qkv, T *__restrict__ out, int hidden,
-                                                           int64_t n, float scale) {
+__global__ __launch_bounds__(256) void attention_mfma_kernel(const T *__restrict__ qkv, T *__restrict__ out, int hidden,
+                                                            int64_t n, float scale) {
+    constexpr bool BF = sizeof(T) == 2;
+    constexpr int KLD = BF ? 32 : 33;                     // K tile row stride (elements): fp32 rows padded against
+    constexpr int VLD = BF ? AT_KT + 8 : AT_KT + 1;       // bank conflicts of the scalar fragment reads
+    __shared__ __attribute__((aligned(16))) T sK[AT_KT * KLD];
+    __shared__ __attribute__((aligned(16))) T sV[32 * VLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane & 15, g = lane >> 4;
     const int head = blockIdx.y, b = blockIdx.z;
-    const int64_t qi = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const int ld = 3 * hidden;
     const T *base = qkv + (int64_t)b * n * ld;
-    float q[32], o[32];
-    const bool ok = qi < n;
+    const int64_t q0 = (int64_t)blockIdx.x * (4 * AT_QW) + wave * AT_QW;
+    // Q^T fragments (B operand): lane = (query lq, d group g)
+    bf16x8 qb16[AT_QB];
+    float qf[AT_QB][8];
 #pragma unroll
-    for (int c = 0; c < 32; ++c) { q[c] = ok ? ld1(base + qi * ld + head * 32 + c) * scale : 0.f; o[c] = 0.f; }
-    float m = -3.4e38f, l = 0.f;
-    for (int64_t j = 0; j < n; ++j) {
-        const T *kp = base + j * ld + hidden + head * 32;
-        const T *vp = base + j * ld + 2 * hidden + head * 32;
-        float s = 0.f;
+    for (int qb = 0; qb < AT_QB; ++qb) {
+        const int64_t qi = min(q0 + qb * 16 + lq, n - 1);
+        const T *qp = base + qi * ld + head * 32;
+        if constexpr (BF) {
+            float v[8];
+            load8(qp + 8 * g, v);
 #pragma unroll
-        for (int c = 0; c < 32; ++c) s += q[c] * ld1(kp + c);
-        const float mn = fmaxf(m, s);
-        const float corr = __expf(m - mn), pj = __expf(s - mn);
-        l = l * corr + pj;
+            for (int e = 0; e < 8; ++e) qb16[qb][e] = (bf16)(v[e] * scale);
+        } else {
 #pragma unroll
-        for (int c = 0; c < 32; ++c) o[c] = o[c] * corr + pj * ld1(vp + c);
-        m = mn;
+            for (int s = 0; s < 8; ++s) qf[qb][s] = (float)qp[4 * s + g] * scale;      // k-step s: d = 4 s + g
+        }
     }
-    if (ok) {
-        const float inv = 1.f / l;
+    f32x4 o[AT_QB][2];
+    float m[AT_QB], l[AT_QB];
 #pragma unroll
-        for (int c = 0; c < 32; ++c) st1(out + ((int64_t)b * n + qi) * hidden + head * 32 + c, o[c] * inv);
+    for (int qb = 0; qb < AT_QB; ++qb) {
+        o[qb][0] = o[qb][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        m[qb] = -3.0e38f;
+        l[qb] = 0.f;
+    }
+    for (int64_t k0 = 0; k0 < n; k0 += AT_KT) {
+        // ---- stage the tile: thread = (key tid / 4, 8 d values tid % 4); keys past n are zero rows
+        {
+            const int key = tid >> 2, c = tid & 3;
+            float kv[8], vv[8];
+            if (k0 + key < n) {
+                load8(base + (k0 + key) * ld + hidden + head * 32 + 8 * c, kv);
+                load8(base + (k0 + key) * ld + 2 * hidden + head * 32 + 8 * c, vv);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) kv[e] = vv[e] = 0.f;
+            }
+            __syncthreads();                               // the previous tile's reads are done
+            if constexpr (BF) store8(&sK[key * KLD + 8 * c], kv);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sK[key * KLD + 8 * c + e] = kv[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sV[(8 * c + e) * VLD + key] = (T)vv[e];
+            __syncthreads();
+        }
+#pragma unroll
+        for (int kb = 0; kb < AT_KT / 32; ++kb) {
+            // ---- S^T for two 16-key blocks: rows = keys (4 g + i), column = query lq
+            f32x4 st[AT_QB][2];
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                const int krow = kb * 32 + blk * 16 + lq;
+                if constexpr (BF) {
+                    const bf16x8 ka = *(const bf16x8 *)&sK[krow * KLD + 8 * g];
+#pragma unroll
+                    for (int qb = 0; qb < AT_QB; ++qb)
+                        st[qb][blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qb16[qb], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int qb = 0; qb < AT_QB; ++qb) st[qb][blk] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) {
+                        const float ka = sK[krow * KLD + 4 * s + g];
+#pragma unroll
+                        for (int qb = 0; qb < AT_QB; ++qb)
+                            st[qb][blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka, qf[qb][s], st[qb][blk], 0, 0, 0);
+                    }
+                }
+            }
+            // ---- online softmax per query (= per lane column), keys past n masked
+            bf16x8 pb[AT_QB];
+            float pf[AT_QB][8];
+#pragma unroll
+            for (int qb = 0; qb < AT_QB; ++qb) {
+                float sv[8], mx = -3.0e38f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int64_t key = k0 + kb * 32 + (e >> 2) * 16 + 4 * g + (e & 3);
+                    sv[e] = key < n ? st[qb][e >> 2][e & 3] : -3.0e38f;
+                    mx = fmaxf(mx, sv[e]);
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float mn = fmaxf(m[qb], mx);
+                const float corr = __expf(m[qb] - mn);
+                float rs = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float pe = __expf(sv[e] - mn);
+                    pf[qb][e] = pe;
+                    rs += pe;
+                }
+                rs += __shfl_xor(rs, 16, 64);
+                rs += __shfl_xor(rs, 32, 64);
+                l[qb] = l[qb] * corr + rs;
+                m[qb] = mn;
+#pragma unroll
+                for (int dblk = 0; dblk < 2; ++dblk) o[qb][dblk] *= corr;
+                if constexpr (BF) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pb[qb][e] = (bf16)pf[qb][e];
+                }
+            }
+            // ---- O^T += V^T P^T: rows = d, k = the 32 keys in accumulator order (e < 4: key 4 g + e; e >= 4: 16 + 4 g + e - 4)
+#pragma unroll
+            for (int dblk = 0; dblk < 2; ++dblk) {
+                const T *vrow = &sV[(dblk * 16 + lq) * VLD + kb * 32 + 4 * g];
+                if constexpr (BF) {
+                    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+                    const bf16x4 v0 = *(const bf16x4 *)vrow, v1 = *(const bf16x4 *)(vrow + 16);
+                    const bf16x8 va = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+                    for (int qb = 0; qb < AT_QB; ++qb)
+                        o[qb][dblk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pb[qb], o[qb][dblk], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {          // k-step e: lane group g contributes key (e < 4 ? 4 g + e : 16 + 4 g + e - 4)
+                        const float va = vrow[(e >> 2) * 16 + (e & 3)];
+#pragma unroll
+                        for (int qb = 0; qb < AT_QB; ++qb)
+                            o[qb][dblk] = __builtin_amdgcn_mfma_f32_16x16x4f32(va, pf[qb][e], o[qb][dblk], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // ---- O^T[d = dblk*16 + 4 g + i][query lq] / l -> out[query][head*32 + d]: 4 consecutive d per lane
+#pragma unroll
+    for (int qb = 0; qb < AT_QB; ++qb) {
+        const int64_t qi = q0 + qb * 16 + lq;
+        if (qi >= n) continue;
+        const float inv = 1.f / l[qb];
+#pragma unroll
+        for (int dblk = 0; dblk < 2; ++dblk) {
+            T *op = out + ((int64_t)b * n + qi) * hidden + head * 32 + dblk * 16 + 4 * g;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) st1(op + i, o[qb][dblk][i] * inv);
+        }
     }
 }
 
@@ -268,13 +407,14 @@ extern "C" int fd_linear_attention(int dtype, void *qkv, int B, int64_t hw, int 
 }
 
 extern "C" int fd_attention(int dtype, const void *qkv, void *out, int B, int64_t n, int hidden, void *stream) {
-    FD_REQUIRE(qkv && out && hidden % 32 == 0, "fd_attention: bad args");
-    dim3 grid((unsigned)((n + 63) / 64), hidden / 32, B), block(64);
+    FD_REQUIRE(qkv && out && hidden % 32 == 0 && n > 0, "fd_attention: bad args");
+    FD_REQUIRE(hidden % 8 == 0, "fd_attention: hidden must be a multiple of 8");
+    dim3 grid((unsigned)((n + 4 * AT_QW - 1) / (4 * AT_QW)), hidden / 32, B), block(256);
     if (dtype == FD_BF16)
-        hipLaunchKernelGGL(attention_rows_kernel<bf16>, grid, block, 0, (hipStream_t)stream, (const bf16 *)qkv, (bf16 *)out,
+        hipLaunchKernelGGL(attention_mfma_kernel<bf16>, grid, block, 0, (hipStream_t)stream, (const bf16 *)qkv, (bf16 *)out,
                            hidden, n, 0.17677669529663687f);
     else
-        hipLaunchKernelGGL(attention_rows_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float *)qkv,
+        hipLaunchKernelGGL(attention_mfma_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float *)qkv,
                            (float *)out, hidden, n, 0.17677669529663687f);
     FD_LAUNCH_OK("fd_attention");
     return FD_OK;

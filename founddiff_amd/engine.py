@@ -383,11 +383,14 @@ class DAEngine:
                    B, H, W, D, s)
         self._pr(tag + ".xc", xc)
         self._pr(tag + ".z", xz[..., D:])
-        Lq = (H // 2) * (W // 2)
+        # odd H / W: the four sub-grids are those of the image zero-padded to even sizes (src/emamba2.py:191-199);
+        # the x_proj gather zero-fills the positions outside the image, the scan treats them as padding
+        H2, W2 = (H + 1) // 2, (W + 1) // 2
+        Lq = H2 * W2
         xdbl = self._b("xdbl", (4, B, Lq, CD), torch.float32)
         self.conv(None, xc, B, H, W, xdbl, c0=D, weight=m["x_proj"], bias=None, Cout=CD, KH=1, KW=1, stride=2,
                   pad=0, ndir=4, w_dir_stride=CD * D, out_dir_stride=B * Lq * CD, out_f32=True,
-                  OH=H // 2, OW=W // 2)
+                  OH=H2, OW=W2)
         self._pr(tag + ".xdbl", xdbl)
         nws = L.lib().fd_scan_ws_floats(B, H, W, D, N)
         ws = self._b("scan_ws", (nws,), torch.float32)
@@ -548,8 +551,8 @@ class DAEngine:
         B, _, H, W = x_t.shape
         nd = len(self.downs)
         div = 2 ** sum(1 for d in self.downs if d["stride"] == 2)
-        if H % (2 * div) or W % (2 * div):
-            raise ValueError(f"H,W must be multiples of {2 * div} (got {H}x{W})")
+        if H % div or W % div:       # what the reference's own down / up-sampling needs (skip shapes must match)
+            raise ValueError(f"H,W must be multiples of {div} (got {H}x{W})")
         s = self.stream
         self.time_cond(time)
         r = self._b("r", (B, H, W, self.dim))

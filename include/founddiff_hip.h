@@ -163,7 +163,9 @@ int fd_pw_dw3x3(int dtype, const void *x, int ld_x, int off_x, int Cin, const fl
 /* ---- SS2D selective scan (replaces selective_scan_cuda_core.fwd, src/emamba2.py:154, together
  * with EfficientScan/EfficientMerge index maps 182-262, dt_proj einsum 340, softplus/bias).
  *   xc    [B,H,W,D]    (dtype)  dwconv+SiLU output, D = d_inner = 2C
- *   xdbl  [4,B,L,CD]   fp32     x_proj output per direction, CD = R + 2N, row l' = h'*W/2 + w'
+ *   xdbl  [4,B,L,CD]   fp32     x_proj output per direction, CD = R + 2N, row l' = h'*ceil(W/2) + w',
+ *                               L = ceil(H/2)*ceil(W/2); odd H / W: the reference's zero padding (src/emamba2.py:
+ *                               191-199, 253-260) -- rows of sub-grid positions outside the image must be zero
  *   dtw   [4,D,R], dtb [4,D], A [4*D,N] (= -exp(A_logs)), Ds [4*D]   fp32
  *   y     [B,H,W,D]    (dtype)  written at the merged pixel positions
  *   ws    fp32 workspace of fd_scan_ws_floats(...) floats

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generate tests/golden/*.npz by running the REFERENCE itself (CPU, this container only).
 
-    python tests/golden/make_golden.py [schedule|modules|e2e_da|e2e_variants|e2e_vanilla|full64|all]
+    python tests/golden/make_golden.py [schedule|modules|modules_odd|e2e_da|e2e_variants|e2e_vanilla|full64|all]
 
 Each fixture is data only: seeded inputs, the reference's outputs, and the {key: shape} spec +
 seed from which founddiff_amd.synth regenerates the exact weights that were loaded into the
@@ -163,6 +163,26 @@ def g_modules(D):
     _, dose, ctx = iqa(x)
     arrs["iqa.in"], arrs["iqa.dose"], arrs["iqa.ctx"] = x[:, :1], dose, ctx
     save("modules", spec=spec, **arrs)
+
+
+def g_modules_odd(D):
+    """SS2D and Mamba_block at ODD image sizes: the reference pads the image to even sizes before the 4-way gather
+    and crops after the merge (src/emamba2.py:191-199, 253-260)."""
+    from src import emamba2 as E
+    arrs, spec = {}, {}
+    for tag, C, N, hw in (("c32n4", 32, 4, (7, 9)), ("c64n32", 64, 32, (5, 6)), ("c32n16", 32, 16, (10, 7))):
+        m = E.SS2D(d_model=C, d_state=N, expand=2.0, dropout=0).eval()
+        spec.update(load_synth(m, prefix=f"ss2d_{tag}."))
+        x = rnd(2, hw[0], hw[1], C, seed=41)
+        c = rnd(2, 1, 256, seed=42)
+        arrs[f"ss2d_{tag}.x"], arrs[f"ss2d_{tag}.c"], arrs[f"ss2d_{tag}.out"] = x, c, m(x, c)
+    for tag, C, N, hw in (("c32", 32, 4, (9, 7)), ("c64", 64, 8, (5, 5))):
+        mb = D.Mamba_block(hidden_size=C, d_state=N, expand=2.0, dropout=0, cross=False, time_emb_dim=128).eval()
+        spec.update(load_synth(mb, prefix=f"mamba_{tag}."))
+        x, c, t = rnd(2, C, hw[0], hw[1], seed=43), rnd(2, 1, 256, seed=44), rnd(2, 128, seed=45)
+        arrs[f"mamba_{tag}.x"], arrs[f"mamba_{tag}.c"], arrs[f"mamba_{tag}.t"] = x, c, t
+        arrs[f"mamba_{tag}.out"] = mb(x, c, t)
+    save("modules_odd", spec=spec, **arrs)
 
 
 def g_modules_vanilla(D):
@@ -373,6 +393,8 @@ if __name__ == "__main__":
         if what in ("modules", "all"):
             g_modules(D)
             g_modules_vanilla(D)
+        if what in ("modules_odd", "all"):
+            g_modules_odd(D)
         if what in ("e2e_da", "all"):
             g_e2e_da(D)
         if what in ("e2e_variants", "all"):

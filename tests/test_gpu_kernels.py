@@ -221,8 +221,12 @@ def test_dwconv_avgpool_gn(eng_factory, mode, tol):
     assert rel_err(nchw(o3), ref) < tol
 
 
+# odd H and / or W: the reference's pad-to-even / crop (src/emamba2.py:191-199, 253-260) as index arithmetic
+ODD_SHAPES = [(64, 4, 4, 15, 24), (64, 8, 2, 9, 7), (128, 32, 8, 13, 11), (128, 4, 4, 16, 37), (256, 16, 16, 63, 65)]
+
+
 @pytest.mark.parametrize("mode,tol", MODES)
-@pytest.mark.parametrize("cfg", [(64, 4, 4, 16, 24), (64, 8, 2, 8, 8), (128, 32, 8, 12, 10), (256, 16, 16, 64, 64)] + BLOCK_SHAPES)
+@pytest.mark.parametrize("cfg", [(64, 4, 4, 16, 24), (64, 8, 2, 8, 8), (128, 32, 8, 12, 10), (256, 16, 16, 64, 64)] + BLOCK_SHAPES + ODD_SHAPES)
 def test_selective_scan(eng_factory, mode, tol, cfg):
     """HIP chunked scan (fused gather/dt_proj/softplus/merge) vs the sequential CPU oracle."""
     from founddiff_amd import _lib as L
@@ -231,7 +235,8 @@ def test_selective_scan(eng_factory, mode, tol, cfg):
     D, N, R, H, W = cfg
     torch.manual_seed(5)
     B, CD = 2, R + 2 * N
-    Lq = (H // 2) * (W // 2)
+    H2, W2 = (H + 1) // 2, (W + 1) // 2
+    Lq = H2 * W2
     xc = rq(torch.randn(B, D, H, W) * 0.5, mode)
     xdbl = torch.randn(4, B, Lq, CD)
     dtw = (torch.rand(4, D, R) * 2 - 1) * R ** -0.5
@@ -240,7 +245,7 @@ def test_selective_scan(eng_factory, mode, tol, cfg):
     Ds = 1 + 0.1 * torch.randn(4 * D)
     # oracle on the explicitly gathered tensors
     xs = nets.efficient_scan(xc)                                                    # (B,4,D,L) in scan order
-    xd = xdbl.permute(1, 0, 2, 3).reshape(B, 4, H // 2, W // 2, CD)
+    xd = xdbl.permute(1, 0, 2, 3).reshape(B, 4, H2, W2, CD)
     xd_scan = torch.stack([xd[:, 0].reshape(B, Lq, CD), xd[:, 1].transpose(1, 2).reshape(B, Lq, CD),
                            xd[:, 2].reshape(B, Lq, CD), xd[:, 3].transpose(1, 2).reshape(B, Lq, CD)], 1)
     dts = torch.einsum("bklr,kdr->bkdl", xd_scan[..., :R], dtw)

@@ -104,3 +104,27 @@ def test_vanilla_bf16_runs(golden):
     g, dif = _model(golden, "pred_noise", 10, precision="bf16")
     res = dif.sample(batch_size=2, noise=g["ddim.pred_noise.xT"].cuda())
     assert torch.isfinite(res[0]).all()
+
+
+@pytest.mark.parametrize("mode,tol", [("fp32", 2e-5), ("bf16", 1.5e-2)])
+@pytest.mark.parametrize("n", [50, 1000, 1024, 4096])
+def test_attention_mfma(mode, tol, n):
+    """fd_attention (MFMA flash attention, dim_head 32, K/V tiles in LDS; src/denoising_diffusion_pytorch.py:257-279)
+    against softmax(q k^T * 32^-0.5) v in fp32: token counts that are not multiples of the 64-key tile / the
+    128-query workgroup, and the 4096 tokens of the 512x512 bottleneck."""
+    from founddiff_amd import _lib as L
+    from founddiff_amd.engine import _T
+    dt, tdt = _T[mode]
+    torch.manual_seed(n)
+    B, heads, hidden = 2, 4, 128
+    qkv = torch.randn(B, n, 3 * hidden) * 1.5
+    if mode == "bf16":
+        qkv = qkv.to(torch.bfloat16).float()
+    q, k, v = [t.reshape(B, n, heads, 32).permute(0, 2, 1, 3) for t in qkv.chunk(3, dim=-1)]
+    attn = torch.softmax((q * 32 ** -0.5) @ k.transpose(-1, -2), dim=-1)
+    ref = (attn @ v).permute(0, 2, 1, 3).reshape(B, n, hidden)
+    qd = qkv.to("cuda", tdt).contiguous()
+    out = torch.empty(B, n, hidden, device="cuda", dtype=tdt)
+    L.call("fd_attention", dt, qd.data_ptr(), out.data_ptr(), B, n, hidden, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert rel_err(out.float().cpu(), ref) < tol

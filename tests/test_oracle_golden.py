@@ -94,6 +94,24 @@ def test_mamba_block(golden, tag):
     assert rel_err(out, g[p + "out"]) < TOL
 
 
+@pytest.mark.parametrize("tag", ["c32n4", "c64n32", "c32n16"])
+def test_ss2d_odd_sizes(golden, tag):
+    """odd H / W: the reference's pad-to-even before the gather and crop after the merge (src/emamba2.py:191-199,
+    253-260), SS2D outputs captured from the reference at 7x9, 5x6, 10x7."""
+    g = golden("modules_odd")
+    p = f"ss2d_{tag}."
+    sd = nets.SD(g.weights(p), p)
+    assert rel_err(nets.ss2d(sd, g[p + "x"], g[p + "c"]), g[p + "out"]) < TOL
+
+
+@pytest.mark.parametrize("tag", ["c32", "c64"])
+def test_mamba_block_odd_sizes(golden, tag):
+    g = golden("modules_odd")
+    p = f"mamba_{tag}."
+    sd = nets.SD(g.weights(p), p)
+    assert rel_err(nets.mamba_block(sd, g[p + "x"], g[p + "c"], g[p + "t"]), g[p + "out"]) < TOL
+
+
 def test_samplers_conv(golden):
     g = golden("modules")
     import torch.nn.functional as F
