@@ -202,6 +202,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-fp32-leg", action="store_true")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp8"],
+                    help="fp8: BASELINE configs[4] -- e4m3 weights on the fp8 MFMA for the 3x3 convs; a separate "
+                         "variant, never the headline")
+    ap.add_argument("--ddim-steps", type=int, default=S_DDIM, help="25 with --precision fp8 reproduces configs[4]")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -219,7 +223,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from founddiff_amd import parallel, synth
-    dif, w = build_model(dev)
+    dif, w = build_model(dev, steps=a.ddim_steps, precision=a.precision)
     B = a.batch
     # global slice range sharded contiguously over ranks; per-slice noise keyed by GLOBAL index
     lo, hi = parallel.shard_range(world * B, world, rank)
@@ -253,20 +257,27 @@ def main():
     if rank == 0:
         slices = world * B * a.steps
         res = {
-            "metric": "denoised CT slices/sec (512x512, 50 DDIM steps)",
+            "metric": f"denoised CT slices/sec (512x512, {a.ddim_steps} DDIM steps)",
             "value": round(slices / dt, 4), "unit": "slices/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": ("bf16" if a.precision == "bf16" else "bf16 activations, e4m3 weights (fp8 MFMA) in the 3x3 convs")
+                     + (f"; last {dif.final_fp32_steps} step(s) one precision class up ({'fp32' if a.precision == 'bf16' else 'bf16'})"
+                        if dif.final_fp32_steps else ""),
+            "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: 512x512 slice, 50-step DDIM, full FoundDiff UNet "
                                    "(dim 64, mults 1-2-4-8) + DA-CLIP RN50 cond, bf16",
                        "slices_per_gpu_per_step": B, "sharding": f"slices over {world} rank(s), no data-path "
                        "collective; 1 all-gather of the output volume"},
-            "ms_per_unet_forward_per_slice": round(dt / a.steps / S_DDIM / B * 1e3, 3),
-            "alg_tflops_sustained": round(ALG_GFLOP_PER_FORWARD * S_DDIM * slices / dt / 1e3, 1),
+            "ms_per_unet_forward_per_slice": round(dt / a.steps / a.ddim_steps / B * 1e3, 3),
+            "alg_tflops_sustained": round(ALG_GFLOP_PER_FORWARD * a.ddim_steps * slices / dt / 1e3, 1),
         }
-        if not a.no_roofline:
+        if a.precision != "bf16" or a.ddim_steps != S_DDIM:
+            res["config"]["workload"] = (f"BASELINE configs[4] geometry: 512x512 slice, {a.ddim_steps}-step DDIM, full FoundDiff "
+                                         f"UNet + DA-CLIP RN50 cond, precision {a.precision}")
+        if not a.no_roofline and a.precision == "bf16":
             res["roofline"] = roofline_leg(dif, x, noise)
-        if world == 1 and not a.no_fp32_leg:
+        if world == 1 and not a.no_fp32_leg and a.precision == "bf16":
             res["fp32_parity_mode"] = fp32_parity_leg(dev, x, noise)
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline_leg(w, x, noise)

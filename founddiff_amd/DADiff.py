@@ -95,8 +95,8 @@ def _build_tree(root, spec):
 
 class Unet(_ParamTree):
     """DA-CLIP conditioned U-Net (reference src/DADiff.py:530-740).  `condition` is forced on
-    as in the reference (line 588).  Extra kwargs: `precision` ('bf16' | 'fp32') selects the
-    kernel mode; `clip_cfg` overrides the RN50 DA-CLIP geometry (tests use a shrunken one)."""
+    as in the reference (line 588).  Extra kwargs: `precision` ('bf16' | 'fp32' | 'fp8': bf16 kernels with e4m3
+    weights on the fp8 MFMA for the 3x3 convolutions, BASELINE configs[4]) selects the kernel mode; `clip_cfg` overrides the RN50 DA-CLIP geometry (tests use a shrunken one)."""
 
     def __init__(self, dim, init_dim=None, out_dim=None, dim_mults=(1, 2, 4, 8), channels=1,
                  self_condition=False, resnet_block_groups=8, learned_variance=False,
@@ -533,11 +533,13 @@ class ResidualDiffusion(nn.Module):
 
     # ---- the per-step hot loop: graph-captured UNet forward + one scheduler kernel
     def _tail_engine(self, eng):
-        """(K, fp32 engine or None): the engine of the last K steps of a loop (final_fp32_steps)."""
+        """(K, engine or None): the higher-precision engine of the last K steps of a loop (final_fp32_steps):
+        fp32 behind the bf16 kernels, bf16 behind the fp8-weight kernels (one precision class up; the fp8 mode is
+        the throughput configuration, BASELINE configs[4])."""
         K = self.final_fp32_steps if eng.mode != "fp32" else 0
         if K <= 0:
             return 0, None
-        e32 = self.model.unet0.engine("fp32")
+        e32 = self.model.unet0.engine("fp32" if eng.mode == "bf16" else "bf16")
         e32.share_condition(eng)
         return K, e32
 

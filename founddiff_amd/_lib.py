@@ -39,6 +39,7 @@ class ConvParams(C.Structure):
         ("prologue", i32), ("ln_eps", f32),
         ("ln_gamma", vp), ("ln_beta", vp), ("ln_shift", vp), ("ln_scale", vp), ("ln_ld", i32),
         ("ln_z", vp), ("ln_ldz", i32), ("ln_offz", i32),
+        ("weight_f8", vp), ("w_scale", vp), ("act_scale", f32),
     ]
 
 
@@ -50,6 +51,7 @@ SIGNATURES = {
     "fd_conv2d": (i32, [C.POINTER(ConvParams), vp]),
     "fd_conv_prologue_ok": (i32, [C.POINTER(ConvParams)]),
     "fd_conv_kernel_id": (i32, [C.POINTER(ConvParams)]),
+    "fd_conv_fp8_ok": (i32, [C.POINTER(ConvParams)]),
     "fd_gn_finalize": (i32, [vp, i32, i32, i32, i32, i64, f32, vp, vp]),
     "fd_gn_silu_apply": (i32, [i32, vp, vp, vp, vp, vp, vp, i32, i64, i32, i32, vp]),
     "fd_ln_modulate": (i32, [i32, vp, vp, vp, f32, vp, vp, i32, vp, i32, i64, i32, vp]),

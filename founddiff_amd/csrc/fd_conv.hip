@@ -568,13 +568,16 @@ extern "C" int fd_conv_mtiles(int OH, int OW) { return cdiv((int64_t)OH * OW, 64
 
 int fd_gemm_rows_launch(const fd_conv_params &p, hipStream_t s);
 int fd_conv3x3_ok(const fd_conv_params &p);
+int fd_conv3x3_fp8_ok(const fd_conv_params &p);
 int fd_conv3x3_launch(const fd_conv_params &p, hipStream_t s);
 
 // Which kernel fd_conv2d dispatches `p` to: 10 streaming row-GEMM, 11 halo-tiled 3x3, else the
 // implicit-GEMM tile variant 0 <128,128>, 1 <128,64>, 2 <64,128>, 3 <64,64>, 4 <128,256>, 5 <256,256>, 6 <128,32> (BM, BN).
+extern "C" int fd_conv_fp8_ok(const fd_conv_params *pp) { return pp && !fd_conv_prologue_ok(pp) && fd_conv3x3_fp8_ok(*pp); }
+
 extern "C" int fd_conv_kernel_id(const fd_conv_params *pp) {
     if (fd_conv_prologue_ok(pp)) return 10;
-    if (fd_conv3x3_ok(*pp)) return 11;
+    if (fd_conv3x3_ok(*pp)) return fd_conv3x3_fp8_ok(*pp) ? 12 : 11;
     const bool wide = pp->Cout > 64, tall = conv_bm((int64_t)pp->OH * pp->OW) == 128;
     // 8-wave 128x256 tile (id 4) for the dense layers of the 64x64 / 128x128 levels: it halves the operand
     // traffic from beyond L2 (+15..30 % at batch 8) but launches 4x fewer workgroups, so it is chosen only

@@ -27,10 +27,22 @@ __device__ __forceinline__ int swz(int row, int chunk) { return (chunk ^ ((row >
 //   <128, 8>   Cout > 64:  2 (row groups) x 2 (channel halves) waves
 //   <64, 16>   Cout <= 64: 4 row groups, each wave all 64 channels (halo overhead 1.27x instead of 1.41x)
 //   <64, 8>    Cout <= 64 when OH is not a multiple of 16: 2 x 2 waves of 64 px x 32 channels
-template <int BN, int TH>
+// F8 (fp8 weights, BASELINE configs[4]): the same tile and ring with the K axis in 128-channel slabs.  A halo pixel
+// row is still 128 bytes -- 128 e4m3 channels instead of 64 bf16 -- so the LDS image, its swizzle and the weight
+// tiles ([BN rows][128 bytes] of the e4m3 matrix) keep their byte geometry.  The bf16 halo is converted (x act_scale)
+// once per slab on its way into LDS; a lane's operand of v_mfma_scale_f32_16x16x128_f8f6f4 is 32 consecutive
+// channels = two adjacent 16-byte chunks (same slot order for A and B: tools/probes/mfma_fp8_layout.hip), block
+// scales 1.0 (e8m0 127); the per-output-channel weight scale is applied in the epilogue.  Per channel this is half
+// the LDS fragment bytes, half the weight DMA and a quarter of the MFMA instructions of the bf16 form.
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+
+template <int BN, int TH, bool F8>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_params p) {
     constexpr int BM = TH * TW, HY = TH + 2, HP = HY * HX;
-    constexpr int HL = (HP * 8 + 255) / 256;          // halo 16-byte chunks per thread
+    constexpr int HL = (HP * 8 + 255) / 256;          // halo 16-byte LDS chunks per thread
+    constexpr int SLABC = F8 ? 128 : 64;              // channels per K slab
+    constexpr int HG = F8 ? 2 : 1;                    // 16-byte global loads per LDS chunk
+    constexpr int ESZ = F8 ? 1 : 2;                   // bytes per weight element
     constexpr int WMW = TH / 4, WNW = 4 / WMW;        // wave grid
     constexpr int NB = BN / 32, NT = BN / WNW / 16, MT = 4;
     constexpr int HALO_B = HP * ROWB;                 // 23040
@@ -45,11 +57,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
     const int tiles_x = p.OW / TW;
     const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
     const int nt = blockIdx.y, b = blockIdx.z;
-    const int Cin = p.c0 + p.c1, K = 9 * Cin, nslab = Cin / 64;
+    const int Cin = p.c0 + p.c1, K = 9 * Cin, nslab = Cin / SLABC;
     const int Hs = p.OH, Ws = p.OW;                   // conv input grid == output grid (stride 1, pad 1)
     const bf16 *in0 = (const bf16 *)p.in0 + (int64_t)b * p.H * p.W * p.ld0 + p.off0;
     const bf16 *in1 = p.in1 ? (const bf16 *)p.in1 + (int64_t)b * p.H * p.W * p.ld1 + p.off1 : nullptr;
-    const bf16 *wgt = (const bf16 *)p.weight;
+    const unsigned char *wgt = (const unsigned char *)(F8 ? p.weight_f8 : p.weight);
 
     // ---- halo loader: chunk ids hid = tid + 256*i -> (halo pixel, 16-byte channel chunk)
     // Every load is issued (from a clamped in-image address, zeroed on the LDS store where it was
@@ -68,15 +80,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
         if (p.upsample) { y >>= 1; x >>= 1; }
         hoff[i] = y * p.W + x;
     }
-    u32x4 rh[HL];
+    u32x4 rh[HL][HG];
     auto halo_gload = [&](int slab) {
-        const int c = slab * 64 + (tid & 7) * 8;
+        const int c = slab * SLABC + (tid & 7) * (SLABC / 8);     // a thread's 8 (16) channels come from ONE source
         const bf16 *src;
         int ld, cc;
         if (c < p.c0) { src = in0; ld = p.ld0; cc = c; }
         else { src = in1; ld = p.ld1; cc = c - p.c0; }
 #pragma unroll
-        for (int i = 0; i < HL; ++i) rh[i] = *(const u32x4 *)(src + (int64_t)hoff[i] * ld + cc);
+        for (int i = 0; i < HL; ++i)
+#pragma unroll
+            for (int h = 0; h < HG; ++h) rh[i][h] = *(const u32x4 *)(src + (int64_t)hoff[i] * ld + cc + 8 * h);
+    };
+    // two bf16 (one dword) -> two e4m3 bytes in the low / high half of `acc`
+    auto cvt2 = [&](uint32_t w, uint32_t acc, bool hi) -> uint32_t {
+        // e4m3fn has no infinity: clamp to its largest finite value (448) instead of letting an outlier become NaN
+        const float a = __builtin_amdgcn_fmed3f(__builtin_bit_cast(float, w << 16) * p.act_scale, -448.f, 448.f);
+        const float b = __builtin_amdgcn_fmed3f(__builtin_bit_cast(float, w & 0xffff0000u) * p.act_scale, -448.f, 448.f);
+        return hi ? (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, (int)acc, true)
+                  : (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, (int)acc, false);
     };
     auto halo_lstore = [&]() {
         unsigned char *sH = smem;
@@ -84,7 +106,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
         for (int i = 0; i < HL; ++i) {
             const int hid = tid + 256 * i, hp = hid >> 3;
             const u32x4 z4 = {0, 0, 0, 0};
-            if (hp < HP) *(u32x4 *)(sH + hp * ROWB + swz(hp, tid & 7)) = ((hvalid >> i) & 1) ? rh[i] : z4;
+            u32x4 v;
+            if constexpr (F8) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const u32x4 s4 = rh[i][h];
+                    v[2 * h] = cvt2(s4[1], cvt2(s4[0], 0u, false), true);
+                    v[2 * h + 1] = cvt2(s4[3], cvt2(s4[2], 0u, false), true);
+                }
+            } else v = rh[i][0];
+            if (hp < HP) *(u32x4 *)(sH + hp * ROWB + swz(hp, tid & 7)) = ((hvalid >> i) & 1) ? v : z4;
         }
     };
     // ---- weight tiles ([BN rows][64 k] of tap t, slab s) by LDS-DMA (global_load_lds_dwordx4): no VGPR
@@ -101,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
         const int r = 8 * (wave * NB + i) + (lane >> 3);
         const int c = (lane & 7) ^ ((r >> 1) & 7);
         const int n = min(nt * BN + r, p.Cout - 1);
-        goff[i] = (unsigned)(n * K + c * 8) * 2u;
+        goff[i] = (unsigned)(n * K * ESZ + c * 16);
     }
     // Issued through inline asm on purpose: for __builtin_amdgcn_global_load_lds on a plain LDS array the
     // compiler's waitcnt pass (no alias scopes to tell the ring slots apart) inserts s_waitcnt vmcnt(0)
@@ -114,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
     const unsigned lds_w = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)smem + HALO_B +
                            __builtin_amdgcn_readfirstlane(wave) * NB * 1024;
     auto w_dma = [&](int slab, int tap, int buf) {
-        const char *wb = (const char *)(wgt + (tap * Cin + slab * 64));
+        const char *wb = (const char *)(wgt + (tap * Cin + slab * SLABC) * ESZ);
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const unsigned dst = lds_w + buf * WT_B + i * 1024;       // wave-uniform: M0
@@ -148,12 +179,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
             const int hp = (4 * wm + j) * HX + fr + kw;
-            aoff[j][kw] = hp * ROWB + swz(hp, fg);
+            aoff[j][kw] = hp * ROWB + swz(hp, F8 ? 2 * fg : fg);        // F8: chunks 2 fg, 2 fg + 1 (= offset ^ 16)
         }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int r = (BN / WNW) * wn + 16 * j + fr;
-        boff[j] = r * ROWB + swz(r, fg);
+        boff[j] = r * ROWB + swz(r, F8 ? 2 * fg : fg);
     }
 
     w_dma(0, 0, 0);
@@ -174,6 +205,31 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
             if (dma) w_dma(tap + 2 < 9 ? slab : slab + 1, (tap + 2) % 9, (tap + 2) % NWB);
             const unsigned char *sB = smem + HALO_B + (tap % NWB) * WT_B;
             const int kh = tap / 3, kw = tap - kh * 3;
+            if constexpr (F8) {
+                // operands are 8 VGPRs each: the A fragments of the wave's 4 m-tiles stay live (32 VGPRs), the B
+                // fragments are read one n-tile at a time (a compiler fence keeps hipcc from hoisting all of them
+                // above the MFMAs, which spilled ~600 registers); 4 MFMAs x 32 cycles cover the next read
+                i32x8 af[MT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const u32x4 lo = *(const u32x4 *)(sH + aoff[i + kh][kw]), hi = *(const u32x4 *)(sH + (aoff[i + kh][kw] ^ 16));
+                    af[i] = (i32x8){(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+                }
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const u32x4 lo = *(const u32x4 *)(sB + boff[j]), hi = *(const u32x4 *)(sB + (boff[j] ^ 16));
+                    const i32x8 bj = (i32x8){(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+                        // inline asm with the accumulator TIED (dst = src C): through the builtin hipcc 7.2 leaves the
+                        // two untied and the register allocator spills ~600 VGPRs.  Hazards by hand: A / B come from
+                        // ds_read (the compiler's s_waitcnt covers asm operands), the same accumulator recurs only
+                        // 4 MFMAs (>= 128 cycles) later, s_nop 1 covers the v_mov of the scale register, and the
+                        // epilogue's first read of the accumulators sits behind the s_nop block after the loop.
+                        asm("s_nop 1\n\tv_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]"
+                            : "+v"(acc[i][j]) : "v"(af[i]), "v"(bj), "v"(0x7f7f7f7f));
+                }
+            } else {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 bf16x8 af[MT], bfr[NT];
@@ -188,11 +244,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
                     for (int j = 0; j < NT; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
             }
+            }
             // tile q+1 (requested one tap ago) must have landed before the barrier publishes it.  vmcnt retires
             // in order: allow exactly the operations issued AFTER that request -- this tap's DMA (NB
             // instructions) and, during the first two taps of a slab, the HL halo loads of the next slab.
             const bool halo_young = tap < 1 && has_next;
-            if (dma) { if (halo_young) FD_WAIT_VM(NB + HL); else FD_WAIT_VM(NB); }
+            if (dma) { if (halo_young) FD_WAIT_VM(NB + HL * HG); else FD_WAIT_VM(NB); }
             else FD_WAIT_VM(0);
             __syncthreads();
             if (last_tap && has_next) {             // every wave is done with this slab's halo
@@ -202,6 +259,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
         }
     }
 #undef FD_WAIT_VM
+    // F8: the last inline-asm MFMAs must have written their accumulators before the epilogue reads them (the
+    // compiler's hazard recognizer does not see into asm); volatile + memory clobber keeps the LDS stores below it
+    if constexpr (F8) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 
     // ---- stage accumulators, row r = tile pixel (ty = r >> 4, tx = r & 15)
     float *sC = (float *)smem;
@@ -219,10 +279,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
     constexpr int VPR = BN / 8, RPP = 256 / VPR;
     const int v = tid % VPR, r0 = tid / VPR;
     const int n0 = nt * BN + v * 8;
-    float bias[8], ssum[8], ssq[8];
+    float bias[8], ssum[8], ssq[8], wsc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         bias[e] = (p.bias && n0 + e < p.Cout) ? p.bias[n0 + e] : 0.f;
+        wsc[e] = (F8 && n0 + e < p.Cout) ? p.w_scale[n0 + e] / p.act_scale : 1.f;
         ssum[e] = ssq[e] = 0.f;
     }
     bf16 *outp = (bf16 *)p.out + (int64_t)b * p.OH * p.OW * p.ldo + p.offo;
@@ -231,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
             const int y = ty0 + (r >> 4), x = tx0 + (r & 15);
             float val[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) val[e] = sC[r * BN + v * 8 + e] + bias[e];
+            for (int e = 0; e < 8; ++e) val[e] = F8 ? sC[r * BN + v * 8 + e] * wsc[e] + bias[e] : sC[r * BN + v * 8 + e] + bias[e];
             if (p.epilogue == FD_EPI_RELU) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) val[e] = fmaxf(val[e], 0.f);
@@ -300,12 +361,26 @@ int fd_conv3x3_ok(const fd_conv_params &p) {
     return 1;
 }
 
+// 1 if `p` carries fp8 weights and runs on the fp8 form of the halo kernel: K axis in 128-channel slabs, each
+// thread's 16 halo channels from one source.
+int fd_conv3x3_fp8_ok(const fd_conv_params &p) {
+    if (!p.weight_f8 || !p.w_scale || !(p.act_scale > 0.f)) return 0;
+    if (!fd_conv3x3_ok(p)) return 0;
+    return (p.c0 + p.c1) % 128 == 0 && p.c0 % 16 == 0 && (p.in1 == nullptr || p.c1 % 16 == 0);
+}
+
 int fd_conv3x3_launch(const fd_conv_params &p, hipStream_t s) {
     const bool wide = p.Cout > 64;
     const int th = (!wide && p.OH % 16 == 0) ? 16 : 8;
     dim3 grid((p.OH / th) * (p.OW / TW), cdiv(p.Cout, wide ? 128 : 64), p.B), block(256);
-    if (wide) hipLaunchKernelGGL((conv3x3_halo_kernel<128, 8>), grid, block, 0, s, p);
-    else if (th == 16) hipLaunchKernelGGL((conv3x3_halo_kernel<64, 16>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((conv3x3_halo_kernel<64, 8>), grid, block, 0, s, p);
+    if (fd_conv3x3_fp8_ok(p)) {
+        if (wide) hipLaunchKernelGGL((conv3x3_halo_kernel<128, 8, true>), grid, block, 0, s, p);
+        else if (th == 16) hipLaunchKernelGGL((conv3x3_halo_kernel<64, 16, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((conv3x3_halo_kernel<64, 8, true>), grid, block, 0, s, p);
+        return 0;
+    }
+    if (wide) hipLaunchKernelGGL((conv3x3_halo_kernel<128, 8, false>), grid, block, 0, s, p);
+    else if (th == 16) hipLaunchKernelGGL((conv3x3_halo_kernel<64, 16, false>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((conv3x3_halo_kernel<64, 8, false>), grid, block, 0, s, p);
     return 0;
 }

@@ -13,7 +13,10 @@ import torch
 
 from . import _lib as L
 
-_T = {"fp32": (L.FD_F32, torch.float32), "bf16": (L.FD_BF16, torch.bfloat16)}
+# 'fp8' (BASELINE configs[4]): bf16 activations and kernels, plus e4m3 weights with one scale per output channel
+# for the convolutions the fp8 MFMA path takes (3x3 halo kernel, K axis in 128-channel slabs)
+_T = {"fp32": (L.FD_F32, torch.float32), "bf16": (L.FD_BF16, torch.bfloat16), "fp8": (L.FD_BF16, torch.bfloat16)}
+FP8_ACT_SCALE = 8.0     # activations are multiplied by this power of two before the e4m3 conversion (|x| <= 56 exact range)
 
 
 def _p(t):
@@ -28,7 +31,7 @@ def _po(t, off_elems):
 class ConvW:
     """Packed convolution / linear weight: [Cout][KH*KW*Cin] in the compute dtype, fp32 bias."""
 
-    def __init__(self, w_oihw, bias, dev, tdt, cin_pad=None):
+    def __init__(self, w_oihw, bias, dev, tdt, cin_pad=None, fp8=False):
         w = w_oihw.detach().float()
         if w.dim() == 2:
             w = w[:, :, None, None]
@@ -37,8 +40,15 @@ class ConvW:
             w = torch.cat([w, w.new_zeros(o, cin_pad - i, kh, kw)], dim=1)
             i = cin_pad
         self.Cout, self.Cin, self.KH, self.KW = o, i, kh, kw
-        self.w = w.permute(0, 2, 3, 1).reshape(o, kh * kw * i).contiguous().to(dev, tdt)
+        wk = w.permute(0, 2, 3, 1).reshape(o, kh * kw * i).contiguous()
+        self.w = wk.to(dev, tdt)
         self.b = bias.detach().float().contiguous().to(dev) if bias is not None else None
+        self.w8 = self.ws = None
+        if fp8 and kh == 3 and kw == 3 and i % 128 == 0:
+            # per-output-channel scaled OCP e4m3 (largest finite value 448): w ~= w8 * ws[n]
+            ws = (wk.abs().amax(dim=1).clamp(min=1e-12) / 448.0)
+            self.w8 = (wk / ws[:, None]).to(torch.float8_e4m3fn).contiguous().to(dev)
+            self.ws = ws.contiguous().to(dev)
 
 
 def ws_standardize(w, eps=1e-5):
@@ -78,9 +88,10 @@ class DAEngine:
         DAEngine._GEN += 1
         self.gen = DAEngine._GEN
         if mode not in _T:
-            raise ValueError(f"mode must be 'fp32' or 'bf16', got {mode!r}")
+            raise ValueError(f"mode must be 'fp32', 'bf16' or 'fp8', got {mode!r}")
         self.mode = mode
         self.dt, self.tdt = _T[mode]
+        self.fp8 = mode == "fp8"
         self.dev = torch.device(device)
         self.f32 = dict(device=self.dev, dtype=torch.float32)
         sd = _Sub(state_dict, prefix)
@@ -93,7 +104,7 @@ class DAEngine:
         return t.detach().float().contiguous().to(self.dev)
 
     def _convw(self, w, b=None, cin_pad=None):
-        return ConvW(w, b, self.dev, self.tdt, cin_pad)
+        return ConvW(w, b, self.dev, self.tdt, cin_pad, fp8=getattr(self, "fp8", False))
 
     def _pack_res(self, s):
         r = {"conv": self._convw(ws_standardize(s["block1.proj.weight"]), s["block1.proj.bias"]),
@@ -310,6 +321,8 @@ class DAEngine:
         p.ln_gamma, p.ln_beta = ptr(ln_gamma), ptr(ln_beta)
         p.ln_shift, p.ln_scale, p.ln_ld = ptr(ln_shift), ptr(ln_scale), ln_ld
         p.ln_z, p.ln_ldz, p.ln_offz = ptr(ln_z), ln_ldz, ln_offz
+        if weight is None and cw is not None and getattr(cw, "w8", None) is not None:
+            p.weight_f8, p.w_scale, p.act_scale = cw.w8.data_ptr(), cw.ws.data_ptr(), FP8_ACT_SCALE
         if probe == "kid":          # which kernel would run (include/founddiff_hip.h: fd_conv_kernel_id)
             return int(L.lib().fd_conv_kernel_id(C.byref(p)))
         if probe:

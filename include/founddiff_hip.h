@@ -96,7 +96,19 @@ typedef struct fd_conv_params {
     int32_t ln_ld;
     const void *ln_z;                  /* LN_GATE: [B,H,W,ln_ldz], channels [ln_offz, +Cin)   */
     int32_t ln_ldz, ln_offz;
+    /* fp8 weights (BASELINE configs[4]): the same [Cout][KH*KW*Cin] matrix as OCP e4m3 bytes,
+     * w_f8[n][k] = e4m3(weight[n][k] / w_scale[n]), one fp32 scale per output channel.  Used by the
+     * 3x3 halo kernel where the K axis splits into 128-channel slabs (fd_conv_fp8_ok): the bf16 halo is
+     * converted to e4m3 (x act_scale, a power of two) once per slab on its way into LDS and the product
+     * runs on v_mfma_scale_f32_16x16x128_f8f6f4 (2x the bf16 rate), fp32 accumulation;
+     * out = acc * w_scale[n] / act_scale + bias.  NULL: bf16 weights.  Other convs ignore these.       */
+    const void *weight_f8;
+    const float *w_scale;
+    float act_scale;
 } fd_conv_params;
+
+/* 1 if fd_conv2d would run `p` (weight_f8 / w_scale set) on the fp8 MFMA path.                        */
+int fd_conv_fp8_ok(const fd_conv_params *p);
 
 #define FD_PRO_NONE 0
 #define FD_PRO_LN_MOD 1
@@ -106,7 +118,7 @@ typedef struct fd_conv_params {
 int fd_conv_prologue_ok(const fd_conv_params *p);
 
 int fd_conv_mtiles(int OH, int OW);         /* number of m-tiles per image (for workspaces)  */
-/* kernel fd_conv2d will run for p: 10 row-GEMM, 11 halo 3x3, 0..6 implicit-GEMM <BM,BN> =
+/* kernel fd_conv2d will run for p: 10 row-GEMM, 11 halo 3x3 (12: its fp8 form), 0..6 implicit-GEMM <BM,BN> =
  * <128,128>, <128,64>, <64,128>, <64,64>, <128,256>, <256,256>, <128,32> (profiling / roofline
  * bookkeeping; ids 4 and 5 depend on the batch size but give bitwise identical outputs)      */
 int fd_conv_kernel_id(const fd_conv_params *p);

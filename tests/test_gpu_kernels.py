@@ -626,3 +626,60 @@ def test_init_conv7(eng_factory, cfg):
     torch.cuda.synchronize()
     assert rel_err(nchw(out), ref) < 4e-3          # output rounding to bf16 only
     assert rel_err(nchw(out)[:, :, :3], ref[:, :, :3]) < 6e-3 and rel_err(nchw(out)[..., -3:], ref[..., -3:]) < 6e-3
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(c0=128, c1=0, cout=128, hw=(64, 64)),                 # <128,8>: 2 x 2 waves
+    dict(c0=256, c1=0, cout=64, hw=(64, 64)),                  # <64,16>
+    dict(c0=64, c1=64, cout=64, hw=(72, 64)),                  # <64,8>, two sources inside one 128-channel slab
+    dict(c0=256, c1=128, cout=200, hw=(64, 64)),               # three slabs, second source, ragged Cout
+    dict(c0=128, c1=0, cout=64, hw=(32, 32), up=True),         # nearest x2 up-sampling in the halo index map
+])
+def test_conv3x3_fp8_weights(eng_factory, cfg):
+    """BASELINE configs[4]: e4m3 weights (one scale per output channel) on v_mfma_scale_f32_16x16x128_f8f6f4 in the
+    3x3 halo kernel.  Checked EXACTLY against the same arithmetic on the CPU: activations x act_scale -> e4m3,
+    weights / scale -> e4m3, fp32 products and sums -- what remains is the accumulation order and the bf16 rounding
+    of the output.  Also against the unquantised conv within the e4m3 rounding noise."""
+    from founddiff_amd import engine as E
+    e = eng_factory("fp8")
+    e.fp8 = True
+    torch.manual_seed(3)
+    B = 2
+    H, W = cfg["hw"]
+    c0, c1, co = cfg["c0"], cfg["c1"], cfg["cout"]
+    cin = c0 + c1
+    up = cfg.get("up", False)
+    x = (torch.randn(B, cin, H, W) * 1.5).to(torch.bfloat16).float()
+    w = torch.randn(co, cin, 3, 3) / (3 * cin ** 0.5)
+    bias = torch.randn(co) * 0.1
+    cw = E.ConvW(w, bias, "cuda", torch.bfloat16, fp8=True)
+    assert cw.w8 is not None and cw.w8.dtype == torch.float8_e4m3fn
+    a_s = E.FP8_ACT_SCALE
+    xq = (x * a_s).clamp(-448, 448).to(torch.float8_e4m3fn).float() / a_s
+    wq = (cw.w8.float().cpu() * cw.ws.cpu()[:, None]).reshape(co, 3, 3, cin).permute(0, 3, 1, 2)
+    xin = F.interpolate(xq, scale_factor=2, mode="nearest") if up else xq
+    ref = F.conv2d(xin, wq, bias, padding=1)
+    full = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest") if up else x, w, bias, padding=1)
+    xd = nhwc(x, torch.bfloat16)
+    a, b = (xd[..., :c0].contiguous(), xd[..., c0:].contiguous()) if c1 else (xd, None)
+    OH, OW = (2 * H, 2 * W) if up else (H, W)
+    out = torch.empty(B, OH, OW, co, device="cuda", dtype=torch.bfloat16)
+    kw = dict(c0=c0, in1=b, c1=c1, upsample=up)
+    assert e.conv(cw, a, B, H, W, out, probe="kid", **kw) == 12
+    e.conv(cw, a, B, H, W, out, **kw)
+    torch.cuda.synchronize()
+    assert rel_err(nchw(out), ref) < 6e-3                     # bf16 output rounding only
+    assert float((nchw(out) - full).norm() / full.norm()) < 6e-2      # e4m3 rounding of both operands
+    # same conv with GroupNorm partial sums: the fp8 form feeds the same statistics workspace
+    mt = L_mtiles(OH, OW)
+    part = torch.zeros(B, mt, co, 2, device="cuda")
+    e.conv(cw, a, B, H, W, out, stats=part, **kw)
+    torch.cuda.synchronize()
+    s = part.sum(1).cpu()
+    got = nchw(out)
+    assert torch.allclose(s[..., 0], got.sum((2, 3)), rtol=2e-2, atol=2.0)
+
+
+def L_mtiles(OH, OW):
+    from founddiff_amd import _lib as L
+    return L.lib().fd_conv_mtiles(OH, OW)
