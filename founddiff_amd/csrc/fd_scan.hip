@@ -18,6 +18,8 @@ namespace {
 struct ScanGeom {
     int B, H, W, D, N, R, CD;
     int H2, W2, L, CL, nch;
+    const void *xw;      // bf16 x_proj weights [4][CD][D], or NULL: phase A computes the chunk's x_dbl rows itself
+    float *xdbl_out;     // ... and writes them here for phase C
 };
 
 // position l of direction k -> (row of xdbl, NHWC pixel index inside the image)
@@ -67,7 +69,57 @@ __global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 8 ? 5 : 1))) void scan_ch
     const int odd = k & 1, ph = k & 1, pw = k >> 1;
     const float *xb = xdbl + ((int64_t)k * g.B + b) * g.L * g.CD;   // [4][B][L][CD]
 
+    // ---- fused x_proj (phase A, bf16, one workgroup per chunk): x_dbl[l][e] = sum_c Wx[k][e][c] xc[pix(l)][c]
+    // (src/emamba2.py:332 einsum) on the matrix cores, straight into the LDS row buffer and out to the x_dbl
+    // workspace phase C stages from.  The separate x_proj launch read the whole xc tensor once more from HBM
+    // (0.17 ms per batch-8 launch at 512x512); here that read is the first touch of the chunk's pixels and the
+    // recurrence's own u loads below hit L2.  Transposed issue: rows = outputs e, columns = 16 positions.
+    if constexpr (!FINAL && sizeof(T) == 2) {
+        if (g.xw) {
+            const bf16 *Wk = (const bf16 *)g.xw + (int64_t)k * CD * g.D;
+            const bf16 *ubx = (const bf16 *)xc + (int64_t)b * g.H * g.W * g.D;
+            float *xo = g.xdbl_out + ((int64_t)k * g.B + b) * g.L * g.CD;
+            constexpr int MB = (CD + 15) / 16;
+            const int fr = lane & 15, fg = lane >> 4;
+            const int nblk = (l1 - l0 + 15) >> 4;
+            for (int nb = wave; nb < nblk; nb += nw) {
+                const int l = l0 + nb * 16 + fr;
+                int h2, w2;
+                if (odd) { w2 = l / g.H2; h2 = l - w2 * g.H2; }
+                else { h2 = l / g.W2; w2 = l - h2 * g.W2; }
+                const int hh = 2 * h2 + ph, ww = 2 * w2 + pw;
+                const bool inimg = l < l1 && hh < g.H && ww < g.W;      // odd sizes: padded positions are zero rows
+                const bf16 *px = ubx + ((int64_t)hh * g.W + ww) * g.D + 8 * fg;
+                f32x4 acc[MB];
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) acc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int ks = 0; ks < g.D / 32; ++ks) {
+                    bf16x8 bfr = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (inimg) bfr = *(const bf16x8 *)(px + 32 * ks);
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) {
+                        const int e = mb * 16 + fr;
+                        bf16x8 afr = {0, 0, 0, 0, 0, 0, 0, 0};
+                        if (e < CD) afr = *(const bf16x8 *)(Wk + (int64_t)e * g.D + 32 * ks + 8 * fg);
+                        acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr, acc[mb], 0, 0, 0);
+                    }
+                }
+                if (l < l1) {
+                    const int lrow = h2 * g.W2 + w2;
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) {
+                        const int e0 = mb * 16 + 4 * fg;                // CD % 4 == 0 (launcher): all four or none
+                        if (e0 < CD) {
+                            *(f32x4 *)&sx[(nb * 16 + fr) * CDP + e0] = acc[mb];
+                            *(f32x4 *)&xo[(int64_t)lrow * CD + e0] = acc[mb];
+                        }
+                    }
+                }
+            }
+        }
+    }
     // ---- stage the chunk's rows
+    if (FINAL || sizeof(T) != 2 || !g.xw)
     for (int idx = threadIdx.x; idx < (l1 - l0) * CD; idx += blockDim.x) {
         const int row = idx / CD, e = idx - row * CD;
         const int l = l0 + row;
@@ -377,28 +429,58 @@ ScanGeom make_geom(int B, int H, int W, int D, int N, int R) {
     g.H2 = (H + 1) / 2; g.W2 = (W + 1) / 2; g.L = g.H2 * g.W2;     // odd sizes: padded sub-grids (src/emamba2.py:191-199)
     g.CL = chunk_len(g.L, D);
     g.nch = (g.L + g.CL - 1) / g.CL;
+    g.xw = nullptr;
+    g.xdbl_out = nullptr;
     return g;
 }
 
 }  // namespace
+
+extern "C" int fd_selective_scan_fuses_xproj(int dtype, int D, int N, int R);
 
 extern "C" int64_t fd_scan_ws_floats(int B, int H, int W, int D, int N) {
     ScanGeom g = make_geom(B, H, W, D, N, 1);
     return 2 * (int64_t)B * 4 * g.nch * N * D;
 }
 
-extern "C" int fd_selective_scan(int dtype, const void *xc, const float *xdbl, const float *dtw,
-                                 const float *dtb, const float *A, const float *Ds, void *y, float *ws,
-                                 int B, int H, int W, int D, int N, int R, void *stream) {
+static int scan_entry(int dtype, const void *xc, const void *x_proj_w, float *xdbl, const float *dtw, const float *dtb,
+                      const float *A, const float *Ds, void *y, float *ws, int B, int H, int W, int D, int N, int R,
+                      void *stream) {
     FD_REQUIRE(xc && xdbl && dtw && dtb && A && Ds && y && ws, "fd_selective_scan: null pointer");
     FD_REQUIRE(H > 0 && W > 0, "fd_selective_scan: bad image size %d x %d", H, W);
     FD_REQUIRE(D % 64 == 0, "fd_selective_scan: d_inner=%d must be a multiple of 64", D);
     FD_REQUIRE((int64_t)H * W * D * 4 < (1ll << 31), "fd_selective_scan: one image must stay below 2^31 bytes");
     ScanGeom g = make_geom(B, H, W, D, N, R);
+    if (x_proj_w) {
+        FD_REQUIRE(fd_selective_scan_fuses_xproj(dtype, D, N, R), "fd_selective_scan_xproj: not available for this shape "
+                   "(bf16, d_inner <= 256, (R + 2N) %% 4 == 0): D=%d N=%d R=%d", D, N, R);
+        FD_REQUIRE(((uintptr_t)x_proj_w & 15) == 0 && ((uintptr_t)xc & 15) == 0, "fd_selective_scan_xproj: 16-byte alignment");
+        g.xw = x_proj_w;
+        g.xdbl_out = xdbl;
+    }
     int rc = dtype == FD_BF16
                  ? dispatch_n<bf16>((const bf16 *)xc, xdbl, dtw, dtb, A, Ds, (bf16 *)y, ws, g, (hipStream_t)stream)
                  : dispatch_n<float>((const float *)xc, xdbl, dtw, dtb, A, Ds, (float *)y, ws, g, (hipStream_t)stream);
     FD_REQUIRE(rc == 0, "fd_selective_scan: unsupported d_state=%d / dt_rank=%d (need N in {4,8,16,32}, R in {2,4,8,16,32})", N, R);
     FD_LAUNCH_OK("fd_selective_scan");
     return FD_OK;
+}
+
+extern "C" int fd_selective_scan(int dtype, const void *xc, const float *xdbl, const float *dtw,
+                                 const float *dtb, const float *A, const float *Ds, void *y, float *ws,
+                                 int B, int H, int W, int D, int N, int R, void *stream) {
+    return scan_entry(dtype, xc, nullptr, (float *)xdbl, dtw, dtb, A, Ds, y, ws, B, H, W, D, N, R, stream);
+}
+
+// 1 if fd_selective_scan_xproj can compute the x_proj rows inside its first phase for this shape: bf16, one
+// workgroup per chunk (d_inner <= 256, so no workgroup repeats another's rows), rows of whole 16-byte groups.
+extern "C" int fd_selective_scan_fuses_xproj(int dtype, int D, int N, int R) {
+    return dtype == FD_BF16 && D % 64 == 0 && D <= 256 && (R + 2 * N) % 4 == 0;
+}
+
+extern "C" int fd_selective_scan_xproj(int dtype, const void *xc, const void *x_proj_w, float *xdbl, const float *dtw,
+                                       const float *dtb, const float *A, const float *Ds, void *y, float *ws, int B,
+                                       int H, int W, int D, int N, int R, void *stream) {
+    FD_REQUIRE(x_proj_w, "fd_selective_scan_xproj: null x_proj weights");
+    return scan_entry(dtype, xc, x_proj_w, xdbl, dtw, dtb, A, Ds, y, ws, B, H, W, D, N, R, stream);
 }

@@ -401,15 +401,21 @@ class DAEngine:
         H2, W2 = (H + 1) // 2, (W + 1) // 2
         Lq = H2 * W2
         xdbl = self._b("xdbl", (4, B, Lq, CD), torch.float32)
-        self.conv(None, xc, B, H, W, xdbl, c0=D, weight=m["x_proj"], bias=None, Cout=CD, KH=1, KW=1, stride=2,
-                  pad=0, ndir=4, w_dir_stride=CD * D, out_dir_stride=B * Lq * CD, out_f32=True,
-                  OH=H2, OW=W2)
-        self._pr(tag + ".xdbl", xdbl)
         nws = L.lib().fd_scan_ws_floats(B, H, W, D, N)
         ws = self._b("scan_ws", (nws,), torch.float32)
         y = self._b("scan_y", (B, H, W, D))
-        L.call("fd_selective_scan", self.dt, _p(xc), _p(xdbl), _p(m["dtw"]), _p(m["dtb"]), _p(m["A"]),
-               _p(m["Ds"]), _p(y), _p(ws), B, H, W, D, N, R, s)
+        if L.lib().fd_selective_scan_fuses_xproj(self.dt, D, N, R):
+            # x_proj inside the scan's first phase (one workgroup per chunk at d_inner <= 256): no separate pass over xc
+            L.call("fd_selective_scan_xproj", self.dt, _p(xc), _p(m["x_proj"]), _p(xdbl), _p(m["dtw"]), _p(m["dtb"]),
+                   _p(m["A"]), _p(m["Ds"]), _p(y), _p(ws), B, H, W, D, N, R, s)
+            self._pr(tag + ".xdbl", xdbl)
+        else:
+            self.conv(None, xc, B, H, W, xdbl, c0=D, weight=m["x_proj"], bias=None, Cout=CD, KH=1, KW=1, stride=2,
+                      pad=0, ndir=4, w_dir_stride=CD * D, out_dir_stride=B * Lq * CD, out_f32=True,
+                      OH=H2, OW=W2)
+            self._pr(tag + ".xdbl", xdbl)
+            L.call("fd_selective_scan", self.dt, _p(xc), _p(xdbl), _p(m["dtw"]), _p(m["dtb"]), _p(m["A"]),
+                   _p(m["Ds"]), _p(y), _p(ws), B, H, W, D, N, R, s)
         self._pr(tag + ".y", y)
         loc = C.c_void_p(self.local_all.data_ptr() + m["loc_off"] * f4)
         x1 = self._b(tag + ".x1", (B, H, W, Cc))

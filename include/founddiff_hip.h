@@ -187,6 +187,13 @@ int64_t fd_scan_ws_floats(int B, int H, int W, int D, int N);
 int fd_selective_scan(int dtype, const void *xc, const float *xdbl, const float *dtw,
                       const float *dtb, const float *A, const float *Ds, void *y, float *ws,
                       int B, int H, int W, int D, int N, int R, void *stream);
+/* The same scan with the x_proj einsum (src/emamba2.py:332) folded into its first phase: x_proj_w [4][R+2N][D] in
+ * dtype; xdbl is then an OUTPUT workspace (phase A writes the rows phase C reads).  Saves the separate x_proj
+ * launch and its pass over xc.  Only where fd_selective_scan_fuses_xproj() says so (bf16, d_inner <= 256).     */
+int fd_selective_scan_fuses_xproj(int dtype, int D, int N, int R);
+int fd_selective_scan_xproj(int dtype, const void *xc, const void *x_proj_w, float *xdbl, const float *dtw,
+                            const float *dtb, const float *A, const float *Ds, void *y, float *ws, int B, int H,
+                            int W, int D, int N, int R, void *stream);
 
 /* ---- The reference's own native-op interface (the only one it has):
  *     out, x, *rest = selective_scan_cuda_core.fwd(u, delta, A, B, C, D, delta_bias, delta_softplus, nrows)

@@ -683,3 +683,45 @@ def test_conv3x3_fp8_weights(eng_factory, cfg):
 def L_mtiles(OH, OW):
     from founddiff_amd import _lib as L
     return L.lib().fd_conv_mtiles(OH, OW)
+
+
+@pytest.mark.parametrize("cfg", [(128, 4, 4, 32, 48), (128, 8, 4, 16, 16), (256, 16, 8, 16, 32), (256, 8, 8, 32, 16), (128, 4, 4, 15, 21),
+                                 (64, 8, 2, 8, 8)])
+def test_selective_scan_fused_xproj(cfg):
+    """fd_selective_scan_xproj: the x_proj einsum (src/emamba2.py:332) inside the scan's first phase (bf16, one
+    workgroup per chunk) -- x_dbl rows and y against the CPU einsum + sequential oracle, incl. an odd image."""
+    from founddiff_amd import _lib as L
+    from oracle import nets
+    D, N, R, H, W = cfg
+    assert L.lib().fd_selective_scan_fuses_xproj(L.FD_BF16, D, N, R) == 1
+    assert L.lib().fd_selective_scan_fuses_xproj(L.FD_BF16, 512, 32, 16) == 0 and L.lib().fd_selective_scan_fuses_xproj(L.FD_F32, D, N, R) == 0
+    torch.manual_seed(8)
+    B, CD = 2, R + 2 * N
+    H2, W2 = (H + 1) // 2, (W + 1) // 2
+    Lq = H2 * W2
+    xc = (torch.randn(B, D, H, W) * 0.5).to(torch.bfloat16).float()
+    xw = (torch.randn(4, CD, D) / D ** 0.5).to(torch.bfloat16).float()
+    dtw = (torch.rand(4, D, R) * 2 - 1) * R ** -0.5
+    dtb = torch.randn(4, D) * 0.5 - 3
+    A = -torch.exp(torch.log(torch.arange(1, N + 1).float())[None].repeat(4 * D, 1) + 0.1 * torch.randn(4 * D, N))
+    Ds = 1 + 0.1 * torch.randn(4 * D)
+    xs = nets.efficient_scan(xc)                                   # (B,4,D,L) in scan order, zero-padded when odd
+    xd_scan = torch.einsum("bkdl,kcd->bklc", xs, xw)               # rows in scan order
+    dts = torch.einsum("bklr,kdr->bkdl", xd_scan[..., :R], dtw)
+    Bs = xd_scan[..., R:R + N].permute(0, 1, 3, 2).contiguous()
+    Cs = xd_scan[..., R + N:].permute(0, 1, 3, 2).contiguous()
+    ys = nets.selective_scan(xs.reshape(B, 4 * D, Lq), dts.reshape(B, 4 * D, Lq), A, Bs, Cs, Ds, dtb.reshape(-1))
+    ref = nets.efficient_merge(ys.view(B, 4, D, Lq), H, W).view(B, D, H, W)
+    # x_dbl rows are stored at row index h2 * W2 + w2 whatever the direction's scan order
+    xd_rows = torch.stack([xd_scan[:, 0], xd_scan[:, 1].reshape(B, W2, H2, CD).transpose(1, 2).reshape(B, Lq, CD),
+                           xd_scan[:, 2], xd_scan[:, 3].reshape(B, W2, H2, CD).transpose(1, 2).reshape(B, Lq, CD)], 0)
+    ws = torch.empty(L.lib().fd_scan_ws_floats(B, H, W, D, N), device="cuda")
+    y = torch.empty(B, H, W, D, device="cuda", dtype=torch.bfloat16)
+    xdbl = torch.full((4, B, Lq, CD), float("nan"), device="cuda")
+    t = [v.contiguous().cuda() for v in (dtw, dtb, A, Ds)]
+    xcd, xwd = nhwc(xc, torch.bfloat16), xw.to("cuda", torch.bfloat16).contiguous()
+    L.call("fd_selective_scan_xproj", L.FD_BF16, xcd.data_ptr(), xwd.data_ptr(), xdbl.data_ptr(), t[0].data_ptr(), t[1].data_ptr(),
+           t[2].data_ptr(), t[3].data_ptr(), y.data_ptr(), ws.data_ptr(), B, H, W, D, N, R, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert rel_err(xdbl.cpu(), xd_rows) < 1e-5
+    assert rel_err(nchw(y), ref) < 1e-2
