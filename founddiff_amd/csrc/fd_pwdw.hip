@@ -26,7 +26,9 @@ constexpr int PMT = (PHP + 15) / 16;                                            
 constexpr int XS_B = PMT * 16 * 128, TS_B = PHP * 128;
 typedef __attribute__((ext_vector_type(2))) __bf16 pd_bf16x2;
 
-__device__ __forceinline__ int xs_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+// row & 7 (not the generic kernel's (row >> 1) & 7): conflict-free for 16 consecutive rows starting at ANY row -- the
+// z phase reads its fragments from tile rows that start at odd halo pixels (fd_conv3x3.hip, swz)
+__device__ __forceinline__ int xs_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 __device__ __forceinline__ int ts_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
 struct PwDwParams {

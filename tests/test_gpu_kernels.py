@@ -686,7 +686,7 @@ def L_mtiles(OH, OW):
 
 
 @pytest.mark.parametrize("cfg", [(128, 4, 4, 32, 48), (128, 8, 4, 16, 16), (256, 16, 8, 16, 32), (256, 8, 8, 32, 16), (128, 4, 4, 15, 21),
-                                 (64, 8, 2, 8, 8)])
+                                 (64, 4, 4, 8, 8)])
 def test_selective_scan_fused_xproj(cfg):
     """fd_selective_scan_xproj: the x_proj einsum (src/emamba2.py:332) inside the scan's first phase (bf16, one
     workgroup per chunk) -- x_dbl rows and y against the CPU einsum + sequential oracle, incl. an odd image."""
