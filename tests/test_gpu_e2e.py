@@ -180,6 +180,21 @@ def test_ddim_tiny_bf16_drift(golden):
     assert l2rel(out, ref) < l2rel(pure, ref)
 
 
+def test_concurrent_half_batches_bitwise(golden):
+    """ResidualDiffusion.sample runs a batch >= 8 as two half-batches on two HIP streams (own engines, own captured
+    loop graphs): bit-identical to the single-stream run and to itself."""
+    g, dif = _tiny_model(golden, "bf16")
+    assert dif.streams == 2
+    x = g["x_input"].cuda().repeat(4, 1, 1, 1) * torch.linspace(0.7, 1.0, 8, device="cuda").view(8, 1, 1, 1)
+    nz = torch.randn(8, 1, 64, 64, generator=torch.Generator().manual_seed(2)).cuda()
+    a = dif.sample([x], batch_size=8, noise=nz)
+    b = dif.sample([x], batch_size=8, noise=nz)
+    dif.streams = 1
+    c = dif.sample([x], batch_size=8, noise=nz)
+    assert len(a) == 2 and a[-1].shape == (8, 1, 64, 64)
+    assert torch.equal(a[-1], b[-1]) and torch.equal(a[-1], c[-1]) and torch.equal(a[0], c[0])
+
+
 def test_p_sample_loop_tiny_fp32(golden):
     """a6: the ancestral loop DRIVER (src/DADiff.py:1233-1273), all 1000 steps of config 1's model through
     p_sample_loop itself; the first 20 steps and x_T against the reference's goldens (noise supplied per step)."""
