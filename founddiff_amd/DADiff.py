@@ -335,6 +335,11 @@ class ResidualDiffusion(nn.Module):
         if final_fp32_steps is None:
             final_fp32_steps = int(os.environ.get("FOUNDDIFF_FINAL_FP32_STEPS", "1"))
         self.final_fp32_steps = int(final_fp32_steps)
+        # ... and of that step only the outermost resolution level(s) -- init_conv, downs[0], ups[-1], the final
+        # block: 53 % of a forward's bf16 drift originates there (profiles/r02_drift_table.md) at a third of the fp32
+        # forward's time -- run one class up, the levels below stay on the fast engine (DAEngine.forward_hybrid).
+        # 0: the whole step runs on the higher-precision engine.
+        self.final_outer_levels = int(os.environ.get("FOUNDDIFF_FINAL_OUTER_LEVELS", "0"))
         for k, v in residual_schedule(timesteps, after_init=False).items():
             self.register_buffer(k, v)
         self._graph = {}
@@ -550,21 +555,31 @@ class ResidualDiffusion(nn.Module):
         e32.share_condition(eng)
         return K, e32
 
-    def _step_forward(self, x_in, img, time_buf, mo, eng=None):
+    def _tail_forward(self, e32, eng, img, x_in, time_buf, mo):
+        """The forward of a tail step: hybrid (outer levels on e32, the rest on eng) or all of it on e32."""
+        k = self.final_outer_levels
+        if k > 0 and k < len(e32.downs):
+            e32.forward_hybrid(eng, img, x_in, time_buf, out=mo, outer_levels=k)
+        else:
+            e32.forward(img, x_in, time_buf, out=mo)
+
+    def _step_forward(self, x_in, img, time_buf, mo, eng=None, tail_of=None):
         eng = eng or self._eng()
-        key = (tuple(img.shape), eng.mode, eng.gen)
+        run = (lambda: self._tail_forward(eng, tail_of, img, x_in, time_buf, mo)) if tail_of is not None else \
+            (lambda: eng.forward(img, x_in, time_buf, out=mo))
+        key = (tuple(img.shape), eng.mode, eng.gen, tail_of.gen if tail_of is not None else 0, self.final_outer_levels)
         if not self.use_graph:
-            eng.forward(img, x_in, time_buf, out=mo)
+            run()
             return
         ent = self._graph.get(key)
         if ent is None:
             # warm-up (allocates every workspace buffer), then capture
-            eng.forward(img, x_in, time_buf, out=mo)
+            run()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                eng.forward(img, x_in, time_buf, out=mo)
-            for k in [k for k in self._graph if k[1] == eng.mode]:     # one graph per engine mode
+                run()
+            for k in [k for k in self._graph if k[2] == eng.gen]:     # one graph per engine
                 del self._graph[k]
             ent = self._graph[key] = (g, (x_in, img, time_buf, mo))
         g, (gx, gi, gt, gm) = ent
@@ -615,7 +630,10 @@ class ResidualDiffusion(nn.Module):
         K, e32 = self._tail_engine(eng)
         for t in reversed(range(0, T)):
             time_buf.fill_(float(times[t]))
-            self._step_forward(x_in, img, time_buf, mo, e32 if t < K else eng)
+            if t < K:
+                self._step_forward(x_in, img, time_buf, mo, e32, tail_of=eng)
+            else:
+                self._step_forward(x_in, img, time_buf, mo, eng)
             coef = coefs[t:t + 1].expand(B, 4).contiguous()
             nz = None
             if t > 0:
@@ -670,23 +688,29 @@ class ResidualDiffusion(nn.Module):
         if self.use_graph and last and os.environ.get("FOUNDDIFF_LOOP_GRAPH", "1") != "0":
             # the whole S-step loop as ONE HIP graph (S x (time fill + 141 kernels + DDIM update), every
             # scheduler constant baked into its node): replayed per sample() on the persistent loop buffers
-            key = ("ddim", tuple(shape), eng.mode, eng.gen, S, T, K, e32.gen if e32 else 0)
+            key = ("ddim", tuple(shape), eng.mode, eng.gen, S, T, K, e32.gen if e32 else 0, self.final_outer_levels)
+
+            def fwd(e):
+                if e is eng:
+                    e.forward(img, x_in, time_buf, out=mo)
+                else:
+                    self._tail_forward(e, eng, img, x_in, time_buf, mo)
             if key not in self._loop_graph:
                 start = img.clone()
                 for e in (eng, e32):
                     if e is not None:
-                        e.forward(img, x_in, time_buf, out=mo)    # warm-up: every workspace buffer exists
+                        fwd(e)                                    # warm-up: every workspace buffer exists
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
-                    run_steps(lambda e: e.forward(img, x_in, time_buf, out=mo))
+                    run_steps(fwd)
                 for k in [k for k in self._loop_graph if k[3] == eng.gen]:     # one loop graph per engine
                     del self._loop_graph[k]
                 self._loop_graph[key] = g
                 img.copy_(start)                                   # capture does not execute: restore x_T
             self._loop_graph[key].replay()
         else:
-            run_steps(lambda e: self._step_forward(x_in, img, time_buf, mo, e))
+            run_steps(lambda e: self._step_forward(x_in, img, time_buf, mo, e, tail_of=None if e is eng else eng))
         if not last:
             img_list = [input_add_noise] + img_list
         else:

@@ -448,6 +448,28 @@ extern "C" int fd_avgpool(int dtype, const void *in, void *out, int B, int H, in
     return FD_OK;
 }
 
+// activation tensor in the other storage type (hybrid-precision forward: fp32 <-> bf16 at a level boundary)
+template <typename S, typename D>
+__global__ void cast_kernel(const S *__restrict__ in, D *__restrict__ out, int64_t n8) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        float v[8];
+        load8(in + 8 * i, v);
+        store8(out + 8 * i, v);
+    }
+}
+
+extern "C" int fd_cast(int src_dtype, const void *in, int dst_dtype, void *out, int64_t n, void *stream) {
+    FD_REQUIRE(in && out && n % 8 == 0 && (((uintptr_t)in | (uintptr_t)out) & 15) == 0, "fd_cast: n %% 8 and 16-byte alignment");
+    FD_REQUIRE(src_dtype != dst_dtype, "fd_cast: same dtype");
+    dim3 grid(grid1d(n / 8)), block(256);
+    if (src_dtype == FD_F32)
+        hipLaunchKernelGGL((cast_kernel<float, bf16>), grid, block, 0, (hipStream_t)stream, (const float *)in, (bf16 *)out, n / 8);
+    else
+        hipLaunchKernelGGL((cast_kernel<bf16, float>), grid, block, 0, (hipStream_t)stream, (const bf16 *)in, (float *)out, n / 8);
+    FD_LAUNCH_OK("fd_cast");
+    return FD_OK;
+}
+
 extern "C" int fd_pack_planes3(int dtype, const float *p0, const float *p1, const float *p2, void *out, int B,
                                int64_t hw, int cpad, void *stream) {
     FD_REQUIRE(p0 && out && cpad >= 8 && cpad % 8 == 0, "fd_pack_planes: bad args");

@@ -572,8 +572,57 @@ class DAEngine:
         div = 2 ** sum(1 for d in self.downs if d["stride"] == 2)
         if H % div or W % div:       # what the reference's own down / up-sampling needs (skip shapes must match)
             raise ValueError(f"H,W must be multiples of {div} (got {H}x{W})")
-        s = self.stream
         self.time_cond(time)
+        r = self._head(x_t, x_in, x_cond2)
+        x, h, w = r, H, W
+        self._skips = []
+        for i in range(nd):
+            x, h, w = self._down(i, x, B, h, w)
+        x = self._mid(x, B, h, w)
+        for i in range(len(self.ups)):
+            x, h, w = self._up(i, x, B, h, w)
+        return self._tail(x, r, B, H, W, out)
+
+    def forward_hybrid(self, inner, x_t, x_in, time, out=None, outer_levels=1):
+        """One forward with THIS engine on the outermost `outer_levels` resolution levels (init_conv, the first
+        down stages, the last up stages, final block) and `inner` -- another engine of the same weights, normally
+        one precision class down -- on the levels in between; the activation crosses the boundary through a
+        dtype cast (`fd_cast`).  The last step of a sampling loop runs this way (ResidualDiffusion: fp32 at the
+        full-resolution level, where 53 % of the bf16 drift of a forward originates, bf16 below)."""
+        B, _, H, W = x_t.shape
+        nd, nu = len(self.downs), len(self.ups)
+        k = outer_levels
+        assert 0 < k < nd and nu == nd
+        self.time_cond(time)
+        inner.time_cond(time)
+        r = self._head(x_t, x_in, None)
+        x, h, w = r, H, W
+        self._skips, inner._skips = [], []
+        for i in range(k):
+            x, h, w = self._down(i, x, B, h, w)
+        x = inner._cast_from(x, self, "hyb_in")
+        for i in range(k, nd):
+            x, h, w = inner._down(i, x, B, h, w)
+        x = inner._mid(x, B, h, w)
+        for i in range(nu - k):
+            x, h, w = inner._up(i, x, B, h, w)
+        x = self._cast_from(x, inner, "hyb_out")
+        for i in range(nu - k, nu):
+            x, h, w = self._up(i, x, B, h, w)
+        return self._tail(x, r, B, H, W, out)
+
+    def _cast_from(self, x, src, name):
+        """x (a tensor of engine `src`) in this engine's storage type."""
+        if src.tdt == self.tdt:
+            return x
+        o = self._b(name, tuple(x.shape))
+        L.call("fd_cast", src.dt, _p(x), self.dt, _p(o), x.numel(), self.stream)
+        return o
+
+    # ---- the stages of a forward (src/DADiff.py:703-740)
+    def _head(self, x_t, x_in, x_cond2):
+        B, _, H, W = x_t.shape
+        s = self.stream
         r = self._b("r", (B, H, W, self.dim))
         if self.init_w7 is not None and L.lib().fd_init_conv7_ok(self.dt, self.dim, H, W):
             L.call("fd_init_conv7", self.dt, _p(x_t), _p(x_in), _p(x_cond2), _p(self.init_w7), _p(self.init_conv.b),
@@ -583,43 +632,50 @@ class DAEngine:
             L.call("fd_pack_planes3", self.dt, _p(x_t), _p(x_in), _p(x_cond2), _p(xin8), B, H * W, 8, s)
             self.conv(self.init_conv, xin8, B, H, W, r)
         self._pr("init", r)
-        x, h, w = r, H, W
-        skips = []
-        for i, d in enumerate(self.downs):
-            x = self.mamba_block(d["mamba"], x, B, h, w, f"d{i}m")
-            x = self.res_block(d["res"], x, x.shape[-1], None, 0, B, h, w, f"d{i}r")
-            skips.append((x, h, w))
-            cw = d["samp"]
-            if d["stride"] == 2:
-                o = self._b(f"d{i}s", (B, h // 2, w // 2, cw.Cout))
-                self.conv(cw, x, B, h, w, o, stride=2, pad=1)
-                h, w = h // 2, w // 2
-            else:
-                o = self._b(f"d{i}s", (B, h, w, cw.Cout))
-                self.conv(cw, x, B, h, w, o)
-            x = o
-            self._pr(f"d{i}s", x)
+        return r
+
+    def _down(self, i, x, B, h, w):
+        d = self.downs[i]
+        x = self.mamba_block(d["mamba"], x, B, h, w, f"d{i}m")
+        x = self.res_block(d["res"], x, x.shape[-1], None, 0, B, h, w, f"d{i}r")
+        self._skips.append((x, h, w))
+        cw = d["samp"]
+        if d["stride"] == 2:
+            o = self._b(f"d{i}s", (B, h // 2, w // 2, cw.Cout))
+            self.conv(cw, x, B, h, w, o, stride=2, pad=1)
+            h, w = h // 2, w // 2
+        else:
+            o = self._b(f"d{i}s", (B, h, w, cw.Cout))
+            self.conv(cw, x, B, h, w, o)
+        self._pr(f"d{i}s", o)
+        return o, h, w
+
+    def _mid(self, x, B, h, w):
         x = self.res_block(self.mid_res, x, x.shape[-1], None, 0, B, h, w, "midr")
-        x = self.mamba_block(self.mid_mamba, x, B, h, w, "midm")
-        for i, u in enumerate(self.ups):
-            sk, hs, ws_ = skips.pop()
-            assert (hs, ws_) == (h, w)
-            x = self.res_block(u["res"], x, x.shape[-1], sk, sk.shape[-1], B, h, w, f"u{i}r")
-            x = self.mamba_block(u["mamba"], x, B, h, w, f"u{i}m")
-            cw = u["samp"]
-            if u["up"]:
-                o = self._b(f"u{i}s", (B, 2 * h, 2 * w, cw.Cout))
-                self.conv(cw, x, B, h, w, o, upsample=True)
-                h, w = 2 * h, 2 * w
-            else:
-                o = self._b(f"u{i}s", (B, h, w, cw.Cout))
-                self.conv(cw, x, B, h, w, o)
-            x = o
-            self._pr(f"u{i}s", x)
-        x = self.res_block(self.final_res, x, x.shape[-1], r, r.shape[-1], B, h, w, "finr")
+        return self.mamba_block(self.mid_mamba, x, B, h, w, "midm")
+
+    def _up(self, i, x, B, h, w):
+        u = self.ups[i]
+        sk, hs, ws_ = self._skips.pop()
+        assert (hs, ws_) == (h, w)
+        x = self.res_block(u["res"], x, x.shape[-1], sk, sk.shape[-1], B, h, w, f"u{i}r")
+        x = self.mamba_block(u["mamba"], x, B, h, w, f"u{i}m")
+        cw = u["samp"]
+        if u["up"]:
+            o = self._b(f"u{i}s", (B, 2 * h, 2 * w, cw.Cout))
+            self.conv(cw, x, B, h, w, o, upsample=True)
+            h, w = 2 * h, 2 * w
+        else:
+            o = self._b(f"u{i}s", (B, h, w, cw.Cout))
+            self.conv(cw, x, B, h, w, o)
+        self._pr(f"u{i}s", o)
+        return o, h, w
+
+    def _tail(self, x, r, B, H, W, out):
+        x = self.res_block(self.final_res, x, x.shape[-1], r, r.shape[-1], B, H, W, "finr")
         if out is None:
             out = self._b("model_out", (B, 1, H, W), torch.float32)
         L.call("fd_final_conv1", self.dt, _p(x), _p(self.final_w), _p(self.final_b), _p(out), B * H * W,
-               x.shape[-1], s)
+               x.shape[-1], self.stream)
         self._pr("out", out)
         return out

@@ -260,6 +260,9 @@ int fd_init_conv7(int dtype, const float *p0, const float *p1, const float *p2, 
 int fd_pack_planes3(int dtype, const float *p0, const float *p1, const float *p2, void *out, int B,
                     int64_t hw, int cpad, void *stream);
 /* final 1x1 conv to ONE channel (src/DADiff.py:683,740): out[b,p] = b0 + sum_c x[b,p,c] w[c] */
+/* n elements (n % 8 == 0) of an activation tensor from one storage type to the other (FD_F32 <-> FD_BF16): the
+ * level boundary of a hybrid-precision forward (engine.py: DAEngine.forward_hybrid).                       */
+int fd_cast(int src_dtype, const void *in, int dst_dtype, void *out, int64_t n, void *stream);
 int fd_final_conv1(int dtype, const void *x, const float *w, const float *b, float *out,
                    int64_t npix, int C, void *stream);
 /* avg-pool k x k stride k, NHWC (src/DACLIP.py:181,193,282)                                  */

@@ -25,9 +25,11 @@ def main():
         x = torch.from_numpy(ld).to(dev)
         nz = torch.randn(a.batch, 1, size, size, generator=torch.Generator().manual_seed(7)).to(dev)
         outs = {}
-        for prec in ("fp32", "bf16", "bf16+1", "bf16+2"):
+        for prec in ("fp32", "bf16", "bf16+1", "bf16+1/1", "bf16+1/2"):
             dif, _ = bench.build_model(dev, size, a.steps, prec.split("+")[0])
-            dif.final_fp32_steps = int(prec.split("+")[1]) if "+" in prec else 0
+            tail = prec.split("+")[1] if "+" in prec else "0"
+            dif.final_fp32_steps = int(tail.split("/")[0])
+            dif.final_outer_levels = int(tail.split("/")[1]) if "/" in tail else 0
             dif.sample([x], batch_size=a.batch, noise=nz)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
