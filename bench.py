@@ -265,8 +265,9 @@ def main():
             "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": ("bf16" if a.precision == "bf16" else "bf16 activations, e4m3 weights (fp8 MFMA) in the 3x3 convs")
-                     + (f"; last {dif.final_fp32_steps} step(s) one precision class up ({'fp32' if a.precision == 'bf16' else 'bf16'})"
-                        if dif.final_fp32_steps else ""),
+                     + (f"; last {dif.final_fp32_steps} step(s): "
+                        + (f"resolution levels 0-{dif.final_outer_levels - 1}" if dif.final_outer_levels else "whole forward")
+                        + f" in {'fp32' if a.precision == 'bf16' else 'bf16'}" if dif.final_fp32_steps else ""),
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: 512x512 slice, 50-step DDIM, full FoundDiff UNet "
                                    "(dim 64, mults 1-2-4-8) + DA-CLIP RN50 cond, bf16",
