@@ -362,7 +362,12 @@ def test_full_arch_64(golden):
     assert rel_err(res[-1].cpu(), g["ddim2.out"]) < 1e-3
     net.unet0.precision = "bf16"
     res16 = dif.sample([g["x_input"].cuda()], batch_size=1, last=True, noise=g["noise0"].cuda())
-    assert l2rel(res16[-1].cpu(), g["ddim2.out"]) < 1e-2      # production mode: the second of the two steps runs in fp32
+    # production mode: of the two steps, the second runs levels 0-1 on the fp32 engine (2-step DDIM jumps from t = 999
+    # straight to x_start: the bf16 first step weighs more than in a 50-step run); whole second step in fp32: <= 1e-2
+    assert l2rel(res16[-1].cpu(), g["ddim2.out"]) < 2e-2
+    dif.final_outer_levels = 0
+    res16f = dif.sample([g["x_input"].cuda()], batch_size=1, last=True, noise=g["noise0"].cuda())
+    assert l2rel(res16f[-1].cpu(), g["ddim2.out"]) < 1e-2
 
 
 def test_vs_oracle_random_256(golden):
