@@ -40,12 +40,7 @@ __device__ __forceinline__ void scan_pos(const ScanGeom &g, int k, int l, int &l
 // x_dbl row (x_proj has no bias), i.e. the state only decays by exp(softplus(dt_bias) A) there, and their outputs
 // are dropped.  Here they are positions whose pixel lies outside the image: u := 0, no store; the x_dbl rows of
 // those positions are zeros written by the x_proj launch (its gather zero-fills out-of-range pixels).
-// DTM (chunks of 32 positions, dt_rank >= 8: the 128x128 / 64x64 levels): dt_proj -- R multiply-adds per (step,
-// channel), a third of the packed-VALU work at N = R = 32, plus R/2 weight registers -- moves onto the matrix
-// cores: before the recurrence each wave computes  z[pos][d] = log2e-scaled (w[d] . x_dbl[pos][:R] + bias[d])  for its
-// 64 channels and the chunk's 32 positions with the exact-f32 MFMA (16x16x4: same products, k-ordered sums) into an
-// LDS table [32][channels of the workgroup]; a step then reads ONE conflict-free dword instead of R broadcast values.
-template <typename T, int N, int R, bool FINAL, bool ODD, bool DTM>
+template <typename T, int N, int R, bool FINAL, bool ODD>
 __global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 8 ? 5 : 1))) void scan_chunk_kernel(const T *__restrict__ xc, const float *__restrict__ xdbl,
                                                         const float *__restrict__ dtw, const float *__restrict__ dtb,
                                                         const float *__restrict__ A, const float *__restrict__ Ds,
@@ -140,35 +135,9 @@ __global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 8 ? 5 : 1))) void scan_ch
 
     // state / weights as float pairs: the recurrence runs on v_pk_mul_f32 / v_pk_fma_f32 (two states
     // per instruction at the scalar-op issue rate); only the two v_exp_f32 per pair stay scalar
-    f32x2 w[DTM ? 1 : R / 2], a2[N / 2], h[N / 2];
-    if constexpr (!DTM) {
+    f32x2 w[R / 2], a2[N / 2], h[N / 2];
 #pragma unroll
-        for (int r = 0; r < R / 2; ++r) w[r] = f32x2{dtw[(int64_t)kd * R + 2 * r], dtw[(int64_t)kd * R + 2 * r + 1]} * WS;
-    }
-    const int DSTR = 64 * nw;                           // DTM: row stride of the z table (channels of the workgroup)
-    float *dtp = sx + g.CL * CDP;
-    if constexpr (DTM) {
-        __syncthreads();                                // the staged rows are complete
-        const int fr = lane & 15, fg = lane >> 4;
-#pragma unroll 1
-        for (int mb = 0; mb < 4; ++mb) {
-            const int c0 = (dg * nw + wave) * 64 + mb * 16;                 // first channel of the m-block
-            const float *wrow = dtw + ((int64_t)k * g.D + c0 + fr) * R;
-            float af[R / 4];
-#pragma unroll
-            for (int q = 0; q < R / 4; ++q) af[q] = wrow[4 * q + fg] * WS;
-            const f32x4 b4 = *(const f32x4 *)(dtb + (int64_t)k * g.D + c0 + 4 * fg);
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int q = 0; q < R / 4; ++q)
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q], sx[(nb * 16 + fr) * CDP + 4 * q + fg], acc, 0, 0, 0);
-                // D[channel 4 fg + i][position fr]
-                *(f32x4 *)&dtp[(nb * 16 + fr) * DSTR + wave * 64 + mb * 16 + 4 * fg] = acc + b4 * WS;
-            }
-        }
-    }
+    for (int r = 0; r < R / 2; ++r) w[r] = f32x2{dtw[(int64_t)kd * R + 2 * r], dtw[(int64_t)kd * R + 2 * r + 1]} * WS;
     // exp(dt*A) = exp2(dt * A*log2(e)): fold the constant into A once (v_exp_f32 is exp2)
 #pragma unroll
     for (int n = 0; n < N / 2; ++n)
@@ -233,15 +202,10 @@ __global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 8 ? 5 : 1))) void scan_ch
 
     auto step = [&](const float *xr, float u, int soff) {
         const f32x2 *xr2 = (const f32x2 *)xr;          // row = [dt_r (R) | B (N) | C (N)], all even
-        float dv;
-        if constexpr (DTM) {
-            dv = dtp[(int)((xr - sx) / CDP) * DSTR + (int)threadIdx.x];
-        } else {
-            f32x2 dv2 = {bias, 0.f};
+        f32x2 dv2 = {bias, 0.f};
 #pragma unroll
-            for (int r = 0; r < R / 2; ++r) dv2 = w[r] * xr2[r] + dv2;
-            dv = dv2.x + dv2.y;
-        }
+        for (int r = 0; r < R / 2; ++r) dv2 = w[r] * xr2[r] + dv2;
+        const float dv = dv2.x + dv2.y;
         float dt;
         if constexpr (LOG2U) dt = __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(fminf(dv, 126.f)));
         else dt = fd_softplus_fast(dv);
@@ -397,15 +361,15 @@ __global__ __launch_bounds__(64 * SEG) void scan_carry_kernel(float *__restrict_
     }
 }
 
-template <typename T, int N, int R, bool ODD, bool DTM>
-void launch_scan_v(const T *xc, const float *xdbl, const float *dtw, const float *dtb, const float *A,
+template <typename T, int N, int R, bool ODD>
+void launch_scan(const T *xc, const float *xdbl, const float *dtw, const float *dtb, const float *A,
                  const float *Ds, T *y, float *ws, const ScanGeom &g, hipStream_t s) {
     const int64_t half = (int64_t)g.B * 4 * g.nch * g.N * g.D;
     float *wsH = ws, *wsP = ws + half;
     const int nw = g.D >= 256 ? 4 : g.D / 64;          // waves (64-channel groups) per workgroup
     dim3 grid(g.nch * (g.D / (64 * nw)), g.B * 4), block(64 * nw);
-    const size_t lds = ((size_t)g.CL * ((g.CD + 3) & ~3) + (DTM ? (size_t)g.CL * 64 * nw : 0)) * sizeof(float);
-    hipLaunchKernelGGL((scan_chunk_kernel<T, N, R, false, ODD, DTM>), grid, block, lds, s, xc, xdbl, dtw, dtb, A, Ds, y, wsH, wsP, g);
+    const size_t lds = (size_t)g.CL * ((g.CD + 3) & ~3) * sizeof(float);
+    hipLaunchKernelGGL((scan_chunk_kernel<T, N, R, false, ODD>), grid, block, lds, s, xc, xdbl, dtw, dtb, A, Ds, y, wsH, wsP, g);
     if (g.nch > 1)
     {
         const int per = (g.nch + SEG - 1) / SEG;
@@ -417,21 +381,7 @@ void launch_scan_v(const T *xc, const float *xdbl, const float *dtw, const float
     }
     else
         (void)hipMemsetAsync(wsH, 0, half * sizeof(float), s);
-    hipLaunchKernelGGL((scan_chunk_kernel<T, N, R, true, ODD, DTM>), grid, block, lds, s, xc, xdbl, dtw, dtb, A, Ds, y, wsH, wsP, g);
-}
-
-template <typename T, int N, int R, bool ODD>
-void launch_scan(const T *xc, const float *xdbl, const float *dtw, const float *dtb, const float *A,
-                 const float *Ds, T *y, float *ws, const ScanGeom &g, hipStream_t s) {
-    // dt_proj on the matrix cores where a chunk is 32 positions (the z table is then <= 32 KiB per workgroup), dt_rank
-    // >= 8 and the workgroup has 4 waves of whole 16-channel blocks
-    if constexpr (R >= 8) {
-        if (g.CL == 32 && g.D >= 256 && g.D % 256 == 0) {
-            launch_scan_v<T, N, R, ODD, true>(xc, xdbl, dtw, dtb, A, Ds, y, ws, g, s);
-            return;
-        }
-    }
-    launch_scan_v<T, N, R, ODD, false>(xc, xdbl, dtw, dtb, A, Ds, y, ws, g, s);
+    hipLaunchKernelGGL((scan_chunk_kernel<T, N, R, true, ODD>), grid, block, lds, s, xc, xdbl, dtw, dtb, A, Ds, y, wsH, wsP, g);
 }
 
 template <typename T, int N>
