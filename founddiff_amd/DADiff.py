@@ -345,8 +345,6 @@ class ResidualDiffusion(nn.Module):
         self.final_outer_levels = int(os.environ.get("FOUNDDIFF_FINAL_OUTER_LEVELS", "2"))
         for k, v in residual_schedule(timesteps, after_init=False).items():
             self.register_buffer(k, v)
-        self._graph = {}
-        self._loop_graph = {}
         self._host_sched = None
         self._slot = 0
         # independent half-batches on concurrent HIP streams: kernels bound by different resources (VALU-issue
@@ -362,16 +360,22 @@ class ResidualDiffusion(nn.Module):
             setattr(self, k, v.to(dev))
         self.num_timesteps = 1000
         self._host_sched = None
-        self._loop_graph = {}
+        self._drop_graphs()
 
     def load_state_dict(self, state_dict, strict=True, assign=False):
         live = {k: v for k, v in state_dict.items()
                 if not (arch.is_dead_key(k, "model.unet0.") or arch.is_dead_key(k, "model.unet1."))}
-        self._graph = {}
-        self._loop_graph = {}
-        return super().load_state_dict(live, strict=strict, assign=assign)
+        return super().load_state_dict(live, strict=strict, assign=assign)     # new weights -> new engines -> new graphs
 
     # ---- helpers
+    def _drop_graphs(self):
+        """Forget every captured graph (they bake in scheduler constants): init() re-derives the schedule."""
+        for name in ("unet0", "unet1"):
+            u = getattr(self.model, name, None)
+            for e in (getattr(u, "_engine", None) or {}).values():
+                e.graphs.clear()
+                e.loop_graphs.clear()
+
     def _hs(self):
         if self._host_sched is None:
             self._host_sched = {k: getattr(self, k).detach().cpu() for k in
@@ -574,7 +578,8 @@ class ResidualDiffusion(nn.Module):
         if not self.use_graph:
             run()
             return
-        ent = self._graph.get(key)
+        cache = eng.graphs                 # captured graphs live and die with the engine whose buffers they bake in
+        ent = cache.get(key)
         if ent is None:
             # warm-up (allocates every workspace buffer), then capture
             run()
@@ -582,9 +587,8 @@ class ResidualDiffusion(nn.Module):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 run()
-            for k in [k for k in self._graph if k[2] == eng.gen]:     # one graph per engine
-                del self._graph[k]
-            ent = self._graph[key] = (g, (x_in, img, time_buf, mo))
+            cache.clear()                                              # one step graph per engine
+            ent = cache[key] = (g, (x_in, img, time_buf, mo))
         g, (gx, gi, gt, gm) = ent
         if gx.data_ptr() != x_in.data_ptr():
             gx.copy_(x_in)
@@ -698,7 +702,8 @@ class ResidualDiffusion(nn.Module):
                     e.forward(img, x_in, time_buf, out=mo)
                 else:
                     self._tail_forward(e, eng, img, x_in, time_buf, mo)
-            if key not in self._loop_graph:
+            loops = eng.loop_graphs
+            if key not in loops:
                 start = img.clone()
                 for e in (eng, e32):
                     if e is not None:
@@ -707,11 +712,10 @@ class ResidualDiffusion(nn.Module):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     run_steps(fwd)
-                for k in [k for k in self._loop_graph if k[3] == eng.gen]:     # one loop graph per engine
-                    del self._loop_graph[k]
-                self._loop_graph[key] = g
+                loops.clear()                                      # one loop graph per engine
+                loops[key] = g
                 img.copy_(start)                                   # capture does not execute: restore x_T
-            self._loop_graph[key].replay()
+            loops[key].replay()
         else:
             run_steps(lambda e: self._step_forward(x_in, img, time_buf, mo, e, tail_of=None if e is eng else eng))
         if not last:

@@ -98,6 +98,7 @@ class DAEngine:
         self._pack(sd)
         self._plan_key = None
         self.buf = {}
+        self.graphs, self.loop_graphs = {}, {}     # HIP graphs captured over this engine's buffers (ResidualDiffusion)
 
     # ------------------------------------------------------------------ packing
     def _f(self, t):

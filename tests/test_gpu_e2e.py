@@ -219,6 +219,28 @@ def test_p_sample_loop_tiny_fp32(golden):
     assert len(two) == 2 and torch.equal(two[-1], fin)
 
 
+def test_p_sample_loop_tiny_bf16_tail(golden):
+    """The ancestral driver in the production mode: 1000 bf16 steps of config 1's model whose last step (t = 0) runs
+    on the fp32 engine, per-step graphs for both engines; against the fp32 loop on the same noise stream."""
+    noises = {}
+
+    def run(prec):
+        g, dif = _tiny_model(golden, prec, S=1000)
+        gen = torch.Generator(device="cuda").manual_seed(1)
+
+        def step_noise(t):
+            if t not in noises:
+                noises[t] = torch.randn((2, 1, 64, 64), device="cuda", generator=gen)
+            return noises[t]
+        return dif, dif.sample([g["x_input"].cuda()], batch_size=2, last=True, noise=g["ddim.noise0"].cuda(),
+                               step_noise=step_noise)[-1].float().cpu()
+    _, ref = run("fp32")
+    dif, out = run("bf16")
+    assert dif.final_fp32_steps == 1 and "fp32" in {k[0] for k in dif.model.unet0._engine}     # the tail engine was built
+    assert l2rel(out, ref) < 2e-2 and psnr(out, ref) > 40.0
+    assert torch.isfinite(out).all()
+
+
 def test_config2_256_bf16_50step_drift():
     """BASELINE configs[1] (256x256, 50-step DDIM, full architecture + DA-CLIP, bf16) in the production mode (last step:
     levels 0-1 on the fp32 engine) against the fp32 parity engine: L2 <= 1e-2, >= 45 dB (7.3e-3 / 53.4 dB measured;
