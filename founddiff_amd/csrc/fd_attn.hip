@@ -20,7 +20,7 @@ constexpr int LDP = 48;     // LDS row stride in floats (32 channels + pad: conf
 template <typename T>
 __global__ __launch_bounds__(256) void gram_kernel(const T *__restrict__ qkv, int64_t hw, int C,
                                                   float *__restrict__ partial, int nblk) {
-    __shared__ float sQ[64 * LDP], sK[64 * LDP];
+    __shared__ __attribute__((aligned(16))) float sQ[64 * LDP], sK[64 * LDP];
     __shared__ float sN[4][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int blk = blockIdx.x, head = blockIdx.y, b = blockIdx.z, heads = gridDim.y;
@@ -35,6 +35,45 @@ __global__ __launch_bounds__(256) void gram_kernel(const T *__restrict__ qkv, in
     float sq[8], sk[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) sq[e] = sk[e] = 0.f;
+    if constexpr (sizeof(T) == 2) {
+        // bf16: q, k are bf16 in HBM, so the bf16 MFMA is exact too (bf16 x bf16 products are exact in fp32) and
+        // contracts 32 pixels per instruction instead of 4 -- 2 MFMAs per 64-pixel step instead of 16 (PMC: the f32
+        // form kept the matrix pipe 37 % busy on a kernel that should be a pure q/k stream).  Its operands want 8
+        // consecutive PIXELS of one channel per lane: the tiles are staged transposed ([channel][pixel], 2-byte
+        // writes from the pixel-major loads).  The next step's loads are in flight during this step's LDS + MFMA.
+        constexpr int TLD = 64 + 8;                  // pixels per row + pad (bf16 elements)
+        bf16 *tQ = (bf16 *)sQ, *tK = (bf16 *)sK;     // [32][TLD] each (4.6 KB of the 12 KB arrays)
+        u32x4 qn = {0, 0, 0, 0}, kn = {0, 0, 0, 0};
+        auto fetch = [&](int64_t pt) {
+            const int64_t p = pt + pr;
+            qn = kn = (u32x4){0, 0, 0, 0};
+            if (p < p1) {
+                qn = *(const u32x4 *)(base + p * 3 * C + head * 32 + cv * 8);
+                kn = *(const u32x4 *)(base + p * 3 * C + C + head * 32 + cv * 8);
+            }
+        };
+        fetch(p0);
+        for (int64_t pt = p0; pt < p1; pt += 64) {
+            const bf16x8 q8 = __builtin_bit_cast(bf16x8, qn), k8 = __builtin_bit_cast(bf16x8, kn);
+            if (pt + 64 < p1) fetch(pt + 64);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float qf = (float)q8[e], kf = (float)k8[e];
+                sq[e] += qf * qf;
+                sk[e] += kf * kf;
+                tQ[(cv * 8 + e) * TLD + pr] = q8[e];
+                tK[(cv * 8 + e) * TLD + pr] = k8[e];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 a = *(const bf16x8 *)&tQ[(i0 + fr) * TLD + 32 * s + 8 * fg];
+                const bf16x8 bb = *(const bf16x8 *)&tK[(j0 + fr) * TLD + 32 * s + 8 * fg];
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bb, acc, 0, 0, 0);
+            }
+            __syncthreads();
+        }
+    } else {
     for (int64_t pt = p0; pt < p1; pt += 64) {
         const int64_t p = pt + pr;
         float q8[8], k8[8];
@@ -60,6 +99,7 @@ __global__ __launch_bounds__(256) void gram_kernel(const T *__restrict__ qkv, in
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bb, acc, 0, 0, 0);
         }
         __syncthreads();
+    }
     }
     float *out = partial + (((int64_t)b * heads + head) * nblk + blk) * (1024 + 64);
 #pragma unroll
