@@ -23,11 +23,12 @@ template <int NG>      // NG = Cout / 32
 __global__ __launch_bounds__(256, 2) void initconv7_kernel(const float *__restrict__ p0, const float *__restrict__ p1,
                                                           const float *__restrict__ p2, const bf16 *__restrict__ wk,
                                                           const float *__restrict__ bias, bf16 *__restrict__ out,
-                                                          int H, int W, int ITPW) {
+                                                          int H, int W) {
     __shared__ __attribute__((aligned(16))) uint2 sx[IHY * IHX];     // [row][col] -> 4 bf16 channel slots
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
-    const int tiles_x = W / IT, ntiles = tiles_x * (H / IT);
+    const int tiles_x = W / IT;
+    const int ty0 = (blockIdx.x / tiles_x) * IT, tx0 = (blockIdx.x % tiles_x) * IT;
     const int64_t img = blockIdx.y, plane = (int64_t)H * W;
     // weight fragments: row = output channel (permuted), 8 consecutive k of filter row kh
     const int rperm = 8 * (fr >> 2) + (fr & 3);
@@ -39,20 +40,6 @@ __global__ __launch_bounds__(256, 2) void initconv7_kernel(const float *__restri
             wa[g][kh] = *(const bf16x8 *)(wk + (int64_t)(32 * g + rperm) * 224 + kh * 32 + fg * 8);
             wb[g][kh] = *(const bf16x8 *)(wk + (int64_t)(32 * g + rperm + 4) * 224 + kh * 32 + fg * 8);
         }
-    float bs[NG][8];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        if (bias) load8(bias + 32 * g + 8 * fg, bs[g]);
-        else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) bs[g][e] = 0.f;
-        }
-    }
-    // A workgroup walks ITPW consecutive tiles with the weight fragments resident: per tile they are 3.5x the bytes
-    // of the output (112 VGPRs x 256 threads from L2 against 32 KiB stored), which held the layer at 1.4 TB/s
-    for (int tile = blockIdx.x * ITPW; tile < min((int)(blockIdx.x + 1) * ITPW, ntiles); ++tile) {
-    const int ty0 = (tile / tiles_x) * IT, tx0 = (tile % tiles_x) * IT;
-    __syncthreads();                                   // the previous tile's fragment reads are done
     // halo -> LDS
     for (int i = tid; i < IHY * IHX; i += 256) {
         const int hy = i / IHX, hx = i - hy * IHX;
@@ -80,6 +67,15 @@ __global__ __launch_bounds__(256, 2) void initconv7_kernel(const float *__restri
         sx[i] = wv;
     }
     __syncthreads();
+    float bs[NG][8];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if (bias) load8(bias + 32 * g + 8 * fg, bs[g]);
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bs[g][e] = 0.f;
+        }
+    }
     constexpr int CO = 32 * NG;
 #pragma unroll 1
     for (int i = 0; i < 4; ++i) {
@@ -110,7 +106,6 @@ __global__ __launch_bounds__(256, 2) void initconv7_kernel(const float *__restri
             store8(op + 32 * g, val);
         }
     }
-    }   // tile loop
 }
 
 }  // namespace
@@ -125,17 +120,13 @@ extern "C" int fd_init_conv7(int dtype, const float *p0, const float *p1, const 
                "(Cout=%d H=%d W=%d)", Cout, H, W);
     FD_REQUIRE(p0 && w_packed && out, "fd_init_conv7: null pointer");
     FD_REQUIRE(!bias || ((uintptr_t)bias & 15) == 0, "fd_init_conv7: bias must be 16-byte aligned");
-    // tiles per workgroup: as many as still leave >= 2 workgroups per CU (a tile's result does not depend on it)
-    const int64_t tiles = (int64_t)(H / IT) * (W / IT);
-    int itpw = 8;
-    while (itpw > 1 && tiles * B / itpw < 512) itpw >>= 1;
-    dim3 grid((unsigned)((tiles + itpw - 1) / itpw), B), block(256);
+    dim3 grid((H / IT) * (W / IT), B), block(256);
     if (Cout == 64)
         hipLaunchKernelGGL(initconv7_kernel<2>, grid, block, 0, (hipStream_t)stream, p0, p1, p2, (const bf16 *)w_packed, bias,
-                           (bf16 *)out, H, W, itpw);
+                           (bf16 *)out, H, W);
     else
         hipLaunchKernelGGL(initconv7_kernel<1>, grid, block, 0, (hipStream_t)stream, p0, p1, p2, (const bf16 *)w_packed, bias,
-                           (bf16 *)out, H, W, itpw);
+                           (bf16 *)out, H, W);
     FD_LAUNCH_OK("fd_init_conv7");
     return FD_OK;
 }
