@@ -31,6 +31,9 @@ typedef __attribute__((ext_vector_type(2))) __bf16 pd_bf16x2;
 __device__ __forceinline__ int xs_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 __device__ __forceinline__ int ts_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
+// hp / 18 for hp < 512 with one full-rate 24-bit multiply (the compiler's exact division is a quarter-rate mul_hi)
+__device__ __forceinline__ int div18(int hp) { return (int)(__umul24((unsigned)hp, 57u) >> 10); }
+
 struct PwDwParams {
     const bf16 *x; int ld_x, off_x;
     const float *ln_gamma, *ln_beta, *ln_shift, *ln_scale; int ln_ld; float ln_eps;
@@ -50,6 +53,9 @@ __global__ __launch_bounds__(256, 3) void pwdw_kernel(const PwDwParams p) {
     const int tiles_x = p.W / PT_W;
     const int ty0 = (blockIdx.x / tiles_x) * PT_H, tx0 = (blockIdx.x % tiles_x) * PT_W;
     const int64_t img = blockIdx.y;
+    const bf16 *xin = p.x + img * p.H * p.W * p.ld_x + p.off_x;                 // wave-uniform image bases
+    bf16 *zout = p.Cz > 0 ? p.out_z + img * p.H * p.W * p.ld_z + p.off_z : nullptr;
+    bf16 *dwout = p.out_dw + img * p.H * p.W * p.ld_dw + p.off_dw;
 
     // ---- phase 0: halo load -> LayerNorm + modulate -> xs
     if (tid < 64) {
@@ -64,9 +70,11 @@ __global__ __launch_bounds__(256, 3) void pwdw_kernel(const PwDwParams p) {
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
         const int hp = (tid + k * 256) >> 3;
-        const int hy = hp / PH_X, hx = hp - hy * PH_X;
+        const int hy = div18(hp), hx = hp - hy * PH_X;
         const int yc = min(max(ty0 + hy - 1, 0), p.H - 1), xc = min(max(tx0 + hx - 1, 0), p.W - 1);
-        raw[k] = *(const u32x4 *)(p.x + ((img * p.H + yc) * p.W + xc) * p.ld_x + p.off_x + v * 8);
+        // 32-bit element offsets from a per-image scalar base, 24-bit multiplies: the 64-bit form of this address
+        // cost 3 v_mad_u64_u32 + 4 v_mul_lo_u32 (quarter rate) per load
+        raw[k] = *(const u32x4 *)(xin + (__umul24(__umul24(yc, p.W) + xc, p.ld_x) + v * 8));
     }
     __syncthreads();                                   // sV
     float g8[8], b8[8];
@@ -104,7 +112,7 @@ __global__ __launch_bounds__(256, 3) void pwdw_kernel(const PwDwParams p) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int hp = (3 * wave + i) * 16 + fr;
-        const int hy = hp / PH_X, hx = hp - hy * PH_X;
+        const int hy = div18(hp), hx = hp - hy * PH_X;
         const int yy = ty0 + hy - 1, xx = tx0 + hx - 1;
         if (hp < PHP && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) inside |= 1u << i;
     }
@@ -152,7 +160,7 @@ __global__ __launch_bounds__(256, 3) void pwdw_kernel(const PwDwParams p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { val[e] = fd_silu(a0[e]); val[4 + e] = fd_silu(a1[e]); }
                 const int y = ty0 + 2 * wave + i, x = tx0 + fr;
-                store8(p.out_z + ((img * p.H + y) * p.W + x) * p.ld_z + p.off_z + 32 * ng + 8 * fg, val);
+                store8(zout + (__umul24(__umul24(y, p.W) + x, p.ld_z) + 32 * ng + 8 * fg), val);
             }
         }
     }
@@ -264,7 +272,7 @@ __global__ __launch_bounds__(256, 3) void pwdw_kernel(const PwDwParams p) {
                 for (int e = 0; e < 8; ++e) acc[e] = fd_silu(acc[e]);
             }
             const int y = ty0 + 4 * rh + rr, x = tx0 + px;
-            store8(p.out_dw + ((img * p.H + y) * p.W + x) * p.ld_dw + p.off_dw + c0, acc);
+            store8(dwout + (__umul24(__umul24(y, p.W) + x, p.ld_dw) + c0), acc);
         }
         __syncthreads();                               // ts is rewritten by the next chunk
     }
@@ -274,7 +282,7 @@ __global__ __launch_bounds__(256, 3) void pwdw_kernel(const PwDwParams p) {
 
 extern "C" int fd_pw_dw3x3_ok(int dtype, int Cin, int Cdw, int Cz, int H, int W) {
     return dtype == FD_BF16 && Cin == 64 && Cdw > 0 && Cdw % 64 == 0 && Cz >= 0 && Cz % 32 == 0 && H % PT_H == 0 &&
-           W % PT_W == 0 && (int64_t)H * W >= 32768;
+           W % PT_W == 0 && (int64_t)H * W >= 32768 && (int64_t)H * W * 256 < (1ll << 31);   // 32-bit element offsets
 }
 
 extern "C" int fd_pw_dw3x3(int dtype, const void *x, int ld_x, int off_x, int Cin, const float *ln_gamma,

@@ -201,6 +201,8 @@ __global__ __launch_bounds__(256) void dwconv3x3_bf16_kernel(const bf16 *__restr
     const int64_t img = blockIdx.z;
     const int x0 = (blockIdx.x / cblocks) * DWB_T, y0 = blockIdx.y * DWB_T;
     const int cbase = cb * DW_CB;
+    const bf16 *in_img = in + img * H * W * ld_in + off_in;
+    bf16 *out_img = out + img * H * W * ld_out + off_out;
     constexpr int HX = DWB_T + 2, HY = DWB_T + 2;
     // all halo loads of the thread are issued before the first LDS write (one HBM round trip per
     // workgroup instead of one per loop iteration)
@@ -217,7 +219,9 @@ __global__ __launch_bounds__(256) void dwconv3x3_bf16_kernel(const bf16 *__restr
         const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W && c0 < C;
         okm |= (ok ? 1u : 0u) << k;
         const int yc = min(max(yy, 0), H - 1), xc = min(max(xx, 0), W - 1), cc = min(c0, C - 8);
-        vals[k] = *(const u32x4 *)(in + ((img * H + yc) * W + xc) * ld_in + off_in + cc);
+        // 32-bit element offset from the image's (wave-uniform) base with 24-bit multiplies: the 64-bit form cost
+        // seven quarter-rate integer instructions per load in a kernel that is 80 % VALU-busy (launcher: H*W < 2^24)
+        vals[k] = *(const u32x4 *)(in_img + (__umul24(__umul24(yc, W) + xc, ld_in) + cc));
     }
     const int cv = tid & 7, px = (tid >> 3) & 15, rhalf = tid >> 7;
     const int c0 = cbase + cv * 8;
@@ -289,7 +293,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_bf16_kernel(const bf16 *__restr
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[e] = fd_silu(acc[e]);
         }
-        store8(out + ((img * H + y) * W + x) * ld_out + off_out + c0, acc);
+        store8(out_img + (__umul24(__umul24(y, W) + x, ld_out) + c0), acc);
     }
 }
 
@@ -416,6 +420,8 @@ extern "C" int fd_dwconv3x3(int dtype, const void *in, int ld_in, int off_in, co
     dim3 grid(((W + DW_TX - 1) / DW_TX) * cblocks, (H + DW_TY - 1) / DW_TY, (unsigned)B), block(256);
     const size_t lds = (size_t)(DW_TY + 2) * (DW_TX + 2) * DW_CB * (dtype == FD_BF16 ? 2 : 4);
     if (dtype == FD_BF16) {
+        FD_REQUIRE((int64_t)H * W < (1 << 24) && (int64_t)H * W * (ld_in > ld_out ? ld_in : ld_out) < (1ll << 31),
+                   "fd_dwconv3x3: image too large for the 24-bit pixel / 32-bit element indices of the bf16 kernel");
         dim3 gridb(((W + DWB_T - 1) / DWB_T) * cblocks, (H + DWB_T - 1) / DWB_T, (unsigned)B);
         const size_t ldsb = (size_t)(DWB_T + 2) * (DWB_T + 2) * DW_CB * 2;
         hipLaunchKernelGGL(dwconv3x3_bf16_kernel, gridb, block, ldsb, (hipStream_t)stream, (const bf16 *)in, ld_in,
