@@ -34,6 +34,13 @@ __device__ __forceinline__ int ts_off(int row, int chunk) { return row * 128 + (
 // hp / 18 for hp < 512 with one full-rate 24-bit multiply (the compiler's exact division is a quarter-rate mul_hi)
 __device__ __forceinline__ int div18(int hp) { return (int)(__umul24((unsigned)hp, 57u) >> 10); }
 
+// Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() is a fence + barrier: hipcc emits
+// s_waitcnt vmcnt(0) in front of it, i.e. every wave stops until all its outstanding global STORES are acknowledged
+// -- here that is up to 32 KiB of z / depthwise output per workgroup per phase, and it is what made the phases of this
+// kernel add up instead of overlapping (z stores 109 us + depthwise 107 us + ... = the whole 472 us).  The tiles only
+// communicate through LDS, so the stores may stay in flight across the barrier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 struct PwDwParams {
     const bf16 *x; int ld_x, off_x;
     const float *ln_gamma, *ln_beta, *ln_shift, *ln_scale; int ln_ld; float ln_eps;
@@ -48,6 +55,9 @@ __global__ __launch_bounds__(256, 3) void pwdw_kernel(const PwDwParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char xs[XS_B];     // LN'd input halo, [192][64] bf16
     __shared__ __attribute__((aligned(16))) unsigned char ts[TS_B];     // 1x1 output of one chunk, [180][64] bf16
     __shared__ float sV[2][64];
+    // tap-pair words [5][Cdw] + bias [Cdw] of the depthwise conv, staged once: a global load issued after a phase's
+    // stores cannot be waited for without waiting for those stores too (vmcnt retires in order)
+    __shared__ __attribute__((aligned(16))) uint32_t sW[6 * 192];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const int tiles_x = p.W / PT_W;
@@ -64,6 +74,8 @@ __global__ __launch_bounds__(256, 3) void pwdw_kernel(const PwDwParams p) {
         sV[0][tid] = g * sc;
         sV[1][tid] = be * sc + sh;
     }
+    for (int i = tid; i < 5 * p.Cdw; i += 256) sW[i] = p.w_dw[i];
+    for (int i = tid; i < p.Cdw; i += 256) sW[5 * p.Cdw + i] = p.b_dw ? __builtin_bit_cast(uint32_t, p.b_dw[i]) : 0u;
     constexpr int NLD = (PMT * 16 * 8) / 256;         // 6 chunks per thread cover all 192 rows
     const int v = tid & 7;
     u32x4 raw[NLD];
@@ -76,7 +88,7 @@ __global__ __launch_bounds__(256, 3) void pwdw_kernel(const PwDwParams p) {
         // cost 3 v_mad_u64_u32 + 4 v_mul_lo_u32 (quarter rate) per load
         raw[k] = *(const u32x4 *)(xin + (__umul24(__umul24(yc, p.W) + xc, p.ld_x) + v * 8));
     }
-    __syncthreads();                                   // sV
+    lds_barrier();                                   // sV
     float g8[8], b8[8];
     load8(&sV[0][v * 8], g8);
     load8(&sV[1][v * 8], b8);
@@ -116,7 +128,7 @@ __global__ __launch_bounds__(256, 3) void pwdw_kernel(const PwDwParams p) {
         const int yy = ty0 + hy - 1, xx = tx0 + hx - 1;
         if (hp < PHP && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) inside |= 1u << i;
     }
-    __syncthreads();
+    lds_barrier();
 
     // weight rows of a 32-channel group, permuted so that a lane ends up with 8 consecutive channels
     const int rperm = 8 * (fr >> 2) + (fr & 3);
@@ -184,15 +196,11 @@ __global__ __launch_bounds__(256, 3) void pwdw_kernel(const PwDwParams p) {
         float bs[8];
 #pragma unroll
         for (int t = 0; t < 5; ++t) {
-            const u32x4 w0 = *(const u32x4 *)(p.w_dw + t * p.Cdw + c0), w1 = *(const u32x4 *)(p.w_dw + t * p.Cdw + c0 + 4);
+            const u32x4 w0 = *(const u32x4 *)(sW + t * p.Cdw + c0), w1 = *(const u32x4 *)(sW + t * p.Cdw + c0 + 4);
             wt[t][0] = w0.x; wt[t][1] = w0.y; wt[t][2] = w0.z; wt[t][3] = w0.w;
             wt[t][4] = w1.x; wt[t][5] = w1.y; wt[t][6] = w1.z; wt[t][7] = w1.w;
         }
-        if (p.b_dw) load8(p.b_dw + c0, bs);
-        else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) bs[e] = 0.f;
-        }
+        load8((const float *)(sW + 5 * p.Cdw + c0), bs);
         // phase 1: t[hp][64 ch] = W_chunk . xn, 3 m-tiles per wave (fragments re-read per chunk: registers
         // are the scarce resource of this kernel, LDS bandwidth is not)
         bf16x8 xh[3][2];
@@ -224,7 +232,7 @@ __global__ __launch_bounds__(256, 3) void pwdw_kernel(const PwDwParams p) {
                 if (hp < PHP) *(bf16x8 *)(ts + ts_off(hp, 4 * ng + fg)) = o;
             }
         }
-        __syncthreads();
+        lds_barrier();
         // phase 2: depthwise 3x3 on ts
         uint32_t win[3][3][4];
 #pragma unroll
@@ -274,14 +282,14 @@ __global__ __launch_bounds__(256, 3) void pwdw_kernel(const PwDwParams p) {
             const int y = ty0 + 4 * rh + rr, x = tx0 + px;
             store8(dwout + (__umul24(__umul24(y, p.W) + x, p.ld_dw) + c0), acc);
         }
-        __syncthreads();                               // ts is rewritten by the next chunk
+        lds_barrier();                               // ts is rewritten by the next chunk
     }
 }
 
 }  // namespace
 
 extern "C" int fd_pw_dw3x3_ok(int dtype, int Cin, int Cdw, int Cz, int H, int W) {
-    return dtype == FD_BF16 && Cin == 64 && Cdw > 0 && Cdw % 64 == 0 && Cz >= 0 && Cz % 32 == 0 && H % PT_H == 0 &&
+    return dtype == FD_BF16 && Cin == 64 && Cdw > 0 && Cdw <= 192 && Cdw % 64 == 0 && Cz >= 0 && Cz % 32 == 0 && H % PT_H == 0 &&
            W % PT_W == 0 && (int64_t)H * W >= 32768 && (int64_t)H * W * 256 < (1ll << 31);   // 32-bit element offsets
 }
 
