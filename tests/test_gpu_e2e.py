@@ -195,6 +195,36 @@ def test_concurrent_half_batches_bitwise(golden):
     assert torch.equal(a[-1], b[-1]) and torch.equal(a[-1], c[-1]) and torch.equal(a[0], c[0])
 
 
+def test_hybrid_forward_stage_split():
+    """DAEngine.forward_hybrid: (i) with two engines of the SAME precision it is the plain forward, bit for bit, for
+    every split (the stage methods, the two skip stacks and the level boundary are consistent); (ii) fp32 outside /
+    bf16 inside lies between the two pure engines; (iii) fd_cast round-trips."""
+    from founddiff_amd import _lib as L, arch, synth
+    from founddiff_amd.engine import DAEngine
+    spec = arch.da_unet_spec(32, (1, 2, 4), prefix="", clip=TINY_CLIP)
+    w = synth.synth_state_dict(spec, seed=1)
+    g = torch.Generator().manual_seed(9)
+    x_in = (torch.rand(2, 1, 64, 64, generator=g) * 2 - 1).cuda()
+    x_t = (x_in + 0.1 * torch.randn(2, 1, 64, 64, generator=g).cuda()).contiguous()
+    tb = torch.full((2,), 300.0, device="cuda")
+    a32, b32, c16 = DAEngine(w, "", "cuda", "fp32"), DAEngine(w, "", "cuda", "fp32"), DAEngine(w, "", "cuda", "bf16")
+    for e in (a32, b32, c16):
+        e.encode_condition(x_in)
+    ref = a32.forward(x_t, x_in, tb).clone()
+    for k in (1, 2):
+        assert torch.equal(a32.forward_hybrid(b32, x_t, x_in, tb, outer_levels=k), ref), k
+    low = c16.forward(x_t, x_in, tb).clone()
+    hyb = a32.forward_hybrid(c16, x_t, x_in, tb, outer_levels=1).clone()
+    assert l2rel(hyb.cpu(), ref.cpu()) < l2rel(low.cpu(), ref.cpu()) < 5e-2
+    v = torch.randn(4096, generator=g).cuda()
+    h = torch.empty(4096, device="cuda", dtype=torch.bfloat16)
+    back = torch.empty(4096, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    L.call("fd_cast", L.FD_F32, v.data_ptr(), L.FD_BF16, h.data_ptr(), 4096, st)
+    L.call("fd_cast", L.FD_BF16, h.data_ptr(), L.FD_F32, back.data_ptr(), 4096, st)
+    assert torch.equal(h, v.to(torch.bfloat16)) and torch.equal(back, v.to(torch.bfloat16).float())
+
+
 def test_p_sample_loop_tiny_fp32(golden):
     """a6: the ancestral loop DRIVER (src/DADiff.py:1233-1273), all 1000 steps of config 1's model through
     p_sample_loop itself; the first 20 steps and x_T against the reference's goldens (noise supplied per step)."""
