@@ -725,3 +725,40 @@ def test_selective_scan_fused_xproj(cfg):
     torch.cuda.synchronize()
     assert rel_err(xdbl.cpu(), xd_rows) < 1e-5
     assert rel_err(nchw(y), ref) < 1e-2
+
+
+def test_integration_recipe_for_the_reference_extension():
+    """the reference imports its native op as
+    `from selective_scan_vmamba_pt202 import selective_scan_cuda_core` (src/emamba2.py:27) and calls
+    `selective_scan_cuda_core.fwd(u, delta, A, B, C, D, delta_bias, delta_softplus, nrows)` (154).  With the two
+    sys.modules entries of the recipe that import resolves to this library and the reference's own call pattern
+    (SelectiveScan.forward, 124-157: contiguity fix-ups, 3-D B/C un-squeezed, `out, x, *rest = ...`) runs unchanged."""
+    import importlib
+    import sys
+    import types
+    from oracle import nets
+    import founddiff_amd.selective_scan_cuda_core as ssc
+    saved = {k: sys.modules.get(k) for k in ("selective_scan_cuda_core", "selective_scan_vmamba_pt202")}
+    try:
+        sys.modules["selective_scan_cuda_core"] = ssc
+        pkg = types.ModuleType("selective_scan_vmamba_pt202")
+        pkg.selective_scan_cuda_core = ssc
+        sys.modules["selective_scan_vmamba_pt202"] = pkg
+        core = importlib.import_module("selective_scan_vmamba_pt202").selective_scan_cuda_core     # what line 27 binds
+        u, delta, A, Bm, Cm, D, bias = _scan_inputs(2, 64, 1, 8, 300, seed=21)
+        ud, dd = u.cuda().transpose(1, 2).contiguous().transpose(1, 2), delta.cuda()      # a non-contiguous u, as 134-135 guards
+        if ud.stride(-1) != 1:
+            ud = ud.contiguous()
+        B3, C3 = Bm[:, 0].cuda(), Cm[:, 0].cuda()                                          # 3-D B / C: 144-149
+        out, x, *rest = core.fwd(ud, dd, A.cuda(), B3.unsqueeze(1), C3.unsqueeze(1), D.cuda(), bias.cuda(), True, 1)
+        assert rest == [] and x.shape == (2, 64, 8)
+        ref = nets.selective_scan(u, delta, A, Bm[:, :1], Cm[:, :1], D, bias, softplus=True)
+        assert rel_err(out.cpu(), ref) < 1e-5
+        with pytest.raises(NotImplementedError):
+            core.bwd()
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
