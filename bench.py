@@ -11,7 +11,6 @@ no data-path collective (weak scaling); one RCCL all-gather reassembles the outp
 the end of the timed region.  Rank 0 prints ONE JSON line.
 """
 import argparse
-import ctypes as C
 import json
 import os
 import sys

@@ -7,7 +7,6 @@ Layout: activations NHWC; `mode` 'fp32' (parity: fp32 storage, exact-f32 MFMA) o
 (bf16 storage + bf16 MFMA, fp32 accumulation/statistics/scan state).
 """
 import ctypes as C
-import math
 
 import torch
 
