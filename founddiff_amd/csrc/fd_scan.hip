@@ -200,18 +200,15 @@ __global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 8 ? 5 : 1))) void scan_ch
     int co = __builtin_amdgcn_readfirstlane(l0 / NI);
     __syncthreads();
 
-    // dt of one position: softplus(w . dt_r + bias) (base-2 units in bf16 mode) -- no dependence on the state
-    auto dt_of = [&](const float *xr) -> float {
+    auto step = [&](const float *xr, float u, int soff) {
         const f32x2 *xr2 = (const f32x2 *)xr;          // row = [dt_r (R) | B (N) | C (N)], all even
         f32x2 dv2 = {bias, 0.f};
 #pragma unroll
         for (int r = 0; r < R / 2; ++r) dv2 = w[r] * xr2[r] + dv2;
         const float dv = dv2.x + dv2.y;
-        if constexpr (LOG2U) return __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(fminf(dv, 126.f)));
-        else return fd_softplus_fast(dv);
-    };
-    auto step_dt = [&](const float *xr, float u, float dt, int soff) {
-        const f32x2 *xr2 = (const f32x2 *)xr;
+        float dt;
+        if constexpr (LOG2U) dt = __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(fminf(dv, 126.f)));
+        else dt = fd_softplus_fast(dv);
         const float dtu = dt * u;
         if (!FINAL) sdt += dt;
         f32x2 acc2 = {0.f, 0.f};
@@ -224,7 +221,6 @@ __global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 8 ? 5 : 1))) void scan_ch
         }
         if (FINAL) st_y(soff, acc2.x + acc2.y + Dd * u);
     };
-    auto step = [&](const float *xr, float u, int soff) { step_dt(xr, u, dt_of(xr), soff); };
     auto advance = [&](int &soff) {            // -> byte offset of the pixel's row inside the image (-1: padding)
         soff = pixc * rowb;
         if (ODD && ((padF && ci == NI - 1) || (padS && co == NO - 1))) soff = -1;
@@ -249,18 +245,8 @@ __global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 8 ? 5 : 1))) void scan_ch
         for (int s = 0; s < U; ++s) u[s] = ld_u(pix[s]);
     };
     auto run = [&](const int (&pix)[U], const float (&u)[U]) {
-        if constexpr (N <= 8) {
-            // small states: the U dt values of the group first (independent chains: the transcendental / packed-FMA
-            // wait states of one position fill with the next position's work), then the state recurrences
-            float dts[U];
 #pragma unroll
-            for (int s = 0; s < U; ++s) dts[s] = dt_of(sx + (l - l0 + s) * CDP);
-#pragma unroll
-            for (int s = 0; s < U; ++s) step_dt(sx + (l - l0 + s) * CDP, u[s], dts[s], pix[s]);
-        } else {
-#pragma unroll
-            for (int s = 0; s < U; ++s) step(sx + (l - l0 + s) * CDP, u[s], pix[s]);
-        }
+        for (int s = 0; s < U; ++s) step(sx + (l - l0 + s) * CDP, u[s], pix[s]);
         l += U;
     };
     if (ngroups > 0) fetch(pixA, uA);
