@@ -60,9 +60,13 @@ SIGNATURES = {
     "fd_pw_dw3x3_ok": (i32, [i32, i32, i32, i32, i32, i32]),
     "fd_pw_dw3x3": (i32, [i32, vp, i32, i32, i32, vp, vp, f32, vp, vp, i32, vp, i32, vp, vp, i32, vp, i32, i32,
                           i32, vp, i32, i32, i32, i32, i32, vp]),
+    "fd_pw_dw3x3_gram_ok": (i32, [i32, i32, i32, i32]),
+    "fd_pw_dw3x3_gram_nblk": (i32, [i32, i32]),
+    "fd_pw_dw3x3_gram": (i32, [i32, vp, i32, i32, i32, vp, vp, f32, vp, vp, i32, vp, vp, vp, i32, i32, vp, i32, i32, i32, vp]),
     "fd_scan_ws_floats": (i64, [i32, i32, i32, i32, i32]),
     "fd_selective_scan": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "fd_selective_scan_fuses_xproj": (i32, [i32, i32, i32, i32]),
+    "fd_selective_scan_plan": (i32, [i32, i32, i32, i32, i32, i32]),
     "fd_selective_scan_xproj": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "fd_selective_scan_fwd_f32": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i64, vp, vp, vp]),
     "fd_chan_attn_nblk": (i32, [i64]),

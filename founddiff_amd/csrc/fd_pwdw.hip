@@ -18,6 +18,7 @@
 //   phase 2  the depthwise 3x3 of dwconv3x3_bf16_kernel on that tile (register row window,
 //            v_dot2c_f32_bf16 against pre-masked bf16 tap weights), 16-byte stores.
 #include "fd_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -286,6 +287,299 @@ __global__ __launch_bounds__(256, 3) void pwdw_kernel(const PwDwParams p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// qkv -> qkv_dwconv -> L2 norms + q k^T (src/DADiff.py:266-276) in ONE pass: q and k never reach HBM.
+// The attention of TransposedAttention is a 32x32 matrix per head whose reduction runs over ALL pixels, so q and k
+// are consumed by nothing but their Gram product and their norms.  The unfused sequence wrote them (2/3 of the 192
+// channels the qkv variant of pwdw_kernel stores) and gram_kernel read them back: 4 of the ~26 tensor passes of a
+// 64-channel Mamba block.  Here a workgroup walks `tpw` consecutive 8x16 tiles; per tile the chunks run in the order
+// v, q, k:  v goes to HBM as before; q's depthwise output is parked in registers (16 packed words) while k's 1x1
+// runs, then written as a [128 px][64 ch] bf16 tile over xs (the LayerNorm'd halo is dead once k's 1x1 has read
+// it); k's output goes over ts the same way; the 32x32 Gram of both heads and the sums of squares are 16 bf16
+// MFMAs per wave whose operands (8 consecutive PIXELS of one channel per lane) come out of those pixel-major tiles
+// through the transposing LDS read ds_read_b64_tr_b16 -- no 2-byte LDS scatter as in gram_kernel (59 % bank
+// conflicts).  LDS stays at the 52 KB of pwdw_kernel (3 workgroups per CU).  The norms are the diagonals of q q^T and
+// k k^T from the same fragments (the matrix pipe is idle in this kernel), i.e. norms and Gram see the same
+// bf16-rounded values, as in the unfused path.  Accumulators persist over the workgroup's tiles; one partial of
+// 2 x (1024 + 64) floats per workgroup, reduced in fixed order by fd_chan_attn_weff.
+typedef __attribute__((ext_vector_type(4))) short pd_s16x4;
+typedef __attribute__((ext_vector_type(8))) short pd_s16x8;
+
+struct PwGramParams {
+    const bf16 *x; int ld_x, off_x;
+    const float *ln_gamma, *ln_beta, *ln_shift, *ln_scale; int ln_ld; float ln_eps;
+    const bf16 *w_pw;                 // [192][64]: q | k | v rows
+    const uint32_t *w_dw;             // [5][192]
+    bf16 *out_v; int ld_v, off_v;
+    float *part; int nblk;            // [B][2 heads][nblk][1024 + 64]
+    int H, W, tpw, ntiles;
+};
+
+// q / k tile: row = tile pixel (128 B = 64 channels), 16-byte chunk index XORed with an EVEN value so that the two
+// chunks of a 16-channel fragment column stay adjacent; the 8 rows one 32-lane half of a transposing read touches
+// (pixels 8g .. 8g+3 of two k-groups) land on 8 distinct 8-bank slots
+__device__ __forceinline__ int gt_swz(int pix) { return (((pix >> 1) & 1) << 1) | (((pix >> 3) & 1) << 2); }
+__device__ __forceinline__ int gt_off(int pix, int chunk) { return pix * 128 + ((chunk ^ gt_swz(pix)) << 4); }
+
+__device__ __forceinline__ pd_s16x4 lds_tr16(const unsigned char *p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) pd_s16x4 *)p);
+}
+
+__global__ __launch_bounds__(256, 3) void pwdw_gram_kernel(const PwGramParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char xs[XS_B];
+    __shared__ __attribute__((aligned(16))) unsigned char ts[TS_B];
+    __shared__ float sV[2][64];
+    __shared__ __attribute__((aligned(16))) uint32_t sW[5 * 192];
+    constexpr int CDW = 192;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int tiles_x = p.W / PT_W;
+    const int64_t img = blockIdx.y;
+    const bf16 *xin = p.x + img * p.H * p.W * p.ld_x + p.off_x;
+    bf16 *vout = p.out_v + img * p.H * p.W * p.ld_v + p.off_v;
+    if (tid < 64) {
+        const float sc = 1.f + p.ln_scale[img * p.ln_ld + tid], sh = p.ln_shift[img * p.ln_ld + tid];
+        const float g = p.ln_gamma ? p.ln_gamma[tid] : 1.f, be = p.ln_beta ? p.ln_beta[tid] : 0.f;
+        sV[0][tid] = g * sc;
+        sV[1][tid] = be * sc + sh;
+    }
+    for (int i = tid; i < 5 * CDW; i += 256) sW[i] = p.w_dw[i];
+    constexpr int NLD = (PMT * 16 * 8) / 256;
+    const int v = tid & 7;
+    const int rperm = 8 * (fr >> 2) + (fr & 3);
+    // 1x1 weight rows in 32-row groups, in the order the chunks run: v (rows 128..191), q (0..63), k (64..127)
+    bf16x8 wnext[4];
+    auto wload = [&](int si) {
+        const int rb = si < 2 ? 128 + 32 * si : 32 * (si - 2);
+        const bf16 *wr = p.w_pw + (int64_t)(rb + rperm) * 64 + fg * 8;
+        wnext[0] = *(const bf16x8 *)(wr);
+        wnext[1] = *(const bf16x8 *)(wr + 32);
+        wnext[2] = *(const bf16x8 *)(wr + 4 * 64);
+        wnext[3] = *(const bf16x8 *)(wr + 4 * 64 + 32);
+    };
+    // phase-2 roles: 8-channel vector cv of tile column px, rows 4*rh .. 4*rh+3
+    const int cv = tid & 7, px = (tid >> 3) & 15, rh = tid >> 7;
+    int toff[6][3];
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) toff[r][dx] = ts_off((4 * rh + r) * PH_X + px + dx, cv);
+    // Gram roles: wave = (head, 16-row block of q channels); transposing-read lane roles
+    const int hd = wave >> 1, mb = wave & 1;
+    const int tq = (lane >> 2) & 3, tp = lane & 3;
+    f32x4 gacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, gnq = {0.f, 0.f, 0.f, 0.f}, gnk = {0.f, 0.f, 0.f, 0.f};
+    wload(0);
+    lds_barrier();                                   // sV, sW
+
+    const int tile0 = blockIdx.x * p.tpw;
+    for (int tt = 0; tt < p.tpw; ++tt) {
+        const int tile = tile0 + tt;
+        if (tile >= p.ntiles) break;                 // workgroup-uniform
+        const int ty0 = (tile / tiles_x) * PT_H, tx0 = (tile % tiles_x) * PT_W;
+        // the halo geometry of a thread does not depend on the tile; hoisted out of this loop it would be ~40 more
+        // live registers (spilled: scratch reloads in front of every tile).  An opaque copy of tid keeps it inside.
+        int tl = tid;
+        asm volatile("" : "+v"(tl));
+        // ---- phase 0: halo load -> LayerNorm + modulate -> xs
+        u32x4 raw[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int hp = (tl + k * 256) >> 3;
+            const int hy = div18(hp), hx = hp - hy * PH_X;
+            const int yc = min(max(ty0 + hy - 1, 0), p.H - 1), xc = min(max(tx0 + hx - 1, 0), p.W - 1);
+            raw[k] = *(const u32x4 *)(xin + (__umul24(__umul24(yc, p.W) + xc, p.ld_x) + v * 8));
+        }
+        float g8[8], b8[8];
+        load8(&sV[0][v * 8], g8);
+        load8(&sV[1][v * 8], b8);
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int hp = (tl + k * 256) >> 3;
+            float f[8];
+            const bf16x8 xv = __builtin_bit_cast(bf16x8, raw[k]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = (float)xv[e];
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += f[e];
+            s += __shfl_xor(s, 1, 64);
+            s += __shfl_xor(s, 2, 64);
+            s += __shfl_xor(s, 4, 64);
+            const float mean = s * (1.f / 64);
+            float q = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = f[e] - mean; q += d * d; }
+            q += __shfl_xor(q, 1, 64);
+            q += __shfl_xor(q, 2, 64);
+            q += __shfl_xor(q, 4, 64);
+            const float rstd = rsqrtf(q * (1.f / 64) + p.ln_eps);
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16)((f[e] - mean) * rstd * g8[e] + b8[e]);
+            *(bf16x8 *)(xs + xs_off(hp, v)) = o;
+        }
+        uint32_t inside = 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int hp = (3 * (tl >> 6) + i) * 16 + (tl & 15);
+            const int hy = div18(hp), hx = hp - hy * PH_X;
+            const int yy = ty0 + hy - 1, xx = tx0 + hx - 1;
+            if (hp < PHP && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) inside |= 1u << i;
+        }
+        lds_barrier();
+
+        u32x4 pk[4];                                   // q, then k: this thread's 4 rows x 8 channels, bf16
+#pragma unroll 1
+        for (int ci = 0; ci < 3; ++ci) {
+            const int ch = ci == 0 ? 2 : ci - 1;       // v, q, k
+            // phase 1: t[hp][64 ch] = W_chunk . xn, 3 m-tiles per wave
+            bf16x8 xh[3][2];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    xh[i][ks] = *(const bf16x8 *)(xs + xs_off((3 * wave + i) * 16 + fr, ks * 4 + fg));
+#pragma unroll
+            for (int ng = 0; ng < 2; ++ng) {
+                const bf16x8 wa[2] = {wnext[0], wnext[1]}, wb[2] = {wnext[2], wnext[3]};
+                const int si = 2 * ci + ng + 1;
+                wload(si < 6 ? si : 0);                // after k: the next tile's first v group
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ks], xh[i][ks], a0, 0, 0, 0);
+                        a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[ks], xh[i][ks], a1, 0, 0, 0);
+                    }
+                    const int hp = (3 * wave + i) * 16 + fr;
+                    const bool in = (inside >> i) & 1;
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        o[e] = (bf16)(in ? a0[e] : 0.f);
+                        o[4 + e] = (bf16)(in ? a1[e] : 0.f);
+                    }
+                    if (hp < PHP) *(bf16x8 *)(ts + ts_off(hp, 4 * ng + fg)) = o;
+                }
+            }
+            lds_barrier();
+            if (ci == 2) {
+                // xs is dead (k's 1x1 was its last reader, and every wave is past the barrier): park q there
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+                    *(u32x4 *)(xs + gt_off((4 * rh + rr) * PT_W + px, cv)) = pk[rr];
+            }
+            // phase 2: depthwise 3x3 on ts
+            const int c0 = 64 * ch + cv * 8;
+            uint32_t wt[5][8];
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                const u32x4 w0 = *(const u32x4 *)(sW + t * CDW + c0), w1 = *(const u32x4 *)(sW + t * CDW + c0 + 4);
+                wt[t][0] = w0.x; wt[t][1] = w0.y; wt[t][2] = w0.z; wt[t][3] = w0.w;
+                wt[t][4] = w1.x; wt[t][5] = w1.y; wt[t][6] = w1.z; wt[t][7] = w1.w;
+            }
+            uint32_t win[3][3][4];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const u32x4 t4 = *(const u32x4 *)(ts + toff[s][dx]);
+                    win[s][dx][0] = t4.x; win[s][dx][1] = t4.y; win[s][dx][2] = t4.z; win[s][dx][3] = t4.w;
+                }
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const u32x4 t4 = *(const u32x4 *)(ts + toff[rr + 2][dx]);
+                    uint32_t *wr_ = win[(rr + 2) % 3][dx];
+                    wr_[0] = t4.x; wr_[1] = t4.y; wr_[2] = t4.z; wr_[3] = t4.w;
+                }
+                float acc[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+                for (int pr = 0; pr < 4; ++pr)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t xa = pr < 3 ? win[rr % 3][pr][j] : win[(rr + 2) % 3][0][j];
+                        const uint32_t xb = pr < 3 ? win[(rr + 1) % 3][pr][j] : win[(rr + 2) % 3][1][j];
+                        const uint32_t lo = __builtin_amdgcn_perm(xb, xa, 0x05040100);
+                        const uint32_t hi = __builtin_amdgcn_perm(xb, xa, 0x07060302);
+                        acc[2 * j] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(pd_bf16x2, lo),
+                            __builtin_bit_cast(pd_bf16x2, wt[pr][2 * j]), acc[2 * j], false);
+                        acc[2 * j + 1] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(pd_bf16x2, hi),
+                            __builtin_bit_cast(pd_bf16x2, wt[pr][2 * j + 1]), acc[2 * j + 1], false);
+                    }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const pd_bf16x2 xv = __builtin_bit_cast(pd_bf16x2, win[(rr + 2) % 3][2][j]);
+                    acc[2 * j] = __builtin_amdgcn_fdot2_f32_bf16(xv, __builtin_bit_cast(pd_bf16x2, wt[4][2 * j]), acc[2 * j], false);
+                    acc[2 * j + 1] = __builtin_amdgcn_fdot2_f32_bf16(xv, __builtin_bit_cast(pd_bf16x2, wt[4][2 * j + 1]), acc[2 * j + 1], false);
+                }
+                if (ci == 0) {
+                    const int y = ty0 + 4 * rh + rr, x = tx0 + px;
+                    store8(vout + (__umul24(__umul24(y, p.W) + x, p.ld_v) + cv * 8), acc);
+                } else {
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (bf16)acc[e];
+                    pk[rr] = __builtin_bit_cast(u32x4, o);
+                }
+            }
+            lds_barrier();                               // every read of ts is done
+        }
+        // k tile over ts, then the Gram of this tile
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+            *(u32x4 *)(ts + gt_off((4 * rh + rr) * PT_W + px, cv)) = pk[rr];
+        lds_barrier();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            pd_s16x4 a[2], b0[2], b1[2];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int pix = 32 * ks + 8 * fg + 4 * hf + tq;
+                const int rowb = pix * 128, sw = gt_swz(pix), sub = 8 * (tp & 1);
+                const int cq = hd * 4 + mb * 2 + (tp >> 1), ck0 = hd * 4 + (tp >> 1), ck1 = ck0 + 2;
+                a[hf] = lds_tr16(xs + rowb + ((cq ^ sw) << 4) + sub);
+                b0[hf] = lds_tr16(ts + rowb + ((ck0 ^ sw) << 4) + sub);
+                b1[hf] = lds_tr16(ts + rowb + ((ck1 ^ sw) << 4) + sub);
+            }
+            const bf16x8 A = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a[0], a[1], 0, 1, 2, 3, 4, 5, 6, 7));
+            const bf16x8 B0 = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0[0], b0[1], 0, 1, 2, 3, 4, 5, 6, 7));
+            const bf16x8 B1 = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b1[0], b1[1], 0, 1, 2, 3, 4, 5, 6, 7));
+            gacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B0, gacc[0], 0, 0, 0);
+            gacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B1, gacc[1], 0, 0, 0);
+            gnq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, A, gnq, 0, 0, 0);
+            const bf16x8 Bm = mb ? B1 : B0;
+            gnk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bm, Bm, gnk, 0, 0, 0);
+        }
+        lds_barrier();                                   // the next tile's phase 0 rewrites xs
+    }
+    // partial of this workgroup: per head [32 q channels][32 k channels], then sum q^2 (32), sum k^2 (32) -- staged
+    // in LDS (ts is free: the loop ends with a barrier) so that the 8.7 KB leave as 16-byte stores
+    float *sp = (float *)ts + hd * (1024 + 64);
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sp[(mb * 16 + 4 * fg + e) * 32 + nb * 16 + fr] = gacc[nb][e];
+    if ((fr >> 2) == fg) {                               // lanes that hold a diagonal element: row 4*fg + e == column fr
+        const int e = fr & 3;
+        const float nq = e == 0 ? gnq[0] : (e == 1 ? gnq[1] : (e == 2 ? gnq[2] : gnq[3]));
+        const float nk = e == 0 ? gnk[0] : (e == 1 ? gnk[1] : (e == 2 ? gnk[2] : gnk[3]));
+        sp[1024 + mb * 16 + fr] = nq;
+        sp[1024 + 32 + mb * 16 + fr] = nk;
+    }
+    lds_barrier();
+    for (int i = tid; i < 2 * (1024 + 64) / 4; i += 256) {
+        const int h2 = i / ((1024 + 64) / 4), r = i - h2 * ((1024 + 64) / 4);
+        float *out = p.part + ((img * 2 + h2) * p.nblk + blockIdx.x) * (1024 + 64);
+        *(f32x4 *)(out + 4 * r) = *(const f32x4 *)((const float *)ts + h2 * (1024 + 64) + 4 * r);
+    }
+}
+
 }  // namespace
 
 extern "C" int fd_pw_dw3x3_ok(int dtype, int Cin, int Cdw, int Cz, int H, int W) {
@@ -316,5 +610,45 @@ extern "C" int fd_pw_dw3x3(int dtype, const void *x, int ld_x, int off_x, int Ci
     dim3 grid((H / PT_H) * (W / PT_W), B), block(256);
     hipLaunchKernelGGL(pwdw_kernel, grid, block, 0, (hipStream_t)stream, p);
     FD_LAUNCH_OK("fd_pw_dw3x3");
+    return FD_OK;
+}
+
+// tiles per workgroup of the Gram-fused qkv kernel: a constant of the build (the order of the partial sums, hence
+// the result, must not depend on the batch); FD_GRAM_TPW overrides it for experiments
+static int gram_tpw() {
+    static const int t = [] { const char *e = getenv("FD_GRAM_TPW"); const int v = e ? atoi(e) : 4; return v >= 1 && v <= 64 ? v : 4; }();
+    return t;
+}
+
+extern "C" int fd_pw_dw3x3_gram_ok(int dtype, int Cin, int H, int W) {
+    static const bool off = getenv("FD_NO_GRAM_FUSE") != nullptr;      // development switch
+    return !off && fd_pw_dw3x3_ok(dtype, Cin, 192, 0, H, W);
+}
+
+extern "C" int fd_pw_dw3x3_gram_nblk(int H, int W) {
+    const int ntiles = (H / PT_H) * (W / PT_W);
+    return (ntiles + gram_tpw() - 1) / gram_tpw();
+}
+
+extern "C" int fd_pw_dw3x3_gram(int dtype, const void *x, int ld_x, int off_x, int Cin, const float *ln_gamma,
+                                const float *ln_beta, float ln_eps, const float *ln_shift, const float *ln_scale,
+                                int ln_ld, const void *w_pw, const uint32_t *w_dw, void *out_v, int ld_v, int off_v,
+                                float *partial, int B, int H, int W, void *stream) {
+    FD_REQUIRE(fd_pw_dw3x3_ok(dtype, Cin, 192, 0, H, W),
+               "fd_pw_dw3x3_gram: unsupported shape (bf16, Cin=64, H%%8, W%%16, >= 32768 px): Cin=%d H=%d W=%d", Cin, H, W);
+    FD_REQUIRE(x && ln_shift && ln_scale && w_pw && w_dw && out_v && partial, "fd_pw_dw3x3_gram: null pointer");
+    FD_REQUIRE(ld_x % 8 == 0 && off_x % 8 == 0 && ld_v % 8 == 0 && off_v % 8 == 0,
+               "fd_pw_dw3x3_gram: strides / offsets must be multiples of 8 channels");
+    FD_REQUIRE(((uintptr_t)w_dw & 15) == 0, "fd_pw_dw3x3_gram: weights must be 16-byte aligned");
+    PwGramParams p;
+    p.x = (const bf16 *)x; p.ld_x = ld_x; p.off_x = off_x;
+    p.ln_gamma = ln_gamma; p.ln_beta = ln_beta; p.ln_shift = ln_shift; p.ln_scale = ln_scale; p.ln_ld = ln_ld; p.ln_eps = ln_eps;
+    p.w_pw = (const bf16 *)w_pw; p.w_dw = w_dw;
+    p.out_v = (bf16 *)out_v; p.ld_v = ld_v; p.off_v = off_v;
+    p.part = partial; p.nblk = fd_pw_dw3x3_gram_nblk(H, W);
+    p.H = H; p.W = W; p.tpw = gram_tpw(); p.ntiles = (H / PT_H) * (W / PT_W);
+    dim3 grid(p.nblk, B), block(256);
+    hipLaunchKernelGGL(pwdw_gram_kernel, grid, block, 0, (hipStream_t)stream, p);
+    FD_LAUNCH_OK("fd_pw_dw3x3_gram");
     return FD_OK;
 }

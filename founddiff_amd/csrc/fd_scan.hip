@@ -12,6 +12,7 @@
 // R-vector), nor dA/dBu ever exist in HBM.  Algorithmic HBM bytes per (pixel, channel):
 // u read twice + y written once (dtype), plus the x_dbl rows (fp32, shared by all channels).
 #include "fd_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -361,9 +362,269 @@ __global__ __launch_bounds__(64 * SEG) void scan_carry_kernel(float *__restrict_
     }
 }
 
+// ---- Single-pass scan for short sequences with a wide state (L <= 1024 and N >= 16: the 64x64 level of a 512x512
+// slice, N = 32; levels 2-3 of a 256x256 slice).  The chunked form above runs the recurrence TWICE (local scan, then
+// the re-run from the carry-in: every exp2, softplus and dt_proj a second time) and, with 32-step chunks and N = 32,
+// moves 4x the u / y bytes through its fp32 chunk-state workspace (N floats per channel and chunk, written, carried,
+// read back).  Where the state is wide the parallelism is in the STATE: SEQ_LPC = 4 neighbouring lanes share one
+// channel, each owns N/4 states and R/4 of the dt_proj contraction, and the sequence is walked once from h = 0 -- no
+// chunks, no workspace, no carry kernel.  Per step: dt_proj partial (R/4 FMAs) + quad all-reduce (2 DPP adds),
+// softplus (replicated in the 4 lanes), N/4 state updates as float pairs, y partial + quad all-reduce, lane 0 of the
+// quad stores.  The x_dbl rows of SEQ_SP positions are staged in LDS (double buffer, the next block's global loads in
+// flight during the current block's steps); each lane reads its own slices of a row: 4 distinct addresses per
+// ds_read.  Which path runs is a function of (H, W, N, R) only -- never of the batch -- so a slice's result does not
+// depend on what else is in the batch (scan_seq_ok).
+constexpr int SEQ_LPC = 4, SEQ_SP = 32, SEQ_MAXL = 1024;
+
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // lane ^ 1
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // lane ^ 2
+    return v;
+}
+
+template <typename T, int N, int R, bool ODD>
+__global__ __launch_bounds__(256) void scan_seq_kernel(const T *__restrict__ xc, const float *__restrict__ xdbl,
+                                                      const float *__restrict__ dtw, const float *__restrict__ dtb,
+                                                      const float *__restrict__ A, const float *__restrict__ Ds,
+                                                      T *__restrict__ y, const ScanGeom g) {
+    constexpr int LPC = SEQ_LPC, NS = N / LPC, RS = R / LPC, SP = SEQ_SP;
+    constexpr int CD = R + 2 * N, CD4 = CD / 4;
+    static_assert(NS % 2 == 0 && RS % 2 == 0 && CD % 4 == 0 && (R + N) % 4 == 0, "scan_seq_kernel: slice shapes");
+    constexpr bool LOG2U = sizeof(T) == 2;                           // see scan_chunk_kernel: dt in base-2 units
+    constexpr float WS = LOG2U ? 1.4426950408889634f : 1.f;
+    constexpr float AS = LOG2U ? 1.f : 1.4426950408889634f;
+    __shared__ __attribute__((aligned(16))) float sx[2][SP * CD];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sub = lane & 3;
+    const int bk = blockIdx.y, b = bk >> 2, k = bk & 3;
+    const int d = blockIdx.x * 64 + wave * 16 + (lane >> 2);
+    const int kd = k * g.D + d;
+    const int odd = k & 1, ph = k & 1, pw = k >> 1;
+    const float *xb = xdbl + ((int64_t)k * g.B + b) * g.L * CD;       // [4][B][L][CD], row = h2 * W2 + w2
+
+    f32x2 w[RS / 2], a2[NS / 2], h[NS / 2];
+#pragma unroll
+    for (int r = 0; r < RS / 2; ++r)
+        w[r] = f32x2{dtw[(int64_t)kd * R + sub * RS + 2 * r], dtw[(int64_t)kd * R + sub * RS + 2 * r + 1]} * WS;
+#pragma unroll
+    for (int n = 0; n < NS / 2; ++n) {
+        a2[n] = f32x2{A[(int64_t)kd * N + sub * NS + 2 * n], A[(int64_t)kd * N + sub * NS + 2 * n + 1]} * AS;
+        h[n] = f32x2{0.f, 0.f};
+    }
+    const float bias = dtb[kd] * WS;
+    const float Dd = Ds[kd];
+
+    const T *ub = xc + (int64_t)b * g.H * g.W * g.D;
+    T *yb = y + (int64_t)b * g.H * g.W * g.D;
+    const int rowb = g.D * (int)sizeof(T);
+    const int img_bytes = g.H * g.W * rowb;
+    const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc((void *)ub, 0, img_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void *)yb, 0, img_bytes, 0x00020000);
+    const int voff = d * (int)sizeof(T);
+    // u is kept RAW (16 / 32 bits as loaded) until the step that uses it: converting at load time puts the wait for
+    // the whole group's loads in front of the previous group's steps
+    auto ld_u = [&](int soff_) -> uint32_t {
+        const int soff = __builtin_amdgcn_readfirstlane(soff_);
+        if (ODD && soff < 0) return 0u;
+        if constexpr (sizeof(T) == 2) return (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rs_u, voff, soff, 0);
+        else return __builtin_amdgcn_raw_buffer_load_b32(rs_u, voff, soff, 0);
+    };
+    auto cvt_u = [&](uint32_t r) -> float {
+        if constexpr (sizeof(T) == 2) return __builtin_bit_cast(float, r << 16);
+        else return __builtin_bit_cast(float, r);
+    };
+    // all four lanes of a quad hold the same y (quad_sum is an all-reduce) and store it to the same address: no
+    // exec-mask branch inside the unrolled group, one basic block for the scheduler
+    auto st_y = [&](int soff_, float v) {
+        // the offsets are wave-uniform by construction; when the register allocator parks a group's offsets in VGPRs
+        // across the loop back-edge the store would otherwise become a waterfall loop
+        const int soff = __builtin_amdgcn_readfirstlane(soff_);
+        if (ODD && soff < 0) return;
+        if constexpr (sizeof(T) == 2) {
+            const bf16 hv = (bf16)v;
+            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hv), rs_y, voff, soff, 0);
+        } else {
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs_y, voff, soff, 0);
+        }
+    };
+    // scan position -> pixel: the branch-free scalar walk of scan_chunk_kernel, from l = 0
+    const int NI = odd ? g.H2 : g.W2;
+    const int s_i = odd ? 2 * g.W : 2, s_o = odd ? 2 : 2 * g.W;
+    int ci = 0, co = 0;
+    int pixc = __builtin_amdgcn_readfirstlane(ph * g.W + pw);
+    const int wrap_fix = s_o - NI * s_i;
+    const int NO = odd ? g.W2 : g.H2;
+    const bool padF = ODD && (odd ? ((g.H & 1) && ph) : ((g.W & 1) && pw));
+    const bool padS = ODD && (odd ? ((g.W & 1) && pw) : ((g.H & 1) && ph));
+    auto advance = [&](int &soff) {
+        soff = pixc * rowb;
+        if (ODD && ((padF && ci == NI - 1) || (padS && co == NO - 1))) soff = -1;
+        ++ci;
+        const bool wrap = ci == NI;
+        ci = wrap ? 0 : ci;
+        if (ODD) co += wrap ? 1 : 0;
+        pixc += s_i + (wrap ? wrap_fix : 0);
+    };
+
+    // staged x_dbl rows: block st = positions [st * SP, ...), row r of the block = [dt_r | B | C] of position st*SP + r
+    constexpr int NLD = (SP * CD4 + 255) / 256;
+    f32x4 stg[NLD];
+    auto load_rows = [&](int st) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int idx = tid + j * 256;
+            const int r = idx / CD4, e4 = idx - r * CD4;
+            const int l = st * SP + r;
+            stg[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (idx < SP * CD4 && l < g.L) {
+                int h2, w2;
+                if (odd) { w2 = l / g.H2; h2 = l - w2 * g.H2; }
+                else { h2 = l / g.W2; w2 = l - h2 * g.W2; }
+                f32x4 v = *(const f32x4 *)(xb + (int64_t)(h2 * g.W2 + w2) * CD + 4 * e4);
+                if (LOG2U && 4 * e4 >= R + N) v = v * 0.6931471805599453f;    // the ln2 of dt*u, once per C element
+                stg[j] = v;
+            }
+        }
+    };
+    auto store_rows = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int idx = tid + j * 256;
+            if (idx < SP * CD4) *(f32x4 *)&sx[buf][4 * idx] = stg[j];
+        }
+    };
+    auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+    // a step's slices of its x_dbl row, in registers: loaded one step ahead of their use (the LDS round trip of a
+    // read issued right before its consumer was most of a step's time at one or two waves per SIMD)
+    struct RowRegs { f32x2 wr[RS / 2], br[NS / 2], cr[NS / 2]; };
+    auto load_row = [&](const float *xr, RowRegs &q) {
+        const f32x2 *wr2 = (const f32x2 *)(xr + sub * RS);
+        const f32x2 *br2 = (const f32x2 *)(xr + R + sub * NS);
+        const f32x2 *cr2 = (const f32x2 *)(xr + R + N + sub * NS);
+#pragma unroll
+        for (int r = 0; r < RS / 2; ++r) q.wr[r] = wr2[r];
+#pragma unroll
+        for (int n = 0; n < NS / 2; ++n) { q.br[n] = br2[n]; q.cr[n] = cr2[n]; }
+    };
+    // A step in two halves.  pre(): everything that does not depend on the state -- dt_proj + quad all-reduce,
+    // softplus, the N/4 decay factors exp2(A dt) and inputs B dt u.  post(): the recurrence itself, the C contraction,
+    // the quad all-reduce of y and the store.  run() issues pre(s + 1) next to post(s): two independent dependency
+    // chains for the scheduler to interleave (a lone wave spent ~500 cycles per step walking one chain of ~30
+    // dependent instructions; the state update is only the last third of it).
+    struct PreOut { f32x2 da[NS / 2], bdu[NS / 2]; float du; };
+    auto pre = [&](const RowRegs &q, uint32_t uraw, PreOut &o) {
+        const float u = cvt_u(uraw);
+        f32x2 dv2 = {0.f, 0.f}, dv3 = {0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < RS / 2; ++r) {
+            if (r & 1) dv3 = w[r] * q.wr[r] + dv3;
+            else dv2 = w[r] * q.wr[r] + dv2;
+        }
+        const float dv = quad_sum((dv2.x + dv3.x) + (dv2.y + dv3.y)) + bias;
+        float dt;
+        if constexpr (LOG2U) dt = __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(fminf(dv, 126.f)));
+        else dt = fd_softplus_fast(dv);
+        const float dtu = dt * u;
+        o.du = Dd * u;
+#pragma unroll
+        for (int n = 0; n < NS / 2; ++n) {
+            const f32x2 t = a2[n] * dt;
+            o.da[n] = f32x2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+            o.bdu[n] = q.br[n] * dtu;
+        }
+    };
+    auto post = [&](const RowRegs &q, const PreOut &o, int soff) {
+        f32x2 acc2 = {0.f, 0.f}, acc3 = {0.f, 0.f};
+#pragma unroll
+        for (int n = 0; n < NS / 2; ++n) {
+            h[n] = o.da[n] * h[n] + o.bdu[n];
+            if (n & 1) acc3 = h[n] * q.cr[n] + acc3;
+            else acc2 = h[n] * q.cr[n] + acc2;
+        }
+        st_y(soff, quad_sum((acc2.x + acc3.x) + (acc2.y + acc3.y)) + o.du);
+    };
+
+    constexpr int U = 8;                                 // steps per prefetch group; SP / U groups per staged block
+    const int G = g.L / U;
+    int pixA[U], pixB[U];
+    uint32_t uA[U], uB[U];
+    auto fetch = [&](int (&pix)[U], uint32_t (&u)[U]) {
+#pragma unroll
+        for (int s = 0; s < U; ++s) advance(pix[s]);
+#pragma unroll
+        for (int s = 0; s < U; ++s) u[s] = ld_u(pix[s]);
+    };
+    auto run = [&](int gi, const int (&pix)[U], const uint32_t (&u)[U]) {
+        const float *rows = &sx[(gi >> 2) & 1][((gi & 3) * U) * CD];
+        RowRegs q[3];
+        PreOut o[2];
+        load_row(rows, q[0]);
+        load_row(rows + CD, q[1]);
+        pre(q[0], u[0], o[0]);
+#pragma unroll
+        for (int s = 0; s < U; ++s) {
+            if (s + 2 < U) load_row(rows + (s + 2) * CD, q[(s + 2) % 3]);
+            __builtin_amdgcn_sched_barrier(0);           // the reads stay two steps ahead of their use
+            if (s + 1 < U) pre(q[(s + 1) % 3], u[s + 1], o[(s + 1) & 1]);
+            post(q[s % 3], o[s & 1], pix[s]);
+        }
+    };
+    load_rows(0);
+    store_rows(0);
+    if (SP < g.L) load_rows(1);
+    if (G > 0) fetch(pixA, uA);
+    lds_barrier();
+    for (int gi = 0; gi < G; gi += 2) {
+        if (gi + 1 < G) fetch(pixB, uB);
+        run(gi, pixA, uA);
+        if (gi + 1 < G) {
+            if (gi + 2 < G) fetch(pixA, uA);
+            run(gi + 1, pixB, uB);
+            if ((gi & 3) == 2) {                          // staged block gi / 4 is done
+                const int st = gi >> 2;
+                if ((st + 1) * SP < g.L) store_rows((st + 1) & 1);
+                lds_barrier();
+                if ((st + 2) * SP < g.L) load_rows(st + 2);
+            }
+        }
+    }
+    for (int l = G * U; l < g.L; ++l) {
+        int soff;
+        advance(soff);
+        RowRegs q;
+        PreOut o;
+        load_row(&sx[(l / SP) & 1][(l % SP) * CD], q);
+        pre(q, ld_u(soff), o);
+        post(q, o, soff);
+    }
+}
+
+// the single-pass form applies to (image size, state size, rank) only: batch-invariant by construction
+bool scan_seq_ok(int H, int W, int D, int N, int R) {
+    static const bool off = getenv("FD_SCAN_NO_SEQ") != nullptr;     // development switch: time the chunked form
+    if (off) return false;
+    const int L = ((H + 1) / 2) * ((W + 1) / 2);
+    return L <= SEQ_MAXL && N >= 16 && N % (2 * SEQ_LPC) == 0 && R % (2 * SEQ_LPC) == 0 && D % 64 == 0;
+}
+
+template <typename T, int N, int R, bool ODD>
+void launch_scan_seq(const T *xc, const float *xdbl, const float *dtw, const float *dtb, const float *A,
+                     const float *Ds, T *y, const ScanGeom &g, hipStream_t s) {
+    if constexpr (N >= 16 && N % (2 * SEQ_LPC) == 0 && R % (2 * SEQ_LPC) == 0) {
+        dim3 grid(g.D / 64, g.B * 4), block(256);
+        hipLaunchKernelGGL((scan_seq_kernel<T, N, R, ODD>), grid, block, 0, s, xc, xdbl, dtw, dtb, A, Ds, y, g);
+    }
+}
+
 template <typename T, int N, int R, bool ODD>
 void launch_scan(const T *xc, const float *xdbl, const float *dtw, const float *dtb, const float *A,
                  const float *Ds, T *y, float *ws, const ScanGeom &g, hipStream_t s) {
+    if (!g.xw && scan_seq_ok(g.H, g.W, g.D, g.N, g.R)) {
+        launch_scan_seq<T, N, R, ODD>(xc, xdbl, dtw, dtb, A, Ds, y, g, s);
+        return;
+    }
     const int64_t half = (int64_t)g.B * 4 * g.nch * g.N * g.D;
     float *wsH = ws, *wsP = ws + half;
     const int nw = g.D >= 256 ? 4 : g.D / 64;          // waves (64-channel groups) per workgroup
@@ -476,6 +737,13 @@ extern "C" int fd_selective_scan(int dtype, const void *xc, const float *xdbl, c
 // workgroup per chunk (d_inner <= 256, so no workgroup repeats another's rows), rows of whole 16-byte groups.
 extern "C" int fd_selective_scan_fuses_xproj(int dtype, int D, int N, int R) {
     return dtype == FD_BF16 && D % 64 == 0 && D <= 256 && (R + 2 * N) % 4 == 0;
+}
+
+// 1 if the engine should call fd_selective_scan_xproj for this block (x_proj inside the chunked scan's first phase),
+// 0 if it should run the x_proj launch and fd_selective_scan: the single-pass scan of short sequences with a wide
+// state takes its x_dbl rows from the workspace.  A function of the shape only.
+extern "C" int fd_selective_scan_plan(int dtype, int D, int N, int R, int H, int W) {
+    return fd_selective_scan_fuses_xproj(dtype, D, N, R) && !scan_seq_ok(H, W, D, N, R);
 }
 
 extern "C" int fd_selective_scan_xproj(int dtype, const void *xc, const void *x_proj_w, float *xdbl, const float *dtw,

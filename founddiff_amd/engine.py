@@ -404,7 +404,7 @@ class DAEngine:
         nws = L.lib().fd_scan_ws_floats(B, H, W, D, N)
         ws = self._b("scan_ws", (nws,), torch.float32)
         y = self._b("scan_y", (B, H, W, D))
-        if L.lib().fd_selective_scan_fuses_xproj(self.dt, D, N, R):
+        if L.lib().fd_selective_scan_plan(self.dt, D, N, R, H, W):
             # x_proj inside the scan's first phase (one workgroup per chunk at d_inner <= 256): no separate pass over xc
             L.call("fd_selective_scan_xproj", self.dt, _p(xc), _p(m["x_proj"]), _p(xdbl), _p(m["dtw"]), _p(m["dtb"]),
                    _p(m["A"]), _p(m["Ds"]), _p(y), _p(ws), B, H, W, D, N, R, s)
@@ -431,8 +431,25 @@ class DAEngine:
             self.conv(m["out_proj"], yz, B, H, W, x1, **ep1)
         self._pr(tag + ".x1", x1)
         # --- channel attention branch
-        qkv2 = self._b("qkv2", (B, H, W, 3 * Cc))
         ln2 = dict(prologue=L.PRO_LN_MOD, ln_eps=1e-6, ln_shift=mp(3), ln_scale=mp(4), ln_ld=ml)
+        if L.lib().fd_pw_dw3x3_gram_ok(self.dt, Cc, H, W):
+            # qkv -> qkv_dwconv -> L2 norms + q k^T in one pass: q and k never reach HBM, only v and one Gram
+            # partial per workgroup do (fd_pwdw.hip: pwdw_gram_kernel)
+            nblk = L.lib().fd_pw_dw3x3_gram_nblk(H, W)
+            vbuf = self._b("attn_v", (B, H, W, Cc))
+            part = self._b("gram", (B, m["heads"], nblk, 1024 + 64), torch.float32)
+            L.call("fd_pw_dw3x3_gram", self.dt, _p(x1), Cc, 0, Cc, None, None, 1e-6, mp(3), mp(4), ml,
+                   _p(m["qkv"].w), _p(m["qdw_wm"]), _p(vbuf), Cc, 0, _p(part), B, H, W, s)
+            self._pr(tag + ".qkv2", vbuf)
+            weff = self._b("weff", (B, Cc, Cc))
+            L.call("fd_chan_attn_weff", self.dt, _p(part), nblk, _p(m["temp"]), _p(m["wproj"]), _p(weff), B, Cc, s)
+            self._pr(tag + ".weff", weff)
+            x2 = self._b(tag + ".x2", (B, H, W, Cc))
+            self.conv(None, vbuf, B, H, W, x2, c0=Cc, ld0=Cc, off0=0, weight=weff, w_batch_stride=Cc * Cc,
+                      bias=None, Cout=Cc, KH=1, KW=1, epi=L.EPI_GATE_RES, res=x1, gate=mp(5), gate_ld=ml)
+            self._pr(tag, x2)
+            return x2
+        qkv2 = self._b("qkv2", (B, H, W, 3 * Cc))
         if L.lib().fd_pw_dw3x3_ok(self.dt, Cc, 3 * Cc, 0, H, W):
             L.call("fd_pw_dw3x3", self.dt, _p(x1), Cc, 0, Cc, None, None, 1e-6, mp(3), mp(4), ml,
                    _p(m["qkv"].w), 3 * Cc, _p(m["qdw_wm"]), None, 0, _p(qkv2), 3 * Cc, 0,

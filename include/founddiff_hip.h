@@ -172,6 +172,19 @@ int fd_pw_dw3x3(int dtype, const void *x, int ld_x, int off_x, int Cin, const fl
                 int dw_silu, void *out_dw, int ld_dw, int off_dw, int Cz, void *out_z, int ld_z,
                 int off_z, int B, int H, int W, void *stream);
 
+/* ---- the qkv form of the above with the channel attention's statistics folded in (src/DADiff.py:266-276):
+ * qkv (C -> 3C) -> qkv_dwconv -> per head L2 norms of q, k over all pixels and the 32x32 Gram q k^T.  q and k never
+ * reach HBM: only v (out_v, [B,H,W,ld_v] channels [off_v, +64)) and one partial per workgroup do --
+ * partial [B][2 heads][nblk][1024 + 64] fp32 in fd_chan_attn_gram's layout (Gram rows = q channels; then sum q^2,
+ * sum k^2), nblk = fd_pw_dw3x3_gram_nblk(H, W), reduced in fixed order by fd_chan_attn_weff.  bf16, Cin = 64 (two
+ * heads), w_pw [192][64] (q | k | v rows), w_dw [5][192] as for fd_pw_dw3x3, no bias.                       */
+int fd_pw_dw3x3_gram_ok(int dtype, int Cin, int H, int W);
+int fd_pw_dw3x3_gram_nblk(int H, int W);
+int fd_pw_dw3x3_gram(int dtype, const void *x, int ld_x, int off_x, int Cin, const float *ln_gamma,
+                     const float *ln_beta, float ln_eps, const float *ln_shift, const float *ln_scale,
+                     int ln_ld, const void *w_pw, const uint32_t *w_dw, void *out_v, int ld_v, int off_v,
+                     float *partial, int B, int H, int W, void *stream);
+
 /* ---- SS2D selective scan (replaces selective_scan_cuda_core.fwd, src/emamba2.py:154, together
  * with EfficientScan/EfficientMerge index maps 182-262, dt_proj einsum 340, softplus/bias).
  *   xc    [B,H,W,D]    (dtype)  dwconv+SiLU output, D = d_inner = 2C
@@ -182,7 +195,10 @@ int fd_pw_dw3x3(int dtype, const void *x, int ld_x, int off_x, int Cin, const fl
  *   y     [B,H,W,D]    (dtype)  written at the merged pixel positions
  *   ws    fp32 workspace of fd_scan_ws_floats(...) floats
  * 3 phases over chunks of the sequence (L = H*W/4 per direction): local scan, carry scan,
- * final scan + C contraction + D skip.  fp32 state throughout.                               */
+ * final scan + C contraction + D skip.  fp32 state throughout.  Short sequences with a wide state
+ * (L <= 1024, N >= 16, R % 8 == 0: the 64x64 level of a 512x512 slice) run ONE sequential pass instead, 4 lanes
+ * per channel sharing the states and the dt_proj contraction -- no chunks, no workspace traffic; which form
+ * runs depends on (H, W, N, R) only, never on B.                                              */
 int64_t fd_scan_ws_floats(int B, int H, int W, int D, int N);
 int fd_selective_scan(int dtype, const void *xc, const float *xdbl, const float *dtw,
                       const float *dtb, const float *A, const float *Ds, void *y, float *ws,
@@ -194,6 +210,9 @@ int fd_selective_scan_fuses_xproj(int dtype, int D, int N, int R);
 int fd_selective_scan_xproj(int dtype, const void *xc, const void *x_proj_w, float *xdbl, const float *dtw,
                             const float *dtb, const float *A, const float *Ds, void *y, float *ws, int B, int H,
                             int W, int D, int N, int R, void *stream);
+/* 1: call fd_selective_scan_xproj for this block; 0: run the x_proj launch, then fd_selective_scan (the single-pass
+ * form takes its x_dbl rows from the workspace).                                                              */
+int fd_selective_scan_plan(int dtype, int D, int N, int R, int H, int W);
 
 /* ---- The reference's own native-op interface (the only one it has):
  *     out, x, *rest = selective_scan_cuda_core.fwd(u, delta, A, B, C, D, delta_bias, delta_softplus, nrows)

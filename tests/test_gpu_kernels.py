@@ -603,6 +603,57 @@ def test_pw_dw3x3_fused(eng_factory, cfg):
         assert float(out_z[..., :cz].float().abs().max()) == 0.0 and float(out_z[..., 2 * cz:].float().abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("hw", [(128, 256), (264, 144)])
+def test_pw_dw3x3_gram(eng_factory, hw):
+    """qkv -> qkv_dwconv -> L2 norms + q k^T in one kernel (fd_pw_dw3x3_gram, src/DADiff.py:266-276): the v it
+    writes, and the reduced Gram / sums of squares, against (a) the unfused HIP pair fd_pw_dw3x3 + fd_chan_attn_gram
+    on the same inputs (same bf16 rounding points: agreement to fp32 summation order) and (b) the fp32 composition.
+    The second size has a tile count that is not a multiple of the tiles per workgroup (ragged last workgroup)."""
+    from founddiff_amd import _lib as L
+    from founddiff_amd.engine import DAEngine
+    torch.manual_seed(33)
+    B, (H, W), Cin = 2, hw, 64
+    bf = lambda t: t.to(torch.bfloat16).float()
+    x = bf(torch.randn(B, H, W, Cin) * 1.3 + 0.2)
+    mod = torch.randn(B, 6 * Cin) * 0.5
+    wpw = bf(torch.randn(192, Cin) / 8)
+    wdw = torch.randn(192, 1, 3, 3) / 3
+    assert L.lib().fd_pw_dw3x3_gram_ok(L.FD_BF16, Cin, H, W)
+    xd, md = x.cuda().to(torch.bfloat16), mod.cuda()
+    wpd = wpw.cuda().to(torch.bfloat16)
+    wm = DAEngine._dw_masked(wdw.reshape(192, 9).t().contiguous().cuda())
+    s = torch.cuda.current_stream().cuda_stream
+    # unfused HIP pair
+    qkv2 = torch.empty(B, H, W, 192, device="cuda", dtype=torch.bfloat16)
+    L.call("fd_pw_dw3x3", L.FD_BF16, xd.data_ptr(), Cin, 0, Cin, None, None, 1e-6, md.data_ptr(), md.data_ptr() + Cin * 4,
+           6 * Cin, wpd.data_ptr(), 192, wm.data_ptr(), None, 0, qkv2.data_ptr(), 192, 0, 0, None, 0, 0, B, H, W, s)
+    nb0 = L.lib().fd_chan_attn_nblk(H * W)
+    part0 = torch.empty(B, 2, nb0, 1088, device="cuda")
+    L.call("fd_chan_attn_gram", L.FD_BF16, qkv2.data_ptr(), B, H * W, Cin, part0.data_ptr(), s)
+    # fused
+    nb1 = L.lib().fd_pw_dw3x3_gram_nblk(H, W)
+    part1 = torch.full((B, 2, nb1, 1088), float("nan"), device="cuda")
+    v = torch.zeros(B, H, W, 64 + 8, device="cuda", dtype=torch.bfloat16)
+    L.call("fd_pw_dw3x3_gram", L.FD_BF16, xd.data_ptr(), Cin, 0, Cin, None, None, 1e-6, md.data_ptr(), md.data_ptr() + Cin * 4,
+           6 * Cin, wpd.data_ptr(), wm.data_ptr(), v.data_ptr(), 64 + 8, 8, part1.data_ptr(), B, H, W, s)
+    torch.cuda.synchronize()
+    assert torch.equal(v[..., 8:], qkv2[..., 128:]) and float(v[..., :8].float().abs().max()) == 0.0
+    g0, g1 = part0.double().sum(2).cpu(), part1.double().sum(2).cpu()
+    assert bool(torch.isfinite(g1).all())
+    assert rel_err(g1[..., :1024], g0[..., :1024]) < 1e-5 and rel_err(g1[..., 1024:], g0[..., 1024:]) < 1e-5
+    # fp32 composition from the stored q, k (the Gram of exactly those bf16 values)
+    q, k = qkv2[..., :64].float().cpu().reshape(B, H * W, 2, 32), qkv2[..., 64:128].float().cpu().reshape(B, H * W, 2, 32)
+    gram = torch.einsum("bphi,bphj->bhij", q.double(), k.double()).reshape(B, 2, 1024)
+    assert rel_err(g1[..., :1024], gram) < 1e-5
+    assert rel_err(g1[..., 1024:1056], (q.double() ** 2).sum(1)) < 1e-5 and rel_err(g1[..., 1056:], (k.double() ** 2).sum(1)) < 1e-5
+    # deterministic
+    part2 = torch.empty_like(part1)
+    L.call("fd_pw_dw3x3_gram", L.FD_BF16, xd.data_ptr(), Cin, 0, Cin, None, None, 1e-6, md.data_ptr(), md.data_ptr() + Cin * 4,
+           6 * Cin, wpd.data_ptr(), wm.data_ptr(), v.data_ptr(), 64 + 8, 8, part2.data_ptr(), B, H, W, s)
+    torch.cuda.synchronize()
+    assert torch.equal(part1, part2)
+
+
 @pytest.mark.parametrize("cfg", [dict(cout=64, planes=2, hw=(48, 64)), dict(cout=32, planes=3, hw=(32, 32)),
                                  dict(cout=64, planes=1, hw=(16, 32))])
 def test_init_conv7(eng_factory, cfg):

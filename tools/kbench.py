@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Micro-benchmarks of single C-ABI entry points at the shapes of a batch-8 512x512 forward (development tool).
+usage: python tools/kbench.py scan|attn|... [--batch 8]"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+
+def timeit(fn, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3      # us
+
+
+def bench_scan(B, shapes=None):
+    from founddiff_amd import _lib as L
+    s = torch.cuda.current_stream().cuda_stream
+    shapes = shapes or [(128, 4, 4, 512, 512), (128, 8, 4, 256, 256), (256, 8, 8, 256, 256), (256, 16, 8, 128, 128),
+                        (512, 16, 16, 128, 128), (512, 32, 16, 64, 64), (1024, 32, 32, 64, 64)]
+    for D, N, R, H, W in shapes:
+        torch.manual_seed(0)
+        CD, Lq = R + 2 * N, (H // 2) * (W // 2)
+        xc = (torch.randn(B, H, W, D, device="cuda") * 0.5).to(torch.bfloat16)
+        xdbl = torch.randn(4, B, Lq, CD, device="cuda")
+        dtw = ((torch.rand(4, D, R, device="cuda") * 2 - 1) * R ** -0.5)
+        dtb = torch.randn(4, D, device="cuda") * 0.5 - 3
+        A = -torch.exp(torch.log(torch.arange(1, N + 1, device="cuda").float())[None].repeat(4 * D, 1))
+        Ds = torch.ones(4 * D, device="cuda")
+        ws = torch.empty(L.lib().fd_scan_ws_floats(B, H, W, D, N), device="cuda")
+        y = torch.empty(B, H, W, D, device="cuda", dtype=torch.bfloat16)
+
+        def run():
+            L.call("fd_selective_scan", L.FD_BF16, xc.data_ptr(), xdbl.data_ptr(), dtw.data_ptr(), dtb.data_ptr(),
+                   A.data_ptr(), Ds.data_ptr(), y.data_ptr(), ws.data_ptr(), B, H, W, D, N, R, s)
+        t = timeit(run)
+        print(f"scan D={D} N={N} R={R} {H}x{W} B={B}: {t:8.1f} us  ({t / B / 1e3:.4f} ms/slice)  y_sum={float(y.float().abs().mean()):.6f}", flush=True)
+
+
+def bench_attn(B, sizes=((512, 512), (256, 256))):
+    """channel-attention branch of a 64-channel Mamba block: fused (qkv+dw+Gram) vs unfused (qkv+dw, Gram)"""
+    from founddiff_amd import _lib as L
+    from founddiff_amd.engine import DAEngine
+    s = torch.cuda.current_stream().cuda_stream
+    for H, W in sizes:
+        torch.manual_seed(0)
+        x = torch.randn(B, H, W, 64, device="cuda").to(torch.bfloat16)
+        mod = torch.randn(B, 384, device="cuda") * 0.5
+        wpw = (torch.randn(192, 64, device="cuda") / 8).to(torch.bfloat16)
+        wm = DAEngine._dw_masked((torch.randn(192, 9, device="cuda") / 3).t().contiguous())
+        qkv2 = torch.empty(B, H, W, 192, device="cuda", dtype=torch.bfloat16)
+        v = torch.empty(B, H, W, 64, device="cuda", dtype=torch.bfloat16)
+        nb0, nb1 = L.lib().fd_chan_attn_nblk(H * W), L.lib().fd_pw_dw3x3_gram_nblk(H, W)
+        p0, p1 = torch.empty(B, 2, nb0, 1088, device="cuda"), torch.empty(B, 2, nb1, 1088, device="cuda")
+        temp, wp = torch.ones(2, device="cuda"), torch.randn(64, 64, device="cuda") / 8
+        weff = torch.empty(B, 64, 64, device="cuda", dtype=torch.bfloat16)
+
+        def unf_a():
+            L.call("fd_pw_dw3x3", L.FD_BF16, x.data_ptr(), 64, 0, 64, None, None, 1e-6, mod.data_ptr(), mod.data_ptr() + 256,
+                   384, wpw.data_ptr(), 192, wm.data_ptr(), None, 0, qkv2.data_ptr(), 192, 0, 0, None, 0, 0, B, H, W, s)
+
+        def unf_b():
+            L.call("fd_chan_attn_gram", L.FD_BF16, qkv2.data_ptr(), B, H * W, 64, p0.data_ptr(), s)
+
+        def unf_c():
+            L.call("fd_chan_attn_weff", L.FD_BF16, p0.data_ptr(), nb0, temp.data_ptr(), wp.data_ptr(), weff.data_ptr(), B, 64, s)
+
+        def fus_a():
+            L.call("fd_pw_dw3x3_gram", L.FD_BF16, x.data_ptr(), 64, 0, 64, None, None, 1e-6, mod.data_ptr(), mod.data_ptr() + 256,
+                   384, wpw.data_ptr(), wm.data_ptr(), v.data_ptr(), 64, 0, p1.data_ptr(), B, H, W, s)
+
+        def fus_c():
+            L.call("fd_chan_attn_weff", L.FD_BF16, p1.data_ptr(), nb1, temp.data_ptr(), wp.data_ptr(), weff.data_ptr(), B, 64, s)
+        ta, tb, tc, fa, fc = timeit(unf_a), timeit(unf_b), timeit(unf_c), timeit(fus_a), timeit(fus_c)
+        print(f"attn {H}x{W} B={B}: unfused qkv+dw {ta:.1f} + gram {tb:.1f} + weff {tc:.1f} = {ta + tb + tc:.1f} us | "
+              f"fused {fa:.1f} + weff {fc:.1f} = {fa + fc:.1f} us  (nblk {nb0} -> {nb1})", flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what")
+    ap.add_argument("--batch", type=int, default=8)
+    a = ap.parse_args()
+    globals()["bench_" + a.what](a.batch)
+
+
+if __name__ == "__main__":
+    main()
