@@ -39,7 +39,7 @@ class ConvParams(C.Structure):
         ("prologue", i32), ("ln_eps", f32),
         ("ln_gamma", vp), ("ln_beta", vp), ("ln_shift", vp), ("ln_scale", vp), ("ln_ld", i32),
         ("ln_z", vp), ("ln_ldz", i32), ("ln_offz", i32),
-        ("weight_f8", vp), ("w_scale", vp), ("act_scale", f32),
+        ("weight_f8", vp), ("w_scale", vp), ("act_scale", f32), ("f32_split", i32),
     ]
 
 

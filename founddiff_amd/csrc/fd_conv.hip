@@ -49,8 +49,15 @@ __device__ __forceinline__ int swz(int row, int chunk) { return (chunk ^ ((row >
 // the K tile): the gather degenerates to "row m, channels k..k+63", so every per-lane offset is computed
 // once and a K step only advances a wave-uniform base pointer (SGPR base + 32-bit VGPR offset loads) --
 // the general decode costs ~80 VALU instructions per K step against 16-32 MFMAs.
-template <typename T, int BM, int BN, int WM, int WN, bool PW = false>
+// SPL (fp32 storage only): split-bf16 contraction.  Each f32 operand is split into hi = bf16(x) and lo = bf16(x - hi)
+// on its way into LDS (the 32 floats of a tile row become 32 hi + 32 lo bf16 in the same 128 bytes) and the product
+// is hi.hi + hi.lo + lo.hi on the bf16 MFMA with fp32 accumulation: ~2^-16 relative per product instead of the
+// exact-f32 MFMA's 2^-24, at 3 x 16 instead of 8 x 32 matrix-pipe cycles per 32-deep step.  It serves the
+// fp32-storage levels of a sampling loop's LAST step in the bf16 production mode (DAEngine mode 'fp32s'); the parity
+// mode ('fp32', the 1e-3 gate) never sets it.
+template <typename T, int BM, int BN, int WM, int WN, bool PW = false, bool SPL = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const fd_conv_params p) {
+    static_assert(!SPL || (sizeof(T) == 4 && !PW), "split-bf16 contraction: fp32 storage, general loader");
     constexpr int NTHR = 64 * WM * WN, NWAVE = WM * WN;
     constexpr int RPL = NTHR / 8;            // tile rows covered by one loader pass (8 chunks per row)
     constexpr int AR = BM / RPL, NB = BN / RPL;
@@ -187,6 +194,28 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const fd_conv_
     auto lstore = [&](int buf) {
         unsigned char *sA = smem + buf * (BM + BN) * ROWB;
         unsigned char *sB = sA + BM * ROWB;
+        if constexpr (SPL) {
+            // 4 floats (k = 4*chunk .. +3) -> 4 hi (8 bytes at k-chunk chunk/2, half chunk&1) + 4 lo (k-chunk 4 + chunk/2)
+            auto split_store = [&](unsigned char *row, int r, const u32x4 v) {
+                const uint32_t raw[4] = {v.x, v.y, v.z, v.w};
+                uint32_t hw[2], lw[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float f0 = __builtin_bit_cast(float, raw[2 * e]), f1 = __builtin_bit_cast(float, raw[2 * e + 1]);
+                    const bf16 h0 = (bf16)f0, h1 = (bf16)f1;
+                    const bf16 l0 = (bf16)(f0 - (float)h0), l1 = (bf16)(f1 - (float)h1);
+                    hw[e] = (uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16);
+                    lw[e] = (uint32_t)__builtin_bit_cast(uint16_t, l0) | ((uint32_t)__builtin_bit_cast(uint16_t, l1) << 16);
+                }
+                *(uint2 *)(row + swz(r, chunk >> 1) + (chunk & 1) * 8) = uint2{hw[0], hw[1]};
+                *(uint2 *)(row + swz(r, 4 + (chunk >> 1)) + (chunk & 1) * 8) = uint2{lw[0], lw[1]};
+            };
+#pragma unroll
+            for (int i = 0; i < AR; ++i) { const int r = rbase + RPL * i; split_store(sA + r * ROWB, r, ra[i]); }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) { const int r = rbase + RPL * i; split_store(sB + r * ROWB, r, rb[i]); }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
             int r = rbase + RPL * i;
@@ -239,6 +268,30 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const fd_conv_
                     for (int j = 0; j < NT; ++j)
                         acc[i][j] = PWE ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0)
                                        : __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            } else if constexpr (SPL) {
+                // split-bf16: hi fragment = k-chunk fg, lo fragment = k-chunk 4 + fg of the row; lane group fg owns
+                // k = 8*fg .. 8*fg+7 in both, which is the K32 bf16 MFMA's own operand layout
+                bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    int r = TMW * wm + 16 * i + fr;
+                    ah[i] = *(const bf16x8 *)(sA + r * ROWB + swz(r, fg));
+                    al[i] = *(const bf16x8 *)(sA + r * ROWB + swz(r, 4 + fg));
+                }
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    int r = TNW * wn + 16 * j + fr;
+                    bh[j] = *(const bf16x8 *)(sB + r * ROWB + swz(r, fg));
+                    bl[j] = *(const bf16x8 *)(sB + r * ROWB + swz(r, 4 + fg));
+                }
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
             } else {
                 // f32: lane group fg owns k = 8*fg .. 8*fg+7 of the 32-wide step; MFMA step e
                 // contracts the k-set {8g + e}: any consistent A/B k-permutation is a valid sum.
@@ -662,6 +715,19 @@ extern "C" int fd_conv2d(const fd_conv_params *pp, void *stream) {
     }
     if (p.dtype == FD_BF16) {
         if (pw) { FD_CONV_DISPATCH(bf16, true) } else { FD_CONV_DISPATCH(bf16, false) }
+    } else if (p.f32_split) {
+#define FD_CONV_LAUNCH_S(BM_, BN_, WM_, WN_) \
+    hipLaunchKernelGGL((conv_igemm_kernel<float, BM_, BN_, WM_, WN_, false, true>), grid, block, 0, s, p)
+        switch (kid) {
+        case 0: FD_CONV_LAUNCH_S(128, 128, 2, 2); break;
+        case 1: FD_CONV_LAUNCH_S(128, 64, 2, 2); break;
+        case 2: FD_CONV_LAUNCH_S(64, 128, 2, 2); break;
+        case 3: FD_CONV_LAUNCH_S(64, 64, 2, 2); break;
+        case 5: FD_CONV_LAUNCH_S(256, 256, 4, 2); break;
+        case 6: FD_CONV_LAUNCH_S(128, 32, 2, 2); break;
+        default: FD_CONV_LAUNCH_S(128, 256, 2, 4); break;
+        }
+#undef FD_CONV_LAUNCH_S
     } else { FD_CONV_DISPATCH(float, false) }
 #undef FD_CONV_DISPATCH
 #undef FD_CONV_LAUNCH

@@ -41,8 +41,13 @@ __device__ __forceinline__ void scan_pos(const ScanGeom &g, int k, int l, int &l
 // x_dbl row (x_proj has no bias), i.e. the state only decays by exp(softplus(dt_bias) A) there, and their outputs
 // are dropped.  Here they are positions whose pixel lies outside the image: u := 0, no store; the x_dbl rows of
 // those positions are zeros written by the x_proj launch (its gather zero-fills out-of-range pixels).
-template <typename T, int N, int R, bool FINAL, bool ODD>
-__global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 8 ? 5 : 1))) void scan_chunk_kernel(const T *__restrict__ xc, const float *__restrict__ xdbl,
+// CPL = channels per lane.  2 (bf16, N <= 8: the 512x512 / 256x256 levels, where these kernels are bound by VALU
+// issue, PMC 73-95 % busy): a lane owns two NEIGHBOURING channels and every float pair is (channel, channel + 1)
+// instead of (state, state + 1) -- the dt_proj contraction, dt*u, the D skip and the y accumulator become packed
+// instructions too, the cross-half add of the y pair disappears, u / y move as one dword per lane and step, and a
+// wave's LDS row broadcasts serve 128 channels: ~26.5 instead of ~31 issue slots per (channel, position).
+template <typename T, int N, int R, bool FINAL, bool ODD, int CPL = 1>
+__global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 8 ? (CPL == 2 ? 4 : 5) : 1))) void scan_chunk_kernel(const T *__restrict__ xc, const float *__restrict__ xdbl,
                                                         const float *__restrict__ dtw, const float *__restrict__ dtb,
                                                         const float *__restrict__ A, const float *__restrict__ Ds,
                                                         T *__restrict__ y, float *__restrict__ wsH,
@@ -60,10 +65,11 @@ __global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 8 ? 5 : 1))) void scan_ch
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nw = blockDim.x >> 6;
-    const int dgroups = g.D / (64 * nw);
+    static_assert(CPL == 1 || (CPL == 2 && sizeof(T) == 2), "two channels per lane: bf16 only");
+    const int dgroups = g.D / (64 * CPL * nw);
     const int chunk = blockIdx.x / dgroups, dg = blockIdx.x - chunk * dgroups;
     const int bk = blockIdx.y, b = bk >> 2, k = bk & 3;
-    const int d = (dg * nw + wave) * 64 + lane;
+    const int d = ((dg * nw + wave) * 64 + lane) * CPL;
     const int kd = k * g.D + d;
     const int l0 = chunk * g.CL;
     const int l1 = min(l0 + g.CL, g.L);
@@ -136,25 +142,41 @@ __global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 8 ? 5 : 1))) void scan_ch
 
     // state / weights as float pairs: the recurrence runs on v_pk_mul_f32 / v_pk_fma_f32 (two states
     // per instruction at the scalar-op issue rate); only the two v_exp_f32 per pair stay scalar
-    f32x2 w[R / 2], a2[N / 2], h[N / 2];
-#pragma unroll
-    for (int r = 0; r < R / 2; ++r) w[r] = f32x2{dtw[(int64_t)kd * R + 2 * r], dtw[(int64_t)kd * R + 2 * r + 1]} * WS;
-    // exp(dt*A) = exp2(dt * A*log2(e)): fold the constant into A once (v_exp_f32 is exp2)
-#pragma unroll
-    for (int n = 0; n < N / 2; ++n)
-        a2[n] = f32x2{A[(int64_t)kd * N + 2 * n], A[(int64_t)kd * N + 2 * n + 1]} * AS;
-    const float bias = dtb[kd] * WS;
-    const float Dd = FINAL ? Ds[kd] : 0.f;
+    // CPL == 1: pair = (state 2n, 2n+1) of one channel, NP = N/2 pairs.  CPL == 2: pair = (channel d, d+1), NP = N.
+    constexpr int NP = CPL == 2 ? N : N / 2, RP = CPL == 2 ? R : R / 2;
+    f32x2 w[RP], a2[NP], h[NP];
+    f32x2 bias2 = {0.f, 0.f}, Dd2 = {0.f, 0.f};
+    float bias = 0.f, Dd = 0.f;
     const int64_t cbase = (((int64_t)bk * g.nch + chunk) * N) * g.D + d;   // [bk][chunk][n][d]
-    if (FINAL) {
+    if constexpr (CPL == 2) {
 #pragma unroll
-        for (int n = 0; n < N / 2; ++n)
-            h[n] = f32x2{wsH[cbase + (int64_t)(2 * n) * g.D], wsH[cbase + (int64_t)(2 * n + 1) * g.D]};
+        for (int r = 0; r < R; ++r) w[r] = f32x2{dtw[(int64_t)kd * R + r], dtw[(int64_t)(kd + 1) * R + r]} * WS;
+#pragma unroll
+        for (int n = 0; n < N; ++n) a2[n] = f32x2{A[(int64_t)kd * N + n], A[(int64_t)(kd + 1) * N + n]} * AS;
+        bias2 = f32x2{dtb[kd], dtb[kd + 1]} * WS;
+        if (FINAL) Dd2 = f32x2{Ds[kd], Ds[kd + 1]};
+#pragma unroll
+        for (int n = 0; n < N; ++n) h[n] = FINAL ? *(const f32x2 *)&wsH[cbase + (int64_t)n * g.D] : f32x2{0.f, 0.f};
     } else {
 #pragma unroll
-        for (int n = 0; n < N / 2; ++n) h[n] = f32x2{0.f, 0.f};
+        for (int r = 0; r < R / 2; ++r) w[r] = f32x2{dtw[(int64_t)kd * R + 2 * r], dtw[(int64_t)kd * R + 2 * r + 1]} * WS;
+        // exp(dt*A) = exp2(dt * A*log2(e)): fold the constant into A once (v_exp_f32 is exp2)
+#pragma unroll
+        for (int n = 0; n < N / 2; ++n)
+            a2[n] = f32x2{A[(int64_t)kd * N + 2 * n], A[(int64_t)kd * N + 2 * n + 1]} * AS;
+        bias = dtb[kd] * WS;
+        Dd = FINAL ? Ds[kd] : 0.f;
+        if (FINAL) {
+#pragma unroll
+            for (int n = 0; n < N / 2; ++n)
+                h[n] = f32x2{wsH[cbase + (int64_t)(2 * n) * g.D], wsH[cbase + (int64_t)(2 * n + 1) * g.D]};
+        } else {
+#pragma unroll
+            for (int n = 0; n < N / 2; ++n) h[n] = f32x2{0.f, 0.f};
+        }
     }
     float sdt = 0.f;
+    f32x2 sdt2 = {0.f, 0.f};
     // wave-uniform row base + per-lane channel index: the row address stays on the scalar unit and the
     // loads/stores use the (sgpr base, vgpr offset) form -- no 64-bit vector address math per step
     // u / y rows through raw buffer descriptors: address = image base (SGPRs of the descriptor) + scalar
@@ -166,16 +188,21 @@ __global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 8 ? 5 : 1))) void scan_ch
     const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc((void *)ub, 0, img_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void *)(FINAL ? yb : (T *)ub), 0, img_bytes, 0x00020000);
     const int voff = d * (int)sizeof(T);
-    auto ld_u = [&](int soff) -> float {
-        if (ODD && soff < 0) return 0.f;               // padded position (wave-uniform)
-        if constexpr (sizeof(T) == 2) {
-            const unsigned short r = __builtin_amdgcn_raw_buffer_load_b16(rs_u, voff, soff, 0);
-            return __builtin_bit_cast(float, (uint32_t)r << 16);
-        } else {
-            return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_u, voff, soff, 0));
-        }
+    // u stays RAW (the 16 / 32 bits as loaded) until the step that uses it: converted at load time, the wait for a
+    // whole group's loads sat in front of the previous group's steps -- the prefetch overlapped nothing
+    auto ld_u = [&](int soff_) -> uint32_t {
+        const int soff = __builtin_amdgcn_readfirstlane(soff_);     // uniform by construction; keeps the offset an SGPR
+        if (ODD && soff < 0) return 0u;                // padded position (wave-uniform)
+        if constexpr (CPL == 2) return __builtin_amdgcn_raw_buffer_load_b32(rs_u, voff, soff, 0);     // two bf16 channels
+        else if constexpr (sizeof(T) == 2) return (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rs_u, voff, soff, 0);
+        else return __builtin_amdgcn_raw_buffer_load_b32(rs_u, voff, soff, 0);
     };
-    auto st_y = [&](int soff, float v) {
+    auto cvt_u = [&](uint32_t r) -> float {
+        if constexpr (sizeof(T) == 2) return __builtin_bit_cast(float, r << 16);
+        else return __builtin_bit_cast(float, r);
+    };
+    auto st_y = [&](int soff_, float v) {
+        const int soff = __builtin_amdgcn_readfirstlane(soff_);     // (a VGPR offset turns the store into a waterfall loop)
         if (ODD && soff < 0) return;
         if constexpr (sizeof(T) == 2) {
             const bf16 hv = (bf16)v;
@@ -183,6 +210,13 @@ __global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 8 ? 5 : 1))) void scan_ch
         } else {
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs_y, voff, soff, 0);
         }
+    };
+    auto st_y2 = [&](int soff_, f32x2 v) {
+        const int soff = __builtin_amdgcn_readfirstlane(soff_);
+        if (ODD && soff < 0) return;
+        typedef __attribute__((ext_vector_type(2))) __bf16 bfx2;
+        const bfx2 hv = {(bf16)v.x, (bf16)v.y};
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, hv), rs_y, voff, soff, 0);
     };
     // scan position -> (h2, w2) kept as scalar counters: no division in the loop
     // The integer division is computed on the vector unit; readfirstlane moves the (uniform) result to
@@ -201,7 +235,29 @@ __global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 8 ? 5 : 1))) void scan_ch
     int co = __builtin_amdgcn_readfirstlane(l0 / NI);
     __syncthreads();
 
-    auto step = [&](const float *xr, float u, int soff) {
+    auto step = [&](const float *xr, uint32_t uraw, int soff) {
+        if constexpr (CPL == 2) {
+            // row = [dt_r (R) | B (N) | C (N)] broadcast scalars; every pair below is (channel d, channel d + 1)
+            const f32x2 u2 = {__builtin_bit_cast(float, uraw << 16), __builtin_bit_cast(float, uraw & 0xffff0000u)};
+            f32x2 dv2 = bias2;
+#pragma unroll
+            for (int r = 0; r < R; ++r) dv2 = w[r] * xr[r] + dv2;
+            f32x2 dt2;
+            dt2.x = __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(fminf(dv2.x, 126.f)));
+            dt2.y = __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(fminf(dv2.y, 126.f)));
+            const f32x2 dtu2 = dt2 * u2;
+            if (!FINAL) sdt2 += dt2;
+            f32x2 acc2 = Dd2 * u2;
+#pragma unroll
+            for (int n = 0; n < N; ++n) {
+                const f32x2 t = a2[n] * dt2;
+                const f32x2 da = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+                h[n] = da * h[n] + dtu2 * xr[R + n];
+                if (FINAL) acc2 = h[n] * xr[R + N + n] + acc2;
+            }
+            if (FINAL) st_y2(soff, acc2);
+        } else {
+        const float u = cvt_u(uraw);
         const f32x2 *xr2 = (const f32x2 *)xr;          // row = [dt_r (R) | B (N) | C (N)], all even
         f32x2 dv2 = {bias, 0.f};
 #pragma unroll
@@ -221,6 +277,7 @@ __global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 8 ? 5 : 1))) void scan_ch
             if (FINAL) acc2 = h[n] * xr2[R / 2 + N / 2 + n] + acc2;
         }
         if (FINAL) st_y(soff, acc2.x + acc2.y + Dd * u);
+        }
     };
     auto advance = [&](int &soff) {            // -> byte offset of the pixel's row inside the image (-1: padding)
         soff = pixc * rowb;
@@ -238,14 +295,14 @@ __global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 8 ? 5 : 1))) void scan_ch
     int l = l0;
     const int ngroups = (l1 - l0) / U;
     int pixA[U], pixB[U];
-    float uA[U], uB[U];
-    auto fetch = [&](int (&pix)[U], float (&u)[U]) {
+    uint32_t uA[U], uB[U];
+    auto fetch = [&](int (&pix)[U], uint32_t (&u)[U]) {
 #pragma unroll
         for (int s = 0; s < U; ++s) advance(pix[s]);
 #pragma unroll
         for (int s = 0; s < U; ++s) u[s] = ld_u(pix[s]);
     };
-    auto run = [&](const int (&pix)[U], const float (&u)[U]) {
+    auto run = [&](const int (&pix)[U], const uint32_t (&u)[U]) {
 #pragma unroll
         for (int s = 0; s < U; ++s) step(sx + (l - l0 + s) * CDP, u[s], pix[s]);
         l += U;
@@ -265,15 +322,21 @@ __global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 8 ? 5 : 1))) void scan_ch
         step(sx + (l - l0) * CDP, ld_u(soff), soff);
     }
     if (!FINAL) {
-#pragma unroll
-        for (int n = 0; n < N / 2; ++n) {
-            wsH[cbase + (int64_t)(2 * n) * g.D] = h[n].x;
-            wsH[cbase + (int64_t)(2 * n + 1) * g.D] = h[n].y;
-        }
         // chunk decay P[n] = exp2(a2[n] * sum dt): only the sum is stored ([bk][chunk][d], N x smaller than
         // P itself); the carry kernel rebuilds P from it -- at the 64x64 levels (N = 32, 32-step chunks)
         // the P/H workspace traffic was 4x the u/y traffic of the scan
-        wsP[((int64_t)bk * g.nch + chunk) * g.D + d] = sdt;
+        if constexpr (CPL == 2) {
+#pragma unroll
+            for (int n = 0; n < N; ++n) *(f32x2 *)&wsH[cbase + (int64_t)n * g.D] = h[n];
+            *(f32x2 *)&wsP[((int64_t)bk * g.nch + chunk) * g.D + d] = sdt2;
+        } else {
+#pragma unroll
+            for (int n = 0; n < N / 2; ++n) {
+                wsH[cbase + (int64_t)(2 * n) * g.D] = h[n].x;
+                wsH[cbase + (int64_t)(2 * n + 1) * g.D] = h[n].y;
+            }
+            wsP[((int64_t)bk * g.nch + chunk) * g.D + d] = sdt;
+        }
     }
 }
 
@@ -618,6 +681,11 @@ void launch_scan_seq(const T *xc, const float *xdbl, const float *dtw, const flo
     }
 }
 
+static bool scan_cpl2_on() {
+    static const bool off = getenv("FD_SCAN_NO_CPL2") != nullptr;    // development switch
+    return !off;
+}
+
 template <typename T, int N, int R, bool ODD>
 void launch_scan(const T *xc, const float *xdbl, const float *dtw, const float *dtb, const float *A,
                  const float *Ds, T *y, float *ws, const ScanGeom &g, hipStream_t s) {
@@ -627,10 +695,16 @@ void launch_scan(const T *xc, const float *xdbl, const float *dtw, const float *
     }
     const int64_t half = (int64_t)g.B * 4 * g.nch * g.N * g.D;
     float *wsH = ws, *wsP = ws + half;
-    const int nw = g.D >= 256 ? 4 : g.D / 64;          // waves (64-channel groups) per workgroup
-    dim3 grid(g.nch * (g.D / (64 * nw)), g.B * 4), block(64 * nw);
+    // two channels per lane where the kernel is VALU-bound and the state is small (bf16, N <= 8); a function of the
+    // shape only
+    constexpr int CPL = (sizeof(T) == 2 && N <= 8) ? 2 : 1;
+    const bool two = CPL == 2 && g.D % 128 == 0 && scan_cpl2_on();
+    const int cw = two ? 128 : 64;                     // channels per wave
+    const int nw = g.D >= 4 * cw ? 4 : g.D / cw;       // waves per workgroup
+    dim3 grid(g.nch * (g.D / (cw * nw)), g.B * 4), block(64 * nw);
     const size_t lds = (size_t)g.CL * ((g.CD + 3) & ~3) * sizeof(float);
-    hipLaunchKernelGGL((scan_chunk_kernel<T, N, R, false, ODD>), grid, block, lds, s, xc, xdbl, dtw, dtb, A, Ds, y, wsH, wsP, g);
+    if (two) hipLaunchKernelGGL((scan_chunk_kernel<T, N, R, false, ODD, CPL>), grid, block, lds, s, xc, xdbl, dtw, dtb, A, Ds, y, wsH, wsP, g);
+    else hipLaunchKernelGGL((scan_chunk_kernel<T, N, R, false, ODD>), grid, block, lds, s, xc, xdbl, dtw, dtb, A, Ds, y, wsH, wsP, g);
     if (g.nch > 1)
     {
         const int per = (g.nch + SEG - 1) / SEG;
@@ -642,7 +716,8 @@ void launch_scan(const T *xc, const float *xdbl, const float *dtw, const float *
     }
     else
         (void)hipMemsetAsync(wsH, 0, half * sizeof(float), s);
-    hipLaunchKernelGGL((scan_chunk_kernel<T, N, R, true, ODD>), grid, block, lds, s, xc, xdbl, dtw, dtb, A, Ds, y, wsH, wsP, g);
+    if (two) hipLaunchKernelGGL((scan_chunk_kernel<T, N, R, true, ODD, CPL>), grid, block, lds, s, xc, xdbl, dtw, dtb, A, Ds, y, wsH, wsP, g);
+    else hipLaunchKernelGGL((scan_chunk_kernel<T, N, R, true, ODD>), grid, block, lds, s, xc, xdbl, dtw, dtb, A, Ds, y, wsH, wsP, g);
 }
 
 template <typename T, int N>

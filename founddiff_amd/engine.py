@@ -14,7 +14,11 @@ from . import _lib as L
 
 # 'fp8' (BASELINE configs[4]): bf16 activations and kernels, plus e4m3 weights with one scale per output channel
 # for the convolutions the fp8 MFMA path takes (3x3 halo kernel, K axis in 128-channel slabs)
-_T = {"fp32": (L.FD_F32, torch.float32), "bf16": (L.FD_BF16, torch.bfloat16), "fp8": (L.FD_BF16, torch.bfloat16)}
+# 'fp32s': fp32 storage and kernels like 'fp32', but the dense contractions run split-bf16 (3 bf16 MFMAs per product,
+# ~2^-16) instead of the exact-f32 MFMA: the engine behind the LAST step of a bf16 sampling loop (ResidualDiffusion
+# final_fp32_steps).  The parity mode 'fp32' (the 1e-3 gate) stays exact.
+_T = {"fp32": (L.FD_F32, torch.float32), "bf16": (L.FD_BF16, torch.bfloat16), "fp8": (L.FD_BF16, torch.bfloat16),
+      "fp32s": (L.FD_F32, torch.float32)}
 FP8_ACT_SCALE = 8.0     # activations are multiplied by this power of two before the e4m3 conversion (|x| <= 56 exact range)
 
 
@@ -87,10 +91,11 @@ class DAEngine:
         DAEngine._GEN += 1
         self.gen = DAEngine._GEN
         if mode not in _T:
-            raise ValueError(f"mode must be 'fp32', 'bf16' or 'fp8', got {mode!r}")
+            raise ValueError(f"mode must be 'fp32', 'fp32s', 'bf16' or 'fp8', got {mode!r}")
         self.mode = mode
         self.dt, self.tdt = _T[mode]
         self.fp8 = mode == "fp8"
+        self.f32_split = int(mode == "fp32s")
         self.dev = torch.device(device)
         self.f32 = dict(device=self.dev, dtype=torch.float32)
         sd = _Sub(state_dict, prefix)
@@ -321,6 +326,7 @@ class DAEngine:
         p.ln_gamma, p.ln_beta = ptr(ln_gamma), ptr(ln_beta)
         p.ln_shift, p.ln_scale, p.ln_ld = ptr(ln_shift), ptr(ln_scale), ln_ld
         p.ln_z, p.ln_ldz, p.ln_offz = ptr(ln_z), ln_ldz, ln_offz
+        p.f32_split = getattr(self, "f32_split", 0)
         if weight is None and cw is not None and getattr(cw, "w8", None) is not None:
             p.weight_f8, p.w_scale, p.act_scale = cw.w8.data_ptr(), cw.ws.data_ptr(), FP8_ACT_SCALE
         if probe == "kid":          # which kernel would run (include/founddiff_hip.h: fd_conv_kernel_id)

@@ -105,6 +105,9 @@ typedef struct fd_conv_params {
     const void *weight_f8;
     const float *w_scale;
     float act_scale;
+    /* fp32 storage only: 1 = split-bf16 contraction (x = hi + lo in bf16, hi.hi + hi.lo + lo.hi on the bf16 MFMA,
+     * fp32 accumulation: ~2^-16 per product) instead of the exact-f32 MFMA.  The parity mode leaves it 0.       */
+    int32_t f32_split;
 } fd_conv_params;
 
 /* 1 if fd_conv2d would run `p` (weight_f8 / w_scale set) on the fp8 MFMA path.                        */

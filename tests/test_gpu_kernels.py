@@ -32,6 +32,7 @@ def eng_factory():
             self.dt, self.tdt = _T[mode]
             self.dev = torch.device("cuda")
             self.buf = {}
+            self.f32_split = int(mode == "fp32s")
     return Bare
 
 
@@ -47,7 +48,8 @@ def rq(x, mode):
     return x.to(torch.bfloat16).float() if mode == "bf16" else x
 
 
-@pytest.mark.parametrize("mode,tol", MODES)
+# 'fp32s': fp32 storage, split-bf16 contraction (3 bf16 MFMAs per product, ~2^-16): the engine of a bf16 loop's last step
+@pytest.mark.parametrize("mode,tol", MODES + [("fp32s", 1e-4)])
 @pytest.mark.parametrize("cfg", [
     dict(cin=64, cout=64, k=3, s=1, p=1, hw=(24, 20)),
     dict(cin=64, cout=128, k=4, s=2, p=1, hw=(16, 24)),
