@@ -114,6 +114,8 @@ class Unet(_ParamTree):
         self.out_dim = default(out_dim, channels)
         self.random_or_learned_sinusoidal_cond = False
         self.precision = precision or os.environ.get("FOUNDDIFF_PRECISION", "bf16")
+        # kernel set for one slice at a time (DAEngine low_latency); Trainer.test(batch_size=1) turns it on
+        self.low_latency = bool(int(os.environ.get("FOUNDDIFF_LOW_LATENCY", "0")))
         self.clip_cfg = clip_cfg or arch.RN50
         _build_tree(self, arch.da_unet_spec(dim, self.dim_mults, channels, "", self.clip_cfg, input_condition))
         self._engine = None
@@ -159,13 +161,14 @@ class Unet(_ParamTree):
         prec = precision or self.precision
         if self._engine is None:
             self._engine = {}
-        eng = self._engine.get((prec, slot))
+        key = (prec, slot) if not self.low_latency else (prec, slot, "ll")
+        eng = self._engine.get(key)
         if eng is None:
             dev = next(self.parameters()).device
             if dev.type != "cuda":
                 raise L.FoundDiffHipError("founddiff_amd runs on MI355X only: move the model to a ROCm device "
                                           "(`.to('cuda')`); there is no CPU path")
-            eng = self._engine[(prec, slot)] = DAEngine(self.state_dict(), "", dev, prec)
+            eng = self._engine[key] = DAEngine(self.state_dict(), "", dev, prec, low_latency=self.low_latency)
         return eng
 
     @torch.no_grad()
@@ -614,9 +617,30 @@ class ResidualDiffusion(nn.Module):
         time_buf = eng._b("loop_time", (shape[0],), torch.float32)
         return x_in, img, mo, time_buf
 
+    X_T_STEP = 0x7FFFFFFF      # the "step" under which the keyed stream draws x_T (fd_keyed_normal)
+
+    def _slice_seeds(self, slice_seeds, B, dev):
+        """(B,) int64 device tensor of per-slice seeds: given, or drawn from torch's global CPU generator (so
+        torch.manual_seed makes a run reproducible, like the reference's set_seed)."""
+        if slice_seeds is None:
+            slice_seeds = torch.randint(0, 2 ** 62, (B,), dtype=torch.int64)
+        slice_seeds = torch.as_tensor(slice_seeds, dtype=torch.int64).reshape(-1)
+        if slice_seeds.numel() != B:
+            raise ValueError(f"slice_seeds must hold one seed per slice ({B}), got {slice_seeds.numel()}")
+        return slice_seeds.to(dev).contiguous()
+
+    def _keyed_noise(self, seeds, t, shape):
+        nz = torch.empty(shape, device=seeds.device, dtype=torch.float32)
+        L.call("fd_keyed_normal", _p(seeds), int(t), _p(nz), shape[0], nz[0].numel(), _stream(nz))
+        return nz
+
     @torch.no_grad()
-    def p_sample_loop(self, x_input, shape, last=True, noise=None, step_noise=None):
-        """src/DADiff.py:1233-1273.  `noise`: the initial randn(shape); `step_noise`: callable t -> tensor."""
+    def p_sample_loop(self, x_input, shape, last=True, noise=None, step_noise=None, slice_seeds=None):
+        """src/DADiff.py:1233-1273.  `noise`: the initial randn(shape); `step_noise`: callable t -> tensor (parity
+        tests feed the reference's noise this way; one eager step at a time).  Without `step_noise` the step noise is
+        the per-slice keyed stream of fd_sched.hip -- a function of (slice_seeds[b], t, pixel) only, so a slice's
+        result does not depend on its batch, rank or stream -- and the loop runs from device tables: chunks of steps
+        are captured in a HIP graph and replayed (no host work per step)."""
         if self.input_condition:
             self._set_cond2(x_input[1])
         x_input = x_input[0].contiguous().float()
@@ -625,8 +649,11 @@ class ResidualDiffusion(nn.Module):
         x_in, img, mo, time_buf = self._loop_buffers(x_input, shape)
         eng = self._eng()
         eng.encode_condition(x_in)
+        seeds = None
+        if step_noise is None:
+            seeds = self._slice_seeds(slice_seeds, shape[0], x_in.device)
         if noise is None:
-            noise = torch.randn(shape, device=x_in.device)
+            noise = self._keyed_noise(seeds, self.X_T_STEP, shape) if seeds is not None else torch.randn(shape, device=x_in.device)
         L.call("fd_axpy_f32", _p(x_in), _p(noise.contiguous()), math.sqrt(self.sum_scale), _p(img), img.numel(),
                _stream(img))
         input_add_noise = img.clone()
@@ -634,29 +661,91 @@ class ResidualDiffusion(nn.Module):
         T = self.num_timesteps
         B = shape[0]
         coefs = torch.stack([hs["posterior_mean_coef1"], hs["posterior_mean_coef2"], hs["posterior_mean_coef3"],
-                             hs["posterior_log_variance_clipped"]], 1).to(x_in.device)      # (T,4)
-        times = (hs["alphas_cumsum"] * T).float().to(x_in.device)
+                             hs["posterior_log_variance_clipped"]], 1).float().contiguous().to(x_in.device)      # (T,4)
+        times = (hs["alphas_cumsum"] * T).float().contiguous().to(x_in.device)
         img_list = []
         K, e32 = self._tail_engine(eng)
-        for t in reversed(range(0, T)):
-            time_buf.fill_(float(times[t]))
-            if t < K:
-                self._step_forward(x_in, img, time_buf, mo, e32, tail_of=eng)
-            else:
-                self._step_forward(x_in, img, time_buf, mo, eng)
-            coef = coefs[t:t + 1].expand(B, 4).contiguous()
-            nz = None
-            if t > 0:
-                nz = step_noise(t) if step_noise is not None else torch.randn(shape, device=x_in.device)
-            L.call("fd_res_posterior_step", _p(mo), _p(img), _p(x_in), _p(nz), _p(coef), _p(img), None, B,
-                   img[0].numel(), _stream(img))
-            if not last:
-                img_list.append(img.clone())
+        if seeds is not None:
+            self._ancestral_keyed(eng, e32, K, x_in, img, mo, time_buf, coefs, times, seeds, last, img_list)
+        else:
+            for t in reversed(range(0, T)):
+                time_buf.fill_(float(times[t]))
+                if t < K:
+                    self._step_forward(x_in, img, time_buf, mo, e32, tail_of=eng)
+                else:
+                    self._step_forward(x_in, img, time_buf, mo, eng)
+                coef = coefs[t:t + 1].expand(B, 4).contiguous()
+                nz = step_noise(t) if t > 0 else None
+                L.call("fd_res_posterior_step", _p(mo), _p(img), _p(x_in), _p(nz), _p(coef), _p(img), None, B,
+                       img[0].numel(), _stream(img))
+                if not last:
+                    img_list.append(img.clone())
         if not last:
             img_list = [input_add_noise] + img_list
         else:
             img_list = [input_add_noise, img.clone()]
         return unnormalize_to_zero_to_one(img_list)
+
+    def _ancestral_keyed(self, eng, e32, K, x_in, img, mo, time_buf, coefs, times, seeds, last, img_list):
+        """The T ancestral steps with the timestep in a device counter: fd_ancestral_begin (t <- t - 1, UNet time
+        input) -> UNet forward -> fd_res_posterior_step_keyed (coefficient row t, keyed noise).  With last=True the
+        T - K main steps run as replays of one captured chunk of G steps and the K tail steps (higher-precision
+        engine) as a second graph."""
+        T, B = self.num_timesteps, x_in.shape[0]
+        npix = img[0].numel()
+        t_dev = eng._b("loop_t", (1,), torch.int32)
+        t_dev.fill_(T)
+        # graphs bake the pointers of coefs / times / seeds: keep them in engine-owned buffers
+        gco, gti, gse = eng._b("loop_coefs", tuple(coefs.shape), torch.float32), eng._b("loop_times", (T,), torch.float32), \
+            eng._b("loop_seeds", (B,), torch.int64)
+        gco.copy_(coefs)
+        gti.copy_(times)
+        gse.copy_(seeds)
+
+        def one(e):
+            L.call("fd_ancestral_begin", _p(t_dev), _p(gti), _p(time_buf), B, _stream(img))
+            if e is eng:
+                e.forward(img, x_in, time_buf, out=mo)
+            else:
+                self._tail_forward(e, eng, img, x_in, time_buf, mo)
+            L.call("fd_res_posterior_step_keyed", _p(mo), _p(img), _p(x_in), _p(gco), _p(t_dev), _p(gse), _p(img), None,
+                   B, npix, _stream(img))
+
+        n_main = T - K
+        if not (self.use_graph and last):
+            for i in range(T):
+                one(eng if i < n_main else e32)
+                if not last:
+                    img_list.append(img.clone())
+            return
+        G = max([g for g in range(8, 65) if n_main % g == 0] or [1])
+        graphs = eng.__dict__.setdefault("anc_graphs", {})
+        key = (tuple(img.shape), eng.mode, eng.gen, G, K, e32.gen if e32 else 0, self.final_outer_levels, T)
+        if key not in graphs:
+            start, t0 = img.clone(), t_dev.clone()
+            eng.forward(img, x_in, time_buf, out=mo)              # warm-up: every workspace buffer exists
+            if e32 is not None:
+                self._tail_forward(e32, eng, img, x_in, time_buf, mo)
+            torch.cuda.synchronize()
+            gm = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gm):
+                for _ in range(G):
+                    one(eng)
+            gt = None
+            if K > 0:
+                gt = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gt):
+                    for _ in range(K):
+                        one(e32)
+            graphs.clear()
+            graphs[key] = (gm, gt)
+            img.copy_(start)
+            t_dev.copy_(t0)
+        gm, gt = graphs[key]
+        for _ in range(n_main // G):
+            gm.replay()
+        if gt is not None:
+            gt.replay()
 
     @torch.no_grad()
     def ddim_sample(self, x_input, shape, last=True, noise=None):
@@ -763,8 +852,10 @@ class ResidualDiffusion(nn.Module):
         return unnormalize_to_zero_to_one(img_list)
 
     @torch.no_grad()
-    def sample(self, x_input=0, batch_size=16, last=True, noise=None, step_noise=None):
-        """src/DADiff.py:1368-1380: x_input = [ldct (B,1,H,W) in [0,1]] -> list of images in ~[0,1]."""
+    def sample(self, x_input=0, batch_size=16, last=True, noise=None, step_noise=None, slice_seeds=None):
+        """src/DADiff.py:1368-1380: x_input = [ldct (B,1,H,W) in [0,1]] -> list of images in ~[0,1].
+        `slice_seeds` (B int64): per-slice keys of the ancestral sampler's step noise (and of x_T when `noise` is not
+        given) -- see p_sample_loop; founddiff_amd.parallel.sample_volume passes seed + GLOBAL slice index."""
         x_input = list(x_input)
         if self.input_condition and self.input_condition_mask:     # src/DADiff.py:1372-1375
             x_input[0] = normalize_to_neg_one_to_one(x_input[0])
@@ -772,16 +863,24 @@ class ResidualDiffusion(nn.Module):
             x_input = normalize_to_neg_one_to_one(x_input)
         batch_size, channels, h, w = x_input[0].shape
         size = (batch_size, channels, h, w)
-        nsl = self.streams if (self._is_shipped() and self.is_ddim_sampling and last and batch_size >= 8 and
-                               batch_size % self.streams == 0) else 1
+        # two concurrent sub-batches: DDIM, and the ancestral sampler when its step noise is the keyed stream
+        nsl = self.streams if (self._is_shipped() and last and batch_size >= 8 and batch_size % self.streams == 0 and
+                               (self.is_ddim_sampling or step_noise is None)) else 1
         if nsl > 1:
-            return self._sample_concurrent(x_input[0], size, noise, nsl)
+            seeds = None
+            if not self.is_ddim_sampling:
+                seeds = self._slice_seeds(slice_seeds, batch_size, x_input[0].device)
+                if noise is None:
+                    noise = self._keyed_noise(seeds, self.X_T_STEP, size)
+            return self._sample_concurrent(x_input[0], size, noise, nsl, seeds)
         if self.is_ddim_sampling:
+            if noise is None and slice_seeds is not None:
+                noise = self._keyed_noise(self._slice_seeds(slice_seeds, batch_size, x_input[0].device), self.X_T_STEP, size)
             return self.ddim_sample(x_input, size, last=last, noise=noise)
-        return self.p_sample_loop(x_input, size, last=last, noise=noise, step_noise=step_noise)
+        return self.p_sample_loop(x_input, size, last=last, noise=noise, step_noise=step_noise, slice_seeds=slice_seeds)
 
-    def _sample_concurrent(self, x_in, size, noise, nsl):
-        """DDIM sampling of a batch as `nsl` independent sub-batches, each on its own HIP stream with its own engine
+    def _sample_concurrent(self, x_in, size, noise, nsl, seeds=None):
+        """Sampling of a batch (DDIM; ancestral with keyed step noise: `seeds`) as `nsl` independent sub-batches, each on its own HIP stream with its own engine
         (workspaces, captured loop graph).  A slice's result does not depend on what else is in its batch (kernel
         configurations depend on the image size only), so the output is bit-identical to the single-stream run."""
         B = size[0]
@@ -799,8 +898,12 @@ class ResidualDiffusion(nn.Module):
             try:
                 with torch.cuda.stream(st):
                     sl = slice(k * per, (k + 1) * per)
-                    o = self.ddim_sample([x_in[sl].contiguous()], (per,) + tuple(size[1:]), last=True,
-                                         noise=noise[sl].contiguous())
+                    if seeds is None:
+                        o = self.ddim_sample([x_in[sl].contiguous()], (per,) + tuple(size[1:]), last=True,
+                                             noise=noise[sl].contiguous())
+                    else:
+                        o = self.p_sample_loop([x_in[sl].contiguous()], (per,) + tuple(size[1:]), last=True,
+                                               noise=noise[sl].contiguous(), slice_seeds=seeds[sl])
             finally:
                 self._slot = 0
             outs.append((st, o))
@@ -974,6 +1077,13 @@ class Trainer(object):
         reference's unconditional `self.sample` rounds (100, or up to 50000 images with FID)."""
         from .metrics import compute_metrics
         self.model.init()
+        # batch_size 1 is the reference's loop: one slice per sample() call -> the kernel set for a lone slice (DAEngine
+        # low_latency: same arithmetic, chunked scans at every level; outputs differ from a batched run by fp32
+        # summation order)
+        for name in ("unet0", "unet1"):
+            u = getattr(getattr(self.model, "model", None), name, None)
+            if u is not None and hasattr(u, "low_latency"):
+                u.low_latency = batch_size == 1
         print("test start")
         if not self.condition:
             if FID:
@@ -1002,12 +1112,17 @@ class Trainer(object):
                 y_pred = all_images_list[-1]
             else:
                 y_pred = list(self.model.sample(xs, batch_size=len(idx), last=last))[-1]
-                if self.crop_patch:
-                    pad = [ds.get_pad_size(i + 1) for i in idx]         # the reference indexes with the NEXT item (1875)
-                    assert len(set(map(tuple, pad))) == 1, "crop_patch needs one pad size per batch"
-                    h, w = y_pred.shape[-2:]
-                    y_pred = y_pred[:, :, 0:h - pad[0][0], 0:w - pad[0][1]]
+                # src/DADiff.py:1872-1886: the metrics use the UNCROPPED prediction; crop_patch only crops what is saved
                 m = compute_metrics(y_pred, y).cpu().numpy()
+            y_save = y_pred
+            if self.crop_patch and not sample:
+                # the reference calls get_pad_size with its 1-based item counter (1826-1838, 1875): the last item would
+                # index one past the end of a 0-based table, so the index is clamped
+                pad = [tuple(ds.get_pad_size(min(i + 1, len(ds) - 1))) for i in idx]
+                if len(set(pad)) != 1:
+                    raise ValueError("crop_patch needs one pad size per batch (use batch_size=1)")
+                h, w = y_pred.shape[-2:]
+                y_save = y_pred[:, :, 0:h - pad[0][0], 0:w - pad[0][1]]
             for j, i in enumerate(idx):
                 file_name = ds.load_name(i, sub_dir=self.sub_dir)
                 self.test_image_names.append(self.image_file_name(file_name))
@@ -1017,8 +1132,8 @@ class Trainer(object):
                     self.test_running_rmse.append(m[j, 2])
                     print("(psnr: %.4f, ssim: %.4f,rmse:.%.4f) " % (m[j, 0], m[j, 1], m[j, 2]))
                 if not getattr(self.opt, "is_train", False) and not sample:
-                    h, w = y_pred.shape[-2:]
-                    np.save(self.results_folder + "/" + file_name[:-4], y_pred[j].detach().cpu().numpy().reshape(h, w))
+                    h, w = y_save.shape[-2:]
+                    np.save(self.results_folder + "/" + file_name[:-4], y_save[j].detach().cpu().numpy().reshape(h, w))
                     print("test-save " + file_name)
         if sample:
             print("test end")

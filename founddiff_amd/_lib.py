@@ -9,6 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libfounddiff_hip.so")
 
 FD_F32, FD_BF16 = 0, 1
+FD_OPT_LOW_LATENCY = 0x100
 EPI_NONE, EPI_SILU_SPLIT, EPI_RELU, EPI_GATE_RES, EPI_RES_RELU, EPI_GNSILU_ADD = range(6)
 ACT_NONE, ACT_SILU, ACT_GELU, ACT_RELU = range(4)
 PRO_NONE, PRO_LN_MOD, PRO_LN_GATE = range(3)
@@ -90,6 +91,9 @@ SIGNATURES = {
     "fd_res_ddim_step": (i32, [vp, vp, vp, vp, f32, f32, i32, vp, i64, vp]),
     "fd_res_step_obj": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i64, vp]),
     "fd_res_posterior_step": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i64, vp]),
+    "fd_keyed_normal": (i32, [vp, i32, vp, i32, i64, vp]),
+    "fd_ancestral_begin": (i32, [vp, vp, vp, i32, vp]),
+    "fd_res_posterior_step_keyed": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i64, vp]),
     "fd_gn_film_silu_apply": (i32, [i32, vp, vp, vp, vp, vp, vp, i32, vp, i32, i64, i32, i32, vp]),
     "fd_chan_ln": (i32, [i32, vp, vp, vp, vp, i64, i32, vp]),
     "fd_linear_attention": (i32, [i32, vp, i32, i64, i32, vp, vp, vp, vp, i32, vp]),

@@ -21,6 +21,7 @@ struct ScanGeom {
     int H2, W2, L, CL, nch;
     const void *xw;      // bf16 x_proj weights [4][CD][D], or NULL: phase A computes the chunk's x_dbl rows itself
     float *xdbl_out;     // ... and writes them here for phase C
+    bool low_latency;    // FD_OPT_LOW_LATENCY: chunked scan at every size (include/founddiff_hip.h)
 };
 
 // position l of direction k -> (row of xdbl, NHWC pixel index inside the image)
@@ -689,7 +690,7 @@ static bool scan_cpl2_on() {
 template <typename T, int N, int R, bool ODD>
 void launch_scan(const T *xc, const float *xdbl, const float *dtw, const float *dtb, const float *A,
                  const float *Ds, T *y, float *ws, const ScanGeom &g, hipStream_t s) {
-    if (!g.xw && scan_seq_ok(g.H, g.W, g.D, g.N, g.R)) {
+    if (!g.xw && !g.low_latency && scan_seq_ok(g.H, g.W, g.D, g.N, g.R)) {
         launch_scan_seq<T, N, R, ODD>(xc, xdbl, dtw, dtb, A, Ds, y, g, s);
         return;
     }
@@ -697,7 +698,7 @@ void launch_scan(const T *xc, const float *xdbl, const float *dtw, const float *
     float *wsH = ws, *wsP = ws + half;
     // two channels per lane where the kernel is VALU-bound and the state is small (bf16, N <= 8); a function of the
     // shape only
-    constexpr int CPL = (sizeof(T) == 2 && N <= 8) ? 2 : 1;
+    constexpr int CPL = (sizeof(T) == 2 && N <= 4) ? 2 : 1;     // N = 8: measured slower (305 vs 293 us at 256x256, batch 8)
     const bool two = CPL == 2 && g.D % 128 == 0 && scan_cpl2_on();
     const int cw = two ? 128 : 64;                     // channels per wave
     const int nw = g.D >= 4 * cw ? 4 : g.D / cw;       // waves per workgroup
@@ -767,6 +768,7 @@ ScanGeom make_geom(int B, int H, int W, int D, int N, int R) {
     g.nch = (g.L + g.CL - 1) / g.CL;
     g.xw = nullptr;
     g.xdbl_out = nullptr;
+    g.low_latency = false;
     return g;
 }
 
@@ -779,14 +781,16 @@ extern "C" int64_t fd_scan_ws_floats(int B, int H, int W, int D, int N) {
     return 2 * (int64_t)B * 4 * g.nch * N * D;
 }
 
-static int scan_entry(int dtype, const void *xc, const void *x_proj_w, float *xdbl, const float *dtw, const float *dtb,
+static int scan_entry(int dtype_opts, const void *xc, const void *x_proj_w, float *xdbl, const float *dtw, const float *dtb,
                       const float *A, const float *Ds, void *y, float *ws, int B, int H, int W, int D, int N, int R,
                       void *stream) {
+    const int dtype = dtype_opts & 0xff;
     FD_REQUIRE(xc && xdbl && dtw && dtb && A && Ds && y && ws, "fd_selective_scan: null pointer");
     FD_REQUIRE(H > 0 && W > 0, "fd_selective_scan: bad image size %d x %d", H, W);
     FD_REQUIRE(D % 64 == 0, "fd_selective_scan: d_inner=%d must be a multiple of 64", D);
     FD_REQUIRE((int64_t)H * W * D * 4 < (1ll << 31), "fd_selective_scan: one image must stay below 2^31 bytes");
     ScanGeom g = make_geom(B, H, W, D, N, R);
+    g.low_latency = (dtype_opts & FD_OPT_LOW_LATENCY) != 0;
     if (x_proj_w) {
         FD_REQUIRE(fd_selective_scan_fuses_xproj(dtype, D, N, R), "fd_selective_scan_xproj: not available for this shape "
                    "(bf16, d_inner <= 256, (R + 2N) %% 4 == 0): D=%d N=%d R=%d", D, N, R);
@@ -817,8 +821,9 @@ extern "C" int fd_selective_scan_fuses_xproj(int dtype, int D, int N, int R) {
 // 1 if the engine should call fd_selective_scan_xproj for this block (x_proj inside the chunked scan's first phase),
 // 0 if it should run the x_proj launch and fd_selective_scan: the single-pass scan of short sequences with a wide
 // state takes its x_dbl rows from the workspace.  A function of the shape only.
-extern "C" int fd_selective_scan_plan(int dtype, int D, int N, int R, int H, int W) {
-    return fd_selective_scan_fuses_xproj(dtype, D, N, R) && !scan_seq_ok(H, W, D, N, R);
+extern "C" int fd_selective_scan_plan(int dtype_opts, int D, int N, int R, int H, int W) {
+    const bool seq = !(dtype_opts & FD_OPT_LOW_LATENCY) && scan_seq_ok(H, W, D, N, R);
+    return fd_selective_scan_fuses_xproj(dtype_opts & 0xff, D, N, R) && !seq;
 }
 
 extern "C" int fd_selective_scan_xproj(int dtype, const void *xc, const void *x_proj_w, float *xdbl, const float *dtw,

@@ -86,7 +86,7 @@ class DAEngine:
     _GEN = 0        # every engine gets a unique generation number: captured HIP graphs are keyed on it
     probe = None    # development hook: probe(tag, tensor) after each stage (tools/drift_table.py, stage_times.py)
 
-    def __init__(self, state_dict, prefix="", device="cuda", mode="bf16"):
+    def __init__(self, state_dict, prefix="", device="cuda", mode="bf16", low_latency=False):
         L.lib()  # fail loudly if the HIP library is missing
         DAEngine._GEN += 1
         self.gen = DAEngine._GEN
@@ -96,6 +96,10 @@ class DAEngine:
         self.dt, self.tdt = _T[mode]
         self.fp8 = mode == "fp8"
         self.f32_split = int(mode == "fp32s")
+        # low_latency: the kernel set for ONE slice at a time (the reference's Trainer.test loop).  The default set is
+        # chosen for throughput at a batch that fills the chip; both are functions of the image size only.
+        self.low_latency = bool(low_latency)
+        self.scan_dt = self.dt | (L.FD_OPT_LOW_LATENCY if low_latency else 0)
         self.dev = torch.device(device)
         self.f32 = dict(device=self.dev, dtype=torch.float32)
         sd = _Sub(state_dict, prefix)
@@ -410,7 +414,7 @@ class DAEngine:
         nws = L.lib().fd_scan_ws_floats(B, H, W, D, N)
         ws = self._b("scan_ws", (nws,), torch.float32)
         y = self._b("scan_y", (B, H, W, D))
-        if L.lib().fd_selective_scan_plan(self.dt, D, N, R, H, W):
+        if L.lib().fd_selective_scan_plan(getattr(self, 'scan_dt', self.dt), D, N, R, H, W):
             # x_proj inside the scan's first phase (one workgroup per chunk at d_inner <= 256): no separate pass over xc
             L.call("fd_selective_scan_xproj", self.dt, _p(xc), _p(m["x_proj"]), _p(xdbl), _p(m["dtw"]), _p(m["dtb"]),
                    _p(m["A"]), _p(m["Ds"]), _p(y), _p(ws), B, H, W, D, N, R, s)
@@ -420,7 +424,7 @@ class DAEngine:
                       pad=0, ndir=4, w_dir_stride=CD * D, out_dir_stride=B * Lq * CD, out_f32=True,
                       OH=H2, OW=W2)
             self._pr(tag + ".xdbl", xdbl)
-            L.call("fd_selective_scan", self.dt, _p(xc), _p(xdbl), _p(m["dtw"]), _p(m["dtb"]), _p(m["A"]),
+            L.call("fd_selective_scan", getattr(self, "scan_dt", self.dt), _p(xc), _p(xdbl), _p(m["dtw"]), _p(m["dtb"]), _p(m["A"]),
                    _p(m["Ds"]), _p(y), _p(ws), B, H, W, D, N, R, s)
         self._pr(tag + ".y", y)
         loc = C.c_void_p(self.local_all.data_ptr() + m["loc_off"] * f4)

@@ -42,8 +42,9 @@ def gather_volume(local, world, n_total=None):
 def sample_volume(diffusion, ldct, world=1, rank=0, noise_seed=0, batch=8, sampler_kwargs=None):
     """Denoise a whole volume ldct (N,1,H,W in [0,1], same tensor on every rank) with `diffusion`
     (a founddiff_amd.DADiff.ResidualDiffusion living on this rank's device).  x_T noise is keyed
-    by the GLOBAL slice index, so the result is invariant to `world`.  Returns the (N,1,H,W)
-    volume on every rank."""
+    by the GLOBAL slice index, and so is the ancestral sampler's per-step noise (`slice_seeds`:
+    fd_sched.hip's counter-based stream), so the result is invariant to `world` for both samplers.
+    Returns the (N,1,H,W) volume on every rank."""
     n = ldct.shape[0]
     lo, hi = shard_range(n, world, rank)
     dev = next(diffusion.parameters()).device
@@ -53,6 +54,7 @@ def sample_volume(diffusion, ldct, world=1, rank=0, noise_seed=0, batch=8, sampl
         x = ldct[s:e].to(dev)
         nz = torch.stack([torch.randn(x.shape[1:], generator=torch.Generator().manual_seed(noise_seed + i))
                           for i in range(s, e)]).to(dev)
-        outs.append(diffusion.sample([x], batch_size=e - s, noise=nz, **(sampler_kwargs or {}))[-1])
+        seeds = torch.arange(s, e, dtype=torch.int64) + int(noise_seed)
+        outs.append(diffusion.sample([x], batch_size=e - s, noise=nz, slice_seeds=seeds, **(sampler_kwargs or {}))[-1])
     local = torch.cat(outs, 0) if outs else ldct.new_zeros((0,) + tuple(ldct.shape[1:])).to(dev)
     return gather_volume(local, world, n)

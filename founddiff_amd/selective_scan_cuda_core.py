@@ -9,7 +9,8 @@ nothing else changed, put this module under that name before `src.emamba2` is im
     import sys, founddiff_amd.selective_scan_cuda_core as m
     sys.modules["selective_scan_cuda_core"] = m
 
-Arguments as the extension takes them (src/emamba2.py:124-149): fp32 CUDA/HIP tensors, last dim contiguous,
+Arguments as the extension takes them (src/emamba2.py:124-149): fp32 CUDA/HIP tensors (fp16 / bf16 are up-cast, as the
+reference's custom_fwd(cast_inputs=float32) does), last dim contiguous,
 u / delta (b, KD, L), A (KD, N), B / C (b, K, N, L), D / delta_bias (KD) or None.  Returns `(out, x)`: out
 (b, KD, L); x = the state after the last position, (b, KD, N) -- the extension returns its backward pass's chunk
 states there, which a forward-only library has no use for (the reference's forward ignores `x` except to save
@@ -24,8 +25,10 @@ from . import _lib as L
 
 
 def _chk(name, t, ndim):
+    if t.dtype in (torch.float16, torch.bfloat16):
+        t = t.float()          # the reference's autograd wrapper casts its inputs to fp32 (custom_fwd, src/emamba2.py:127)
     if t.dtype != torch.float32:
-        raise RuntimeError(f"selective_scan_cuda_core.fwd: {name} must be float32 (got {t.dtype})")
+        raise RuntimeError(f"selective_scan_cuda_core.fwd: {name} must be float32 / float16 / bfloat16 (got {t.dtype})")
     if t.dim() != ndim:
         raise RuntimeError(f"selective_scan_cuda_core.fwd: {name} must be {ndim}-dimensional (got {tuple(t.shape)})")
     if not t.is_cuda:
@@ -50,12 +53,16 @@ def fwd(u, delta, A, B, C_, D=None, delta_bias=None, delta_softplus=False, nrows
         D = _chk("D", D, 1)
     if delta_bias is not None:
         delta_bias = _chk("delta_bias", delta_bias, 1)
-    out = torch.empty_like(u)
-    x = torch.empty(b, KD, N, device=u.device, dtype=torch.float32)
+    for name, t in (("delta", delta), ("A", A), ("B", B), ("C", C_), ("D", D), ("delta_bias", delta_bias)):
+        if t is not None and t.device != u.device:
+            raise RuntimeError(f"selective_scan_cuda_core.fwd: {name} lives on {t.device}, u on {u.device}")
     p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
-    stream = C.c_void_p(torch.cuda.current_stream(u.device).cuda_stream)
-    L.call("fd_selective_scan_fwd_f32", p(u), p(delta), p(A), p(B), p(C_), p(D), p(delta_bias), int(bool(delta_softplus)),
-           int(nrows), b, KD, K, N, Ln, p(out), p(x), stream)
+    with torch.cuda.device(u.device):          # the launch goes to u's GPU, whatever the current device is
+        out = torch.empty_like(u)
+        x = torch.empty(b, KD, N, device=u.device, dtype=torch.float32)
+        stream = C.c_void_p(torch.cuda.current_stream(u.device).cuda_stream)
+        L.call("fd_selective_scan_fwd_f32", p(u), p(delta), p(A), p(B), p(C_), p(D), p(delta_bias),
+               int(bool(delta_softplus)), int(nrows), b, KD, K, N, Ln, p(out), p(x), stream)
     return out, x
 
 

@@ -202,6 +202,11 @@ int fd_pw_dw3x3_gram(int dtype, const void *x, int ld_x, int off_x, int Cin, con
  * (L <= 1024, N >= 16, R % 8 == 0: the 64x64 level of a 512x512 slice) run ONE sequential pass instead, 4 lanes
  * per channel sharing the states and the dt_proj contraction -- no chunks, no workspace traffic; which form
  * runs depends on (H, W, N, R) only, never on B.                                              */
+/* OR-ed into the `dtype` argument of fd_selective_scan / fd_selective_scan_plan: keep the chunked 3-phase form at every
+ * size.  The single-pass form of short sequences is the faster one once a batch fills the chip (x1.7 at 8 slices of
+ * 512x512) but walks its 1024 positions with one wave per channel group: a lone slice takes 2-3x longer in it.  An
+ * engine uses ONE of the two for all its calls (DAEngine low_latency), so results stay batch-invariant within it.  */
+#define FD_OPT_LOW_LATENCY 0x100
 int64_t fd_scan_ws_floats(int B, int H, int W, int D, int N);
 int fd_selective_scan(int dtype, const void *xc, const float *xdbl, const float *dtw,
                       const float *dtb, const float *A, const float *Ds, void *y, float *ws,
@@ -331,6 +336,21 @@ int fd_res_step_obj(int mode, int step, const float *o0, const float *o1, const 
 int fd_res_posterior_step(const float *model_out, const float *x_t, const float *x_in,
                           const float *noise, const float *coef, float *img_out,
                           float *x_start_out, int B, int64_t npix, void *stream);
+/* ---- ancestral sampling without a host in the loop, step noise keyed per slice (fd_sched.hip)
+ * The reference draws randn_like(x) from the device generator at every step (src/DADiff.py:1228): a slice's noise
+ * depends on its place in the batch.  Here noise(slice, t, pixel) = Box-Muller(Philox4x32-10(key = seeds[b] (64 bit),
+ * counter = (pixel / 4, t, 0x46444e5a, 0))): the same slice gets the same stream on any rank / batch / stream
+ * (BASELINE configs[3]: a volume sharded over 8 GPUs).  oracle/keyed_noise.py restates it.
+ *   fd_keyed_normal               out[b][i] = that noise (x_T draws with t = 0x7fffffff, tests)
+ *   fd_ancestral_begin            *t_dev -= 1;  time_buf[b] = times[*t_dev]   (times = alphas_cumsum * T, device)
+ *   fd_res_posterior_step_keyed   fd_res_posterior_step with t = *t_dev, coefficients coef_table[t][4] = c1, c2, c3,
+ *                                 logvar (device, [T][4]) and the keyed noise (none at t = 0)
+ * All three read the step from DEVICE memory: a chunk of steps captures into one HIP graph.                   */
+int fd_keyed_normal(const int64_t *seeds, int t, float *out, int B, int64_t npix, void *stream);
+int fd_ancestral_begin(int *t_dev, const float *times, float *time_buf, int B, void *stream);
+int fd_res_posterior_step_keyed(const float *model_out, const float *x_t, const float *x_in,
+                                const float *coef_table, const int *t_dev, const int64_t *seeds,
+                                float *img_out, float *x_start_out, int B, int64_t npix, void *stream);
 /* ---- vanilla DDPM U-Net extras (src/denoising_diffusion_pytorch.py) -----------------------
  * fd_gn_film_silu_apply: silu(GN(h)*(1+scale[b]) + shift[b])   Block w/ scale_shift, 190-199, 213-221
  * fd_chan_ln:            LN over channels * g (+ res)           LayerNorm/PreNorm/Residual, 95-101,127-146

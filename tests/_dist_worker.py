@@ -11,14 +11,17 @@ import torch.distributed as dist  # noqa: E402
 TINY_CLIP = dict(layers=(2, 1, 1, 1), width=16, embed_dim=1024)
 
 
-def build(dev):
+def build(dev, ancestral=False):
     from founddiff_amd import arch, synth
     from founddiff_amd.DADiff import ResidualDiffusion, UnetRes, load_weights
     spec = arch.da_unet_spec(32, (1, 2), prefix="model.unet0.", clip=TINY_CLIP)
     w = synth.synth_state_dict(spec, seed=0)
     net = UnetRes(dim=32, dim_mults=(1, 2), num_unet=1, condition=True, objective="pred_res",
                   test_res_or_noise="res", precision="bf16", clip_cfg=TINY_CLIP)
-    dif = ResidualDiffusion(net, image_size=64, timesteps=1000, sampling_timesteps=3, objective="pred_res",
+    # ancestral: sampling_timesteps == timesteps selects p_sample_loop (src/DADiff.py:1370); the reference's init()
+    # hard-codes 1000 timesteps, so this is the full-length loop (on the tiny model)
+    T, S = (1000, 1000) if ancestral else (1000, 3)
+    dif = ResidualDiffusion(net, image_size=64, timesteps=T, sampling_timesteps=S, objective="pred_res",
                             loss_type="l2", condition=True, sum_scale=0.01, test_res_or_noise="res")
     load_weights(dif, w)
     dif = dif.to(dev)
@@ -40,8 +43,10 @@ def main():
     rag = parallel.gather_volume(torch.full((rank + 1, 1, 4, 4), float(rank), device=dev), world)
     assert rag.shape[0] == world * (world + 1) // 2
     dist.barrier()
+    # the ancestral sampler over the same shards: step noise keyed by the global slice index
+    vol_a = parallel.sample_volume(build(dev, ancestral=True), torch.from_numpy(ld), world=world, rank=rank, noise_seed=100, batch=2)
     if rank == 0:
-        torch.save(vol.cpu(), out_path)
+        torch.save({"ddim": vol.cpu(), "ancestral": vol_a.cpu()}, out_path)
     dist.destroy_process_group()
 
 

@@ -37,10 +37,14 @@ def test_sample_volume_over_nccl(tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     got = torch.load(out)
     _, ld = synth.ct_phantom(n, 64, seed=10)
-    ref = parallel.sample_volume(wk.build(torch.device("cuda")), torch.from_numpy(ld), world=1, rank=0, noise_seed=100,
-                                 batch=2).cpu()
-    assert got.shape == ref.shape == (n, 1, 64, 64)
-    assert torch.equal(got, ref)
+    for name, anc, batch in (("ddim", False, 2), ("ancestral", True, 3)):
+        # the single-process reference runs with ANOTHER batch composition for the ancestral sampler (3 + 2 instead of
+        # 2 + 2 + 1): its step noise is keyed per slice, not drawn per batch
+        ref = parallel.sample_volume(wk.build(torch.device("cuda"), ancestral=anc), torch.from_numpy(ld), world=1, rank=0,
+                                     noise_seed=100, batch=batch).cpu()
+        assert got[name].shape == ref.shape == (n, 1, 64, 64)
+        assert torch.equal(got[name], ref), name
+    assert not torch.equal(got["ddim"], got["ancestral"])
 
 
 def test_bench_self_launch_single_rank():

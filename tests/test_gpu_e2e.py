@@ -476,6 +476,116 @@ def test_properties_512_bf16():
     assert torch.equal(a[0:1], s0) and torch.equal(a[1:2], s1)
 
 
+def test_keyed_noise_kernels_vs_oracle():
+    """fd_keyed_normal (Philox4x32-10 + Box-Muller keyed by (slice seed, t, pixel), fd_sched.hip) against its numpy
+    restatement oracle/keyed_noise.py; fd_res_posterior_step_keyed == fd_res_posterior_step fed with that noise."""
+    import numpy as np
+    from founddiff_amd import _lib as L
+    from oracle import keyed_noise as kn
+    seeds = torch.tensor([5, (1 << 40) + 17, 123456789012345], dtype=torch.int64, device="cuda")
+    B, npix = 3, 64 * 64 + 3                                    # not a multiple of 4: ragged last group
+    st = torch.cuda.current_stream().cuda_stream
+    for t in (1, 999, 0x7FFFFFFF):
+        out = torch.empty(B, npix, device="cuda")
+        L.call("fd_keyed_normal", seeds.data_ptr(), t, out.data_ptr(), B, npix, st)
+        ref = np.stack([kn.keyed_normal(int(sd), t, npix) for sd in seeds.tolist()])
+        assert float((out.cpu() - torch.from_numpy(ref)).abs().max()) < 5e-5
+    big = torch.empty(1, 1 << 20, device="cuda")
+    L.call("fd_keyed_normal", seeds.data_ptr(), 7, big.data_ptr(), 1, 1 << 20, st)
+    assert abs(float(big.mean())) < 5e-3 and abs(float(big.std()) - 1) < 5e-3
+    # the keyed posterior step: coefficient row t from the device table, step from the device counter
+    T = 50
+    g = torch.Generator().manual_seed(3)
+    mo, xt, xin = (torch.randn(B, npix, generator=g).cuda() for _ in range(3))
+    table = torch.randn(T, 4, generator=g).cuda()
+    for t in (17, 0):
+        t_dev = torch.tensor([t], dtype=torch.int32, device="cuda")
+        o1, x1 = torch.empty_like(mo), torch.empty_like(mo)
+        L.call("fd_res_posterior_step_keyed", mo.data_ptr(), xt.data_ptr(), xin.data_ptr(), table.data_ptr(), t_dev.data_ptr(),
+               seeds.data_ptr(), o1.data_ptr(), x1.data_ptr(), B, npix, st)
+        nz = torch.empty_like(mo)
+        L.call("fd_keyed_normal", seeds.data_ptr(), t, nz.data_ptr(), B, npix, st)
+        o2, x2 = torch.empty_like(mo), torch.empty_like(mo)
+        coef = table[t:t + 1].expand(B, 4).contiguous()
+        L.call("fd_res_posterior_step", mo.data_ptr(), xt.data_ptr(), xin.data_ptr(), nz.data_ptr() if t > 0 else None,
+               coef.data_ptr(), o2.data_ptr(), x2.data_ptr(), B, npix, st)
+        torch.cuda.synchronize()
+        assert torch.allclose(o1, o2, rtol=0, atol=1e-6) and torch.equal(x1, x2)
+    tb = torch.zeros(B, device="cuda")
+    times = torch.arange(T, dtype=torch.float32, device="cuda") * 0.5
+    t_dev = torch.tensor([T], dtype=torch.int32, device="cuda")
+    L.call("fd_ancestral_begin", t_dev.data_ptr(), times.data_ptr(), tb.data_ptr(), B, st)
+    assert int(t_dev.item()) == T - 1 and float(tb[0]) == (T - 1) * 0.5 and float(tb[2]) == (T - 1) * 0.5
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_ancestral_keyed_loop_properties(golden, prec):
+    """p_sample_loop with the per-slice keyed step noise (BASELINE configs[3]'s sampler): the graph-chunk path is
+    bitwise equal to the eager step-by-step path; a slice's result is a function of (its input, its seed) only --
+    not of the batch it sits in, nor of the HIP stream (two concurrent sub-batches at batch 8); other seeds give
+    other images; everything finite."""
+    T = 1000            # the reference's init() hard-codes 1000 timesteps; sampling_timesteps == timesteps -> p_sample_loop
+    g, dif = _tiny_model(golden, prec, S=T)
+    assert not dif.is_ddim_sampling
+    x = g["x_input"].cuda()
+    x8 = torch.cat([x, x.flip(0), x * 0.9, x.flip(-1)], 0)[:8].contiguous()
+    seeds = torch.arange(8, dtype=torch.int64) + 1000
+    a = dif.sample([x8], batch_size=8, slice_seeds=seeds)[-1]               # two sub-batches of 4 on two streams
+    assert torch.isfinite(a).all()
+    assert "anc_graphs" in dif._eng().__dict__
+    dif.streams = 1
+    b = dif.sample([x8], batch_size=8, slice_seeds=seeds)[-1]               # one stream, graph chunks
+    assert torch.equal(a, b)
+    three = dif.sample([x8[2:5]], batch_size=3, slice_seeds=seeds[2:5])[-1]
+    assert torch.equal(three, a[2:5])
+    if prec == "fp32":
+        dif.use_graph = False
+        c = dif.sample([x8[4:6]], batch_size=2, slice_seeds=seeds[4:6])[-1]     # eager, one step at a time
+        assert torch.equal(c, a[4:6])
+        dif.use_graph = True
+        other = dif.sample([x8[5:6]], batch_size=1, slice_seeds=seeds[5:6] + 1)[-1]
+        assert not torch.equal(other, a[5:6])
+        # last=False returns every step (eager path): x_T, then T images
+        steps = dif.sample([x8[:2]], batch_size=2, last=False, slice_seeds=seeds[:2])
+        assert len(steps) == T + 1 and torch.equal(steps[-1], a[:2])
+
+
+def test_low_latency_kernel_set(golden):
+    """DAEngine low_latency (the kernel set Trainer.test(batch_size=1) selects: chunked scans at every level instead
+    of the single-pass scan of short sequences): same arithmetic in another summation order -- fp32 within 1e-4 of
+    the default set and of the reference golden, batch-invariant within itself."""
+    g, dif = _tiny_model(golden, "fp32", S=10)
+    x, nz = g["x_input"].cuda(), g["ddim.noise0"].cuda()
+    a = dif.sample([x], batch_size=x.shape[0], noise=nz)[-1]
+    dif.model.unet0.low_latency = True
+    b = dif.sample([x], batch_size=x.shape[0], noise=nz)[-1]
+    assert ("fp32", 0, "ll") in dif.model.unet0._engine                     # a second engine, its own graphs
+    assert rel_err(b.cpu(), a.cpu()) < 1e-4
+    b1 = dif.sample([x[0:1]], batch_size=1, noise=nz[0:1])[-1]
+    assert torch.equal(b1, b[0:1])
+    # the flag at the C ABI, on a shape the single-pass scan serves (the 64x64 level of the shipped model: d_inner 1024,
+    # N = 32, R = 32): both forms agree to summation order, and they ARE two forms (not bitwise equal)
+    from founddiff_amd import _lib as L
+    B, D, N, R, H, W = 1, 128, 32, 8, 32, 32
+    assert L.lib().fd_selective_scan_plan(L.FD_BF16, D, N, R, H, W) == 0
+    assert L.lib().fd_selective_scan_plan(L.FD_BF16 | L.FD_OPT_LOW_LATENCY, D, N, R, H, W) == 1
+    g = torch.Generator().manual_seed(2)
+    xc = (torch.randn(B, H, W, D, generator=g) * 0.5).cuda()
+    xdbl = torch.randn(4, B, (H // 2) * (W // 2), R + 2 * N, generator=g).cuda()
+    dtw, dtb = (torch.randn(4, D, R, generator=g) * R ** -0.5).cuda(), (torch.randn(4, D, generator=g) * 0.5 - 3).cuda()
+    A = -torch.exp(torch.log(torch.arange(1, N + 1).float())[None].repeat(4 * D, 1)).cuda()
+    Ds = torch.ones(4 * D).cuda()
+    ws = torch.empty(L.lib().fd_scan_ws_floats(B, H, W, D, N), device="cuda")
+    ys = []
+    for opts in (0, L.FD_OPT_LOW_LATENCY):
+        y = torch.empty(B, H, W, D, device="cuda")
+        L.call("fd_selective_scan", L.FD_F32 | opts, xc.data_ptr(), xdbl.data_ptr(), dtw.data_ptr(), dtb.data_ptr(), A.data_ptr(),
+               Ds.data_ptr(), y.data_ptr(), ws.data_ptr(), B, H, W, D, N, R, torch.cuda.current_stream().cuda_stream)
+        ys.append(y)
+    torch.cuda.synchronize()
+    assert rel_err(ys[1].cpu(), ys[0].cpu()) < 1e-5 and not torch.equal(ys[0], ys[1])
+
+
 VARIANTS = {   # name -> (num_unet, objective, test_res_or_noise); mirrors tests/golden/make_golden.py
     "pred_noise": (1, "pred_noise", "noise"), "res_noise": (2, "pred_res_noise", "res_noise"),
     "rn_noise": (2, "pred_res_noise", "noise"), "rn_res": (2, "pred_res_noise", "res"),

@@ -82,6 +82,15 @@ def test_trainer_load_test_sample(tmp_path):
     tr.test(last=True, batch_size=1)
     assert np.allclose(tr.test_running_psnr, one, atol=1e-4)
     assert len(tr.test(last=True, batch_size=2)) == 3 and len(tr.test_running_psnr) == 3
+    # crop_patch (src/DADiff.py:1872-1886): only the SAVED array is cropped by the dataset's pad size, the metrics use
+    # the uncropped prediction
+    ds.get_pad_size = lambda i: (4, 6)
+    tr.crop_patch = True
+    torch.manual_seed(3)
+    tr.test(last=True, batch_size=1)
+    assert np.allclose(tr.test_running_psnr, one, atol=1e-4)
+    assert np.load(os.path.join(tr.results_folder, ds.load_name(2)[:-4] + ".npy")).shape == (60, 58)
+    tr.crop_patch = False
     # sample=True: inputs + outputs, no metrics, nothing saved (src/DADiff.py:1863-1866)
     assert tr.test(sample=True) is None and tr.test_running_psnr == []
     # preview grid: PNG in the HU window, like torchvision's save_image (1792-1812); FID: one PNG per image
