@@ -68,14 +68,63 @@ def _time_launches(lib, launches, reps=5):
     return best
 
 
-def roofline_leg(dif, x, noise):
-    """Roofline of the dominant kernel symbol of the rocprofv3 --stats summary of this command
-    (profiles/): pwdw_kernel, the fused LayerNorm+modulate -> 1x1 -> depthwise 3x3 of the 64-channel
-    Mamba blocks (HBM roofline: it reads 64 and writes 192..256 channels per pixel; in practice it is
-    VALU-issue limited).  Replays exactly its launches of one UNet forward between HIP
-    events.  `others` carries the same measurement for the runner-up symbols (conv3x3_halo_kernel:
-    MFMA-bound implicit GEMM; dwconv3x3_bf16_kernel: HBM-bound) so the table in profiles/ can be
-    cross-checked."""
+def csrc_sha():
+    """hash of the kernel sources: profiles/traffic.json records the one it was measured with"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "founddiff_amd", "csrc", "*"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+TRANSCENDENTALS_PER_S = 256 * 4 * 8 * 2.4e9       # v_exp / v_log: 8 lanes per clock per SIMD (MI355X_MICROARCH.md, issue cost 8 cyc)
+HBM_ACHIEVABLE_BPS = 6.3e12                       # MI355X_MICROARCH.md: 6.29 TB/s measured copy rate
+
+
+def forward_bounds(eng, H, W, traffic, t_measured_ms):
+    """Whole-forward bounds per slice (ms): HBM at the achievable rate over the measured traffic, the bf16 MFMA peak
+    over the algorithmic FLOPs, and the transcendental-issue floor of the selective scans ((N + 2) v_exp / v_log per
+    channel and position and pass: the chunked form runs two passes, the single-pass form of short sequences one)."""
+    from founddiff_amd import _lib as L
+    lib = L.lib()
+    levels = []
+    h, w = H, W
+    for d in eng.downs:
+        levels.append((d["mamba"], h, w))
+        if d["stride"] == 2:
+            h, w = h // 2, w // 2
+    levels.append((eng.mid_mamba, h, w))
+    for u in eng.ups:
+        levels.append((u["mamba"], h, w))
+        if u["up"]:
+            h, w = 2 * h, 2 * w
+    ntr = 0.0
+    for m, hh, ww in levels:
+        fused = lib.fd_selective_scan_plan(getattr(eng, "scan_dt", eng.dt), m["D"], m["N"], m["R"], hh, ww)
+        single = (not fused) and m["N"] >= 16 and ((hh + 1) // 2) * ((ww + 1) // 2) <= 1024 and m["R"] % 8 == 0 and not eng.low_latency
+        ntr += 4.0 * m["D"] * ((hh + 1) // 2) * ((ww + 1) // 2) * (m["N"] + 2) * (1 if single else 2)
+    tot = traffic.get("total_hbm_bytes_per_forward")
+    nb = traffic.get("batch", 8)
+    out = {"t_measured": round(t_measured_ms, 4),
+           "t_mfma": round(ALG_GFLOP_PER_FORWARD * 1e9 / (PEAK_BF16_TFLOPS * 1e12) * 1e3, 4),
+           "t_scan_transcendental_floor": round(ntr / TRANSCENDENTALS_PER_S * 1e3, 4),
+           "scan_transcendentals": int(ntr), "unit": "ms per slice-forward"}
+    if tot:
+        out["hbm_bytes_measured"] = int(tot / nb)
+        out["t_hbm_at_6.3TBps"] = round(tot / nb / HBM_ACHIEVABLE_BPS * 1e3, 4)
+        out["traffic_measured_with_current_kernels"] = traffic.get("csrc_sha") == csrc_sha()
+        out["frac_of_bound"] = round(max(out["t_hbm_at_6.3TBps"], out["t_mfma"], out["t_scan_transcendental_floor"]) / t_measured_ms, 3)
+    return out
+
+
+def roofline_leg(dif, x, noise, t_measured_ms=None):
+    """Roofline of the dominant kernel symbol of one UNet forward -- the symbol with the largest total time, which is
+    also the top symbol of the rocprofv3 --stats summary of this command (profiles/).  Candidates: pwdw_kernel and
+    pwdw_gram_kernel (fused LayerNorm+modulate -> 1x1 -> depthwise 3x3 [-> Gram] of the 64-channel Mamba blocks: HBM
+    roofline), the two instantiations of conv3x3_halo_kernel (MFMA roofline) and dwconv3x3_bf16_kernel (HBM).  Each is
+    measured by replaying exactly its launches of one forward between HIP events on the launch stream; the largest
+    becomes `roofline`, the rest `roofline.others`.  `forward`: the whole-forward bounds (forward_bounds)."""
     from founddiff_amd import _lib as L
     eng = dif._eng()
     # the timed region launches every kernel on sub-batches (concurrent half-batches): measure that launch shape
@@ -106,19 +155,22 @@ def roofline_leg(dif, x, noise):
                 "launches_per_forward": len(launches), "avg_launch_us": round(ms * 1e3 / len(launches), 2),
                 "alg_bytes_per_launch": round(nbytes / len(launches)), "kernel_ms_per_forward": round(ms, 3)}
 
-    # ---- dominant: fused 1x1 -> depthwise.  args = (dtype, x, ld_x, off_x, Cin, gamma, beta, eps, shift, scale, ln_ld,
+    cands = []
+    # fused 1x1 -> depthwise.  args = (dtype, x, ld_x, off_x, Cin, gamma, beta, eps, shift, scale, ln_ld,
     #      w_pw, Cdw, w_dw, b_dw, silu, out_dw, ld_dw, off_dw, Cz, out_z, ld_z, off_z, B, H, W, stream)
     pw = [(n, a) for n, a in trace if n == "fd_pw_dw3x3"]
-    pw_bytes = sum(1.0 * a[23] * a[24] * a[25] * (a[4] + a[12] + a[19]) * esz for _, a in pw)   # in + dw out + z out, once
-    res = hbm_entry("pwdw_kernel", pw, pw_bytes, "pwdw_hbm_bytes_per_launch")
-    res.update({"all_kernels_ms_per_forward": round(all_ms, 3), "batch": B, "others": [],
-                "note": "every kernel replayed ALONE on the launch stream at the sub-batch the timed region launches (8): the "
-                        "figures a kernel reaches when it owns the chip.  In the timed region two sub-batches run on two "
-                        "streams, so rocprofv3's per-kernel durations of the default command include co-scheduling; the "
-                        "summary of `FOUNDDIFF_STREAMS=1 python bench.py --batch 8` (profiles/) is the one whose averages "
-                        "agree with avg_launch_us"})
-    # ---- runner-up symbols: the two instantiations of the halo 3x3 kernel separately (they are separate symbols in the
-    # rocprof summary: <128,8> serves Cout > 64, <64,16> / <64,8> Cout <= 64)
+    if pw:
+        pw_bytes = sum(1.0 * a[23] * a[24] * a[25] * (a[4] + a[12] + a[19]) * esz for _, a in pw)   # in + dw out + z out, once
+        cands.append(hbm_entry("pwdw_kernel", pw, pw_bytes, "pwdw_hbm_bytes_per_launch"))
+    # ... with the Gram: args = (dtype, x, ld_x, off_x, Cin, gamma, beta, eps, shift, scale, ln_ld, w_pw, w_dw, out_v, ld_v,
+    #      off_v, partial, B, H, W, stream): reads 64 channels, writes v (64 channels) + one Gram partial per workgroup
+    pg = [(n, a) for n, a in trace if n == "fd_pw_dw3x3_gram"]
+    if pg:
+        pg_bytes = sum(1.0 * a[17] * a[18] * a[19] * (64 + 64) * esz + 1.0 * a[17] * 2 * lib.fd_pw_dw3x3_gram_nblk(a[18], a[19]) * 1088 * 4
+                       for _, a in pg)
+        cands.append(hbm_entry("pwdw_gram_kernel", pg, pg_bytes, "pwdw_gram_hbm_bytes_per_launch"))
+    # the two instantiations of the halo 3x3 kernel separately (separate symbols in the rocprof summary: <128,8> serves
+    # Cout > 64, <64,16> / <64,8> Cout <= 64)
     halo = [(n, a) for n, a in trace if n == "fd_conv2d" and lib.fd_conv_kernel_id(a[0]) == 11]
     for name, sel in (("conv3x3_halo_kernel<128,8,false>", lambda q: q.Cout > 64), ("conv3x3_halo_kernel<64,16|8,false>", lambda q: q.Cout <= 64)):
         part = [(n, a) for n, a in halo if sel(a[0]._obj)]
@@ -127,17 +179,26 @@ def roofline_leg(dif, x, noise):
         fl = sum(conv_flops(a[0]._obj) for _, a in part)
         ms = _time_launches(lib, part)
         tf = fl / (ms * 1e-3) / 1e12
-        res["others"].append({"bound": "mfma", "kernel": name, "achieved": round(tf, 1),
-                              "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4),
-                              "traffic": traffic.get("conv3x3_halo_hbm_bytes_per_launch"),
-                              "launches_per_forward": len(part), "avg_launch_us": round(ms * 1e3 / len(part), 2),
-                              "alg_gflop_per_launch": round(fl / 1e9 / len(part), 2),
-                              "kernel_ms_per_forward": round(ms, 3)})
+        cands.append({"bound": "mfma", "kernel": name, "achieved": round(tf, 1),
+                      "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4),
+                      "traffic": traffic.get("conv3x3_halo_hbm_bytes_per_launch"),
+                      "launches_per_forward": len(part), "avg_launch_us": round(ms * 1e3 / len(part), 2),
+                      "alg_gflop_per_launch": round(fl / 1e9 / len(part), 2),
+                      "kernel_ms_per_forward": round(ms, 3)})
     # depthwise 3x3 alone: args = (dtype, in, ld_in, off_in, w, bias, silu, out, ld_out, off_out, B, H, W, C, stream)
     dws = [(n, a) for n, a in trace if n == "fd_dwconv3x3"]
     if dws:
         dw_bytes = sum(2.0 * a[10] * a[11] * a[12] * a[13] * esz for _, a in dws)
-        res["others"].append(hbm_entry("dwconv3x3_bf16_kernel", dws, dw_bytes, "dwconv3x3_bf16_hbm_bytes_per_launch"))
+        cands.append(hbm_entry("dwconv3x3_bf16_kernel", dws, dw_bytes, "dwconv3x3_bf16_hbm_bytes_per_launch"))
+    cands.sort(key=lambda c: -c["kernel_ms_per_forward"])
+    res = cands[0]
+    res.update({"all_kernels_ms_per_forward": round(all_ms, 3), "batch": B, "others": cands[1:],
+                "forward": forward_bounds(eng, x.shape[2], x.shape[3], traffic, t_measured_ms if t_measured_ms else all_ms / B),
+                "note": "every kernel replayed ALONE on the launch stream at the sub-batch the timed region launches (8): the "
+                        "figures a kernel reaches when it owns the chip.  In the timed region two sub-batches run on two "
+                        "streams, so rocprofv3's per-kernel durations of the default command include co-scheduling; the "
+                        "summary of `FOUNDDIFF_STREAMS=1 python bench.py --batch 8` (profiles/) is the one whose averages "
+                        "agree with avg_launch_us"})
     return res
 
 
@@ -164,12 +225,13 @@ def cpu_baseline_leg(w, x_in01, noise, n_forwards=3):
         per_fwd.append(time.time() - ts)
     fwd = sum(per_fwd) / len(per_fwd)
     per_slice = (t1 - t0) + S_DDIM * fwd
-    # why 32 threads: one more forward each at other thread counts (s per forward), reported, not used for `value`
+    # why 32 threads: one more forward each at other TORCH intra-op thread counts (s per forward), reported, not used
+    # for `value`.  Only torch's pool changes: the C/OpenMP scan oracle's runtime is initialised by then and keeps the
+    # thread count it started with (nthr) -- the sweep is labelled accordingly.
     sweep = {str(nthr): round(fwd, 2)}
     for n in (8, 16, 64, 128):
         if n != nthr and n <= os.cpu_count():
             torch.set_num_threads(n)
-            os.environ["OMP_NUM_THREADS"] = str(n)
             ts = time.time()
             orc.unet(xt, xi, torch.full((1,), 499, dtype=torch.long))
             sweep[str(n)] = round(time.time() - ts, 2)
@@ -177,7 +239,7 @@ def cpu_baseline_leg(w, x_in01, noise, n_forwards=3):
     return {"value": round(1.0 / per_slice, 6), "unit": "slices/s", "cores": nthr, "kind": "port",
             "sample": f"1 slice: DA-CLIP encode ({t1 - t0:.1f}s) + {len(per_fwd)} of {S_DDIM} UNet forwards "
                       f"({', '.join('%.1f' % v for v in per_fwd)} s) at 512x512 fp32, extrapolated to {S_DDIM}",
-            "seconds_per_forward_by_threads": sweep, "host_cores": os.cpu_count()}
+            "seconds_per_forward_by_torch_threads": sweep, "host_cores": os.cpu_count()}
 
 
 def fp32_parity_leg(dev, x, noise, steps=1):
@@ -197,6 +259,50 @@ def fp32_parity_leg(dev, x, noise, steps=1):
     return {"value": round(B / dt, 4), "unit": "slices/s", "ms_per_step": round(dt * 1e3, 2),
             "ms_per_unet_forward_per_slice": round(dt / S_DDIM / B * 1e3, 3), "steps": steps, "batch": B,
             "dtype": "f32 storage, exact-f32 MFMA"}
+
+
+def fp8_leg(dev, x, noise, ddim_steps=25):
+    """BASELINE configs[4] geometry outside the timed region: e4m3 weights + e4m3 halo on the fp8 MFMA in the eligible
+    3x3 convolutions, 25-step DDIM, same batch -- so that the driver's record carries the number."""
+    dif, _ = build_model(dev, steps=ddim_steps, precision="fp8")
+    B = x.shape[0]
+    dif.sample([x], batch_size=B, noise=noise)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dif.sample([x], batch_size=B, noise=noise)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    del dif
+    torch.cuda.empty_cache()
+    return {"value": round(B / dt, 4), "unit": "slices/s", "ddim_steps": ddim_steps, "batch": B,
+            "ms_per_unet_forward_per_slice": round(dt / ddim_steps / B * 1e3, 3),
+            "dtype": "bf16 activations, e4m3 weights (fp8 MFMA) in the 3x3 convs; last step's levels 0-1 on the bf16 engine",
+            "workload": "BASELINE configs[4] geometry: 512x512, 25-step DDIM (single GPU, synthetic mixed-dose phantoms)"}
+
+
+def ancestral_leg(dev, x, chunks=2):
+    """BASELINE configs[3]'s sampler (1000-step ancestral p_sample_loop, per-slice keyed step noise) outside the timed
+    region: `chunks` replays of the captured step chunk + the tail step are TIMED, the 1000-step figure is an
+    EXTRAPOLATION from them (a full volume takes ~30 s per 16 slices; `--sampler ancestral` times it for real)."""
+    dif, _ = build_model(dev, steps=1000)
+    B = x.shape[0]
+    seeds = torch.arange(B, dtype=torch.int64) + 5000
+    dif._anc_max_chunks = 1
+    dif.sample([x], batch_size=B, slice_seeds=seeds)                    # warm-up: graph capture
+    dif._anc_max_chunks = chunks
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dif.sample([x], batch_size=B, slice_seeds=seeds)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    nsteps = dif._anc_steps_run
+    del dif
+    torch.cuda.empty_cache()
+    per_step = dt / nsteps
+    return {"value": round(B / (per_step * 1000), 5), "unit": "slices/s", "extrapolated": True,
+            "timed": f"{nsteps} of 1000 steps ({chunks} graph chunks + the tail step) incl. the DA-CLIP encode, batch {B}",
+            "ms_per_step_per_slice": round(per_step / B * 1e3, 4),
+            "workload": "BASELINE configs[3] sampler: 512x512, 1000-step ancestral, keyed per-slice step noise (one GPU's share)"}
 
 
 def self_launch(a):
@@ -228,7 +334,13 @@ def main():
                     help="fp8: BASELINE configs[4] -- e4m3 weights on the fp8 MFMA for the 3x3 convs; a separate "
                          "variant, never the headline")
     ap.add_argument("--ddim-steps", type=int, default=S_DDIM, help="25 with --precision fp8 reproduces configs[4]")
+    ap.add_argument("--sampler", default="ddim", choices=["ddim", "ancestral"],
+                    help="ancestral: BASELINE configs[3]'s 1000-step p_sample_loop (keyed per-slice step noise) as the timed "
+                         "workload -- ~30 s per step of 16 slices; a separate variant, never the headline")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the fp8 (configs[4]) and ancestral (configs[3]) legs")
     a = ap.parse_args()
+    if a.sampler == "ancestral":
+        a.ddim_steps = 1000
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -254,8 +366,10 @@ def main():
     noise = torch.stack([torch.randn(1, SIZE, SIZE, generator=torch.Generator().manual_seed(1000 + i))
                          for i in range(lo, hi)]).to(dev)
 
+    seeds = torch.arange(lo, hi, dtype=torch.int64) + 1000      # ancestral: step noise keyed by the GLOBAL slice index
+
     def step():
-        out = dif.sample([x], batch_size=B, noise=noise)[-1]
+        out = dif.sample([x], batch_size=B, noise=noise, slice_seeds=seeds)[-1]
         return parallel.gather_volume(out, world)
 
     for _ in range(a.warmup):
@@ -296,11 +410,18 @@ def main():
             "ms_per_unet_forward_per_slice": round(dt / a.steps / a.ddim_steps / B * 1e3, 3),
             "alg_tflops_sustained": round(ALG_GFLOP_PER_FORWARD * a.ddim_steps * slices / dt / 1e3, 1),
         }
-        if a.precision != "bf16" or a.ddim_steps != S_DDIM:
+        if a.sampler == "ancestral":
+            res["metric"] = "denoised CT slices/sec (512x512, 1000-step ancestral p_sample_loop)"
+            res["config"]["workload"] = ("BASELINE configs[3] sampler: 512x512 slices, 1000-step ancestral p_sample, step noise "
+                                         "keyed per slice, full FoundDiff UNet + DA-CLIP RN50 cond, bf16")
+        elif a.precision != "bf16" or a.ddim_steps != S_DDIM:
             res["config"]["workload"] = (f"BASELINE configs[4] geometry: 512x512 slice, {a.ddim_steps}-step DDIM, full FoundDiff "
                                          f"UNet + DA-CLIP RN50 cond, precision {a.precision}")
         if not a.no_roofline and a.precision == "bf16":
-            res["roofline"] = roofline_leg(dif, x, noise)
+            res["roofline"] = roofline_leg(dif, x, noise, t_measured_ms=res["ms_per_unet_forward_per_slice"])
+        if world == 1 and not a.no_extra_legs and a.precision == "bf16" and a.sampler == "ddim":
+            res["fp8_25step"] = fp8_leg(dev, x, noise)
+            res["ancestral_config3"] = ancestral_leg(dev, x)
         if world == 1 and not a.no_fp32_leg and a.precision == "bf16":
             res["fp32_parity_mode"] = fp32_parity_leg(dev, x, noise)
         if world == 1 and not a.no_cpu_baseline:

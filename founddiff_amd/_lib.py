@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libfounddiff_hip.so")
 
 FD_F32, FD_BF16 = 0, 1
 FD_OPT_LOW_LATENCY = 0x100
-EPI_NONE, EPI_SILU_SPLIT, EPI_RELU, EPI_GATE_RES, EPI_RES_RELU, EPI_GNSILU_ADD = range(6)
+EPI_NONE, EPI_SILU_SPLIT, EPI_RELU, EPI_GATE_RES, EPI_RES_RELU, EPI_GNSILU_ADD, EPI_GNSILU_ADD_FINAL = range(7)
 ACT_NONE, ACT_SILU, ACT_GELU, ACT_RELU = range(4)
 PRO_NONE, PRO_LN_MOD, PRO_LN_GATE = range(3)
 
@@ -40,7 +40,9 @@ class ConvParams(C.Structure):
         ("prologue", i32), ("ln_eps", f32),
         ("ln_gamma", vp), ("ln_beta", vp), ("ln_shift", vp), ("ln_scale", vp), ("ln_ld", i32),
         ("ln_z", vp), ("ln_ldz", i32), ("ln_offz", i32),
-        ("weight_f8", vp), ("w_scale", vp), ("act_scale", f32), ("f32_split", i32),
+        ("weight_f8", vp), ("w_scale", vp), ("act_scale", f32), ("f32_split", i32), ("debug", i32),
+        ("fin_w", vp), ("fin_b", f32), ("fin_out", vp), ("fin_mode", i32), ("fin_last", i32), ("fin_img", vp),
+        ("fin_xin", vp), ("fin_alpha", f32),
     ]
 
 
@@ -64,6 +66,9 @@ SIGNATURES = {
     "fd_pw_dw3x3_gram_ok": (i32, [i32, i32, i32, i32]),
     "fd_pw_dw3x3_gram_nblk": (i32, [i32, i32]),
     "fd_pw_dw3x3_gram": (i32, [i32, vp, i32, i32, i32, vp, vp, f32, vp, vp, i32, vp, vp, vp, i32, i32, vp, i32, i32, i32, vp]),
+    "fd_dwconv_gram_ok": (i32, [i32, i32, i32, i32]),
+    "fd_dwconv_gram_nblk": (i32, [i32, i32]),
+    "fd_dwconv_gram": (i32, [i32, vp, i32, i32, vp, vp, i32, i32, i32, vp]),
     "fd_scan_ws_floats": (i64, [i32, i32, i32, i32, i32]),
     "fd_selective_scan": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "fd_selective_scan_fuses_xproj": (i32, [i32, i32, i32, i32]),

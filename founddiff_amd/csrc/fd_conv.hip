@@ -668,10 +668,12 @@ extern "C" int fd_conv2d(const fd_conv_params *pp, void *stream) {
     FD_REQUIRE(p.B > 0 && p.H > 0 && p.W > 0 && p.OH > 0 && p.OW > 0 && p.Cout > 0, "fd_conv2d: bad sizes");
     FD_REQUIRE(p.KH > 0 && p.KW > 0 && p.stride > 0, "fd_conv2d: bad kernel/stride");
     FD_REQUIRE(p.ndir == 1 || p.ndir == 4, "fd_conv2d: ndir must be 1 or 4");
-    FD_REQUIRE(p.epilogue >= FD_EPI_NONE && p.epilogue <= FD_EPI_GNSILU_ADD, "fd_conv2d: bad epilogue %d", p.epilogue);
+    FD_REQUIRE(p.epilogue >= FD_EPI_NONE && p.epilogue <= FD_EPI_GNSILU_ADD_FINAL, "fd_conv2d: bad epilogue %d", p.epilogue);
+    FD_REQUIRE(p.epilogue != FD_EPI_GNSILU_ADD_FINAL || fd_conv_prologue_ok(pp),
+               "fd_conv2d: GNSILU_ADD_FINAL runs on the streaming row-GEMM only (bf16, 1x1, >= 16384 px, fin_* set)");
     if (p.epilogue == FD_EPI_GATE_RES) FD_REQUIRE(p.res && p.gate, "fd_conv2d: GATE_RES needs res and gate");
     if (p.epilogue == FD_EPI_RES_RELU) FD_REQUIRE(p.res, "fd_conv2d: RES_RELU needs res");
-    if (p.epilogue == FD_EPI_GNSILU_ADD)
+    if (p.epilogue == FD_EPI_GNSILU_ADD || p.epilogue == FD_EPI_GNSILU_ADD_FINAL)
         FD_REQUIRE(p.h && p.gn_mean_rstd && p.gn_gamma && p.gn_beta && p.gn_groups > 0 && p.Cout % p.gn_groups == 0,
                    "fd_conv2d: GNSILU_ADD needs h, statistics, affine and groups | Cout");
     if (fd_conv_prologue_ok(pp)) {

@@ -157,6 +157,9 @@ __global__ __launch_bounds__(NT) void gemm_rows_kernel(const fd_conv_params p, i
             }
         }
         const int64_t m0 = (int64_t)wt * (16 * S) + fr;
+        float fdot[S];                       // GNSILU_ADD_FINAL: this lane's share of the final 1x1 (Cout -> 1)
+#pragma unroll
+        for (int s = 0; s < S; ++s) fdot[s] = 0.f;
 #pragma unroll 1
         for (int ng = 0; ng < N / 32; ++ng) {
             f32x4 acc[2][S];
@@ -184,7 +187,7 @@ __global__ __launch_bounds__(NT) void gemm_rows_kernel(const fd_conv_params p, i
                 for (int e = 0; e < 8; ++e) bias[e] = 0.f;
             }
             if (EPI == FD_EPI_GATE_RES) load8(p.gate + (int64_t)b * p.gate_ld + n0, ev0);
-            if (EPI == FD_EPI_GNSILU_ADD) {
+            if (EPI == FD_EPI_GNSILU_ADD || EPI == FD_EPI_GNSILU_ADD_FINAL) {
                 load8(p.gn_gamma + n0, ev0);
                 load8(p.gn_beta + n0, ev1);
                 // channels-per-group is a multiple of 8 (checked on the host): one group per vector
@@ -219,13 +222,41 @@ __global__ __launch_bounds__(NT) void gemm_rows_kernel(const fd_conv_params p, i
 #pragma unroll
                         for (int e = 0; e < 8; ++e) val[e] = fmaxf(val[e] + rs[e], 0.f);
                     }
-                } else if (EPI == FD_EPI_GNSILU_ADD) {
+                } else if (EPI == FD_EPI_GNSILU_ADD || EPI == FD_EPI_GNSILU_ADD_FINAL) {
                     float hv[8];
                     load8(hp + m * N + n0, hv);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) val[e] += fd_silu((hv[e] - ev2[e]) * ev3[e] * ev0[e] + ev1[e]);
                 }
-                store8(outp + m * p.ldo + n0, val);
+                if (EPI == FD_EPI_GNSILU_ADD_FINAL) {
+                    // the block output is rounded to the storage type before final_conv reads it in the unfused
+                    // sequence: same rounding point here
+                    float fw[8];
+                    load8(p.fin_w + n0, fw);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) fdot[s] += (float)(bf16)val[e] * fw[e];
+                } else {
+                    store8(outp + m * p.ldo + n0, val);
+                }
+            }
+        }
+        if (EPI == FD_EPI_GNSILU_ADD_FINAL) {
+            // a pixel's Cout channels sit in the 4 lanes fr, fr + 16, fr + 32, fr + 48: two xor-shuffles
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                float o = fdot[s];
+                o += __shfl_xor(o, 16, 64);
+                o += __shfl_xor(o, 32, 64);
+                o += p.fin_b;
+                const int64_t m = m0 + 16 * s;
+                if (fg == 0 && m < hw) {
+                    const int64_t j = (int64_t)b * hw + m;
+                    p.fin_out[j] = o;
+                    if (p.fin_mode == 1) {
+                        const float pr = fminf(fmaxf(o, -1.f), 1.f);
+                        p.fin_img[j] = p.fin_last ? fminf(fmaxf(p.fin_xin[j] - pr, -1.f), 1.f) : p.fin_img[j] - p.fin_alpha * pr;
+                    }
+                }
             }
         }
     }
@@ -272,7 +303,9 @@ extern "C" int fd_conv_prologue_ok(const fd_conv_params *pp) {
     if (p.epilogue == FD_EPI_GATE_RES && (p.gate_ld % 4 || ((uintptr_t)p.gate & 15))) return 0;
     if (p.epilogue == FD_EPI_SILU_SPLIT && p.epi_split % 8) return 0;
     if (p.bias && ((uintptr_t)p.bias & 15)) return 0;
-    if (p.epilogue == FD_EPI_GNSILU_ADD && (p.gn_groups <= 0 || (p.Cout / p.gn_groups) % 8)) return 0;
+    if ((p.epilogue == FD_EPI_GNSILU_ADD || p.epilogue == FD_EPI_GNSILU_ADD_FINAL) && (p.gn_groups <= 0 || (p.Cout / p.gn_groups) % 8)) return 0;
+    if (p.epilogue == FD_EPI_GNSILU_ADD_FINAL && (!p.fin_w || !p.fin_out || ((uintptr_t)p.fin_w & 15) ||
+                                                  (p.fin_mode == 1 && (!p.fin_img || !p.fin_xin)))) return 0;
     if (p.prologue == FD_PRO_LN_MOD && p.epilogue != FD_EPI_NONE && p.epilogue != FD_EPI_SILU_SPLIT) return 0;
     if (p.prologue == FD_PRO_LN_GATE && p.epilogue != FD_EPI_GATE_RES) return 0;
     if (p.prologue != FD_PRO_NONE) {
@@ -322,6 +355,7 @@ int fd_gemm_rows_launch(const fd_conv_params &p, hipStream_t s) {
         case FD_EPI_GATE_RES: FD_GR_K(0, FD_EPI_GATE_RES) break;
         case FD_EPI_RES_RELU: FD_GR_K(0, FD_EPI_RES_RELU) break;
         case FD_EPI_GNSILU_ADD: FD_GR_K(0, FD_EPI_GNSILU_ADD) break;
+        case FD_EPI_GNSILU_ADD_FINAL: FD_GR_K(0, FD_EPI_GNSILU_ADD_FINAL) break;
         default: return -1;
         }
     }

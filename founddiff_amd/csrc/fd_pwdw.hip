@@ -580,6 +580,191 @@ __global__ __launch_bounds__(256, 3) void pwdw_gram_kernel(const PwGramParams p)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// qkv_dwconv -> L2 norms + q k^T for the WIDER Mamba blocks (C >= 128: the 1x1 qkv stays a separate GEMM there), in
+// one pass over q and k: the depthwise outputs of q and k go straight into the Gram (same tile images, transposing
+// reads and MFMAs as pwdw_gram_kernel) and never reach HBM; v keeps the plain depthwise kernel.  Unfused, q and k
+// were written by dwconv3x3_bf16_kernel and read back by gram_kernel: 4C of the 9C channel passes of this branch.
+// A workgroup owns (tile group, pair of heads = 64 q channels + the matching 64 k channels):
+//   q halo (10 x 18 x 64 ch) -> LDS; the k halo's global loads are issued right away (registers);
+//   depthwise(q) -> registers -> Q tile;   k halo -> LDS (the q halo is dead);   depthwise(k) -> registers ->
+//   K tile written OVER the halo;   16 MFMAs per wave;  next tile.   39 KB of LDS: 4 workgroups per CU.
+struct DwGramParams {
+    const bf16 *qkv; int ld;          // [B,H,W,ld]: q at channel 0, k at channel C
+    int C;
+    const uint32_t *w_dw;             // [5][3C] tap-pair words (fd_pw_dw3x3's layout)
+    float *part; int nblk;            // [B][C/32 heads][nblk][1024 + 64]
+    int H, W, tpw, ntiles;
+};
+
+__global__ __launch_bounds__(256, 3) void dwconv_gram_kernel(const DwGramParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char hs[TS_B];       // input halo [180][64] bf16, later the K tile
+    __shared__ __attribute__((aligned(16))) unsigned char qs[128 * 128];  // Q tile [128 px][64 ch]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int tiles_x = p.W / PT_W;
+    const int hp2 = blockIdx.y;                         // pair of heads: q channels [64 hp2, +64), k channels C + the same
+    const int64_t img = blockIdx.z;
+    const bf16 *base = p.qkv + img * p.H * p.W * p.ld;
+    const int cv = tid & 7, px = (tid >> 3) & 15, rh = tid >> 7;
+    const int C3 = 3 * p.C;
+    // tap-pair words of the 64 q and the 64 k channels, staged once: [2][5][64] words
+    __shared__ __attribute__((aligned(16))) uint32_t sWd[2 * 5 * 64];
+    for (int i = tid; i < 2 * 5 * 64; i += 256) {
+        const int qk = i / 320, t = (i % 320) / 64, c = i % 64;
+        sWd[i] = p.w_dw[t * C3 + qk * p.C + 64 * hp2 + c];
+    }
+    int toff[6][3];
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) toff[r][dx] = ts_off((4 * rh + r) * PH_X + px + dx, cv);
+    const int hd = wave >> 1, mb = wave & 1;
+    const int tq = (lane >> 2) & 3, tp = lane & 3;
+    f32x4 gacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, gnq = {0.f, 0.f, 0.f, 0.f}, gnk = {0.f, 0.f, 0.f, 0.f};
+    constexpr int NLD = (PHP * 8 + 255) / 256;          // 6 halo chunks per thread (180 px x 8)
+
+    // one depthwise pass over the halo image in hs: this thread's 4 rows x 8 channels, packed bf16
+    auto dw = [&](int qk, u32x4 (&pk)[4]) {
+        uint32_t wt[5][8];
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            const u32x4 a0 = *(const u32x4 *)(sWd + (qk * 5 + t) * 64 + cv * 8), a1 = *(const u32x4 *)(sWd + (qk * 5 + t) * 64 + cv * 8 + 4);
+            wt[t][0] = a0.x; wt[t][1] = a0.y; wt[t][2] = a0.z; wt[t][3] = a0.w; wt[t][4] = a1.x; wt[t][5] = a1.y; wt[t][6] = a1.z; wt[t][7] = a1.w;
+        }
+        uint32_t win[3][3][4];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const u32x4 t4 = *(const u32x4 *)(hs + toff[s][dx]);
+                win[s][dx][0] = t4.x; win[s][dx][1] = t4.y; win[s][dx][2] = t4.z; win[s][dx][3] = t4.w;
+            }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const u32x4 t4 = *(const u32x4 *)(hs + toff[rr + 2][dx]);
+                uint32_t *wr_ = win[(rr + 2) % 3][dx];
+                wr_[0] = t4.x; wr_[1] = t4.y; wr_[2] = t4.z; wr_[3] = t4.w;
+            }
+            float acc[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int pr = 0; pr < 4; ++pr)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t xa = pr < 3 ? win[rr % 3][pr][j] : win[(rr + 2) % 3][0][j];
+                    const uint32_t xb = pr < 3 ? win[(rr + 1) % 3][pr][j] : win[(rr + 2) % 3][1][j];
+                    const uint32_t lo = __builtin_amdgcn_perm(xb, xa, 0x05040100);
+                    const uint32_t hi = __builtin_amdgcn_perm(xb, xa, 0x07060302);
+                    acc[2 * j] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(pd_bf16x2, lo),
+                        __builtin_bit_cast(pd_bf16x2, wt[pr][2 * j]), acc[2 * j], false);
+                    acc[2 * j + 1] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(pd_bf16x2, hi),
+                        __builtin_bit_cast(pd_bf16x2, wt[pr][2 * j + 1]), acc[2 * j + 1], false);
+                }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const pd_bf16x2 xv = __builtin_bit_cast(pd_bf16x2, win[(rr + 2) % 3][2][j]);
+                acc[2 * j] = __builtin_amdgcn_fdot2_f32_bf16(xv, __builtin_bit_cast(pd_bf16x2, wt[4][2 * j]), acc[2 * j], false);
+                acc[2 * j + 1] = __builtin_amdgcn_fdot2_f32_bf16(xv, __builtin_bit_cast(pd_bf16x2, wt[4][2 * j + 1]), acc[2 * j + 1], false);
+            }
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16)acc[e];
+            pk[rr] = __builtin_bit_cast(u32x4, o);
+        }
+    };
+
+    const int tile0 = blockIdx.x * p.tpw;
+    for (int tt = 0; tt < p.tpw; ++tt) {
+        const int tile = tile0 + tt;
+        if (tile >= p.ntiles) break;                    // workgroup-uniform
+        const int ty0 = (tile / tiles_x) * PT_H, tx0 = (tile % tiles_x) * PT_W;
+        int tl = tid;
+        asm volatile("" : "+v"(tl));                    // keep the halo geometry inside the loop (see pwdw_gram_kernel)
+        u32x4 rq[NLD], rk[NLD];
+        uint32_t okm = 0;
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int idx = tl + k * 256;
+            const int hp = min(idx >> 3, PHP - 1), v = idx & 7;
+            const int hy = div18(hp), hx = hp - hy * PH_X;
+            const int yy = ty0 + hy - 1, xx = tx0 + hx - 1;
+            if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) okm |= 1u << k;
+            const int yc = min(max(yy, 0), p.H - 1), xc = min(max(xx, 0), p.W - 1);
+            const bf16 *src = base + (__umul24(__umul24(yc, p.W) + xc, p.ld) + 64 * hp2 + v * 8);
+            rq[k] = *(const u32x4 *)src;
+            rk[k] = *(const u32x4 *)(src + p.C);
+        }
+        auto halo_store = [&](const u32x4 (&r)[NLD]) {
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) {
+                const int idx = tl + k * 256, hp = idx >> 3;
+                const u32x4 z4 = {0, 0, 0, 0};
+                if (hp < PHP) *(u32x4 *)(hs + ts_off(hp, idx & 7)) = ((okm >> k) & 1) ? r[k] : z4;
+            }
+        };
+        u32x4 pk[4];
+        halo_store(rq);
+        lds_barrier();
+        dw(0, pk);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) *(u32x4 *)(qs + gt_off((4 * rh + rr) * PT_W + px, cv)) = pk[rr];
+        lds_barrier();                                  // every read of the q halo is done
+        halo_store(rk);
+        lds_barrier();
+        dw(1, pk);
+        lds_barrier();                                  // every read of the k halo is done: the K tile goes over it
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) *(u32x4 *)(hs + gt_off((4 * rh + rr) * PT_W + px, cv)) = pk[rr];
+        lds_barrier();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            pd_s16x4 a[2], b0[2], b1[2];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int pix = 32 * ks + 8 * fg + 4 * hf + tq;
+                const int rowb = pix * 128, sw = gt_swz(pix), sub = 8 * (tp & 1);
+                const int cq = hd * 4 + mb * 2 + (tp >> 1), ck0 = hd * 4 + (tp >> 1), ck1 = ck0 + 2;
+                a[hf] = lds_tr16(qs + rowb + ((cq ^ sw) << 4) + sub);
+                b0[hf] = lds_tr16(hs + rowb + ((ck0 ^ sw) << 4) + sub);
+                b1[hf] = lds_tr16(hs + rowb + ((ck1 ^ sw) << 4) + sub);
+            }
+            const bf16x8 A = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a[0], a[1], 0, 1, 2, 3, 4, 5, 6, 7));
+            const bf16x8 B0 = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0[0], b0[1], 0, 1, 2, 3, 4, 5, 6, 7));
+            const bf16x8 B1 = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b1[0], b1[1], 0, 1, 2, 3, 4, 5, 6, 7));
+            gacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B0, gacc[0], 0, 0, 0);
+            gacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B1, gacc[1], 0, 0, 0);
+            gnq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, A, gnq, 0, 0, 0);
+            const bf16x8 Bm = mb ? B1 : B0;
+            gnk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bm, Bm, gnk, 0, 0, 0);
+        }
+        lds_barrier();                                  // the next tile's halo rewrites hs
+    }
+    float *sp = (float *)hs + hd * (1024 + 64);
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sp[(mb * 16 + 4 * fg + e) * 32 + nb * 16 + fr] = gacc[nb][e];
+    if ((fr >> 2) == fg) {
+        const int e = fr & 3;
+        const float nq = e == 0 ? gnq[0] : (e == 1 ? gnq[1] : (e == 2 ? gnq[2] : gnq[3]));
+        const float nk = e == 0 ? gnk[0] : (e == 1 ? gnk[1] : (e == 2 ? gnk[2] : gnk[3]));
+        sp[1024 + mb * 16 + fr] = nq;
+        sp[1024 + 32 + mb * 16 + fr] = nk;
+    }
+    lds_barrier();
+    const int heads = p.C / 32;
+    for (int i = tid; i < 2 * (1024 + 64) / 4; i += 256) {
+        const int h2 = i / ((1024 + 64) / 4), r = i - h2 * ((1024 + 64) / 4);
+        float *out = p.part + ((img * heads + 2 * hp2 + h2) * p.nblk + blockIdx.x) * (1024 + 64);
+        *(f32x4 *)(out + 4 * r) = *(const f32x4 *)((const float *)hs + h2 * (1024 + 64) + 4 * r);
+    }
+}
+
 }  // namespace
 
 extern "C" int fd_pw_dw3x3_ok(int dtype, int Cin, int Cdw, int Cz, int H, int W) {
@@ -650,5 +835,32 @@ extern "C" int fd_pw_dw3x3_gram(int dtype, const void *x, int ld_x, int off_x, i
     dim3 grid(p.nblk, B), block(256);
     hipLaunchKernelGGL(pwdw_gram_kernel, grid, block, 0, (hipStream_t)stream, p);
     FD_LAUNCH_OK("fd_pw_dw3x3_gram");
+    return FD_OK;
+}
+
+// ---- qkv_dwconv + Gram for C >= 128 (dwconv_gram_kernel): q, k of a [B,H,W,ld] qkv tensor -> Gram partials only
+static int dwgram_tpw(int ntiles) { return ntiles >= 256 ? 4 : (ntiles >= 64 ? 2 : 1); }
+
+extern "C" int fd_dwconv_gram_ok(int dtype, int C, int H, int W) {
+    static const bool off = getenv("FD_NO_DWGRAM") != nullptr;         // development switch
+    return !off && dtype == FD_BF16 && C % 64 == 0 && C >= 64 && H % PT_H == 0 && W % PT_W == 0 &&
+           (int64_t)H * W * 3 * C < (1ll << 31);
+}
+
+extern "C" int fd_dwconv_gram_nblk(int H, int W) {
+    const int ntiles = (H / PT_H) * (W / PT_W), tpw = dwgram_tpw(ntiles);
+    return (ntiles + tpw - 1) / tpw;
+}
+
+extern "C" int fd_dwconv_gram(int dtype, const void *qkv, int ld, int C, const uint32_t *w_dw, float *partial, int B, int H,
+                              int W, void *stream) {
+    FD_REQUIRE(fd_dwconv_gram_ok(dtype, C, H, W) || getenv("FD_NO_DWGRAM"), "fd_dwconv_gram: unsupported shape (bf16, C %% 64, H %% 8, W %% 16): C=%d H=%d W=%d", C, H, W);
+    FD_REQUIRE(qkv && w_dw && partial && ld % 8 == 0 && ld >= 2 * C && ((uintptr_t)w_dw & 15) == 0, "fd_dwconv_gram: bad args");
+    DwGramParams p;
+    p.qkv = (const bf16 *)qkv; p.ld = ld; p.C = C; p.w_dw = w_dw; p.part = partial;
+    p.H = H; p.W = W; p.ntiles = (H / PT_H) * (W / PT_W); p.tpw = dwgram_tpw(p.ntiles); p.nblk = fd_dwconv_gram_nblk(H, W);
+    dim3 grid(p.nblk, C / 64, B), block(256);
+    hipLaunchKernelGGL(dwconv_gram_kernel, grid, block, 0, (hipStream_t)stream, p);
+    FD_LAUNCH_OK("fd_dwconv_gram");
     return FD_OK;
 }

@@ -7,6 +7,7 @@ Layout: activations NHWC; `mode` 'fp32' (parity: fp32 storage, exact-f32 MFMA) o
 (bf16 storage + bf16 MFMA, fp32 accumulation/statistics/scan state).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -170,6 +171,7 @@ class DAEngine:
         )
         # tap weights of the two depthwise convs in the operand layout of the fused 1x1 -> 3x3 kernel
         d["dw_wm"], d["qdw_wm"] = self._dw_masked(d["dw_w"]), self._dw_masked(d["qdw_w"])
+        d["qdw_w_v"] = d["qdw_w"][:, 2 * C_:].contiguous()          # the v third alone (fd_dwconv_gram serves q and k)
         assert d["heads"] * 32 == C_, "TransposedAttention heads must be C/32 (src/DADiff.py:468)"
         d["adaln_w"] = s["adaLN_modulation.1.weight"].detach().float()
         d["adaln_b"] = s["adaLN_modulation.1.bias"].detach().float()
@@ -212,6 +214,7 @@ class DAEngine:
         if fw.shape[0] != 1:
             raise NotImplementedError("final_conv with out_dim != 1 (learned_variance) is not built")
         self.final_w, self.final_b = self._f(fw.reshape(-1)), self._f(sd["final_conv.bias"])
+        self.final_b_host = float(sd["final_conv.bias"].detach().float().reshape(-1)[0])
         # all adaLN / local projections concatenated: ONE matvec per step / per slice
         mambas = [d["mamba"] for d in self.downs] + [self.mid_mamba] + [u["mamba"] for u in self.ups]
         off_m = off_l = 0
@@ -284,7 +287,7 @@ class DAEngine:
              epi=L.EPI_NONE, split=0, res=None, ld_res=0, off_res=0, gate=None, gate_ld=0, h=None,
              gn=None, gamma=None, beta=None, groups=8, stats=None, OH=None, OW=None,
              prologue=L.PRO_NONE, ln_gamma=None, ln_beta=None, ln_eps=1e-5, ln_shift=None, ln_scale=None,
-             ln_ld=0, ln_z=None, ln_ldz=0, ln_offz=0, probe=False):
+             ln_ld=0, ln_z=None, ln_ldz=0, ln_offz=0, probe=False, fin=None):
         """One fd_conv2d launch.  `probe=True` only asks the library whether this conv can take the
         fused LayerNorm prologue (bf16 streaming row-GEMM path) and launches nothing; `probe="kid"`
         returns fd_conv_kernel_id (tests pin which kernel a shape exercises)."""
@@ -331,6 +334,13 @@ class DAEngine:
         p.ln_shift, p.ln_scale, p.ln_ld = ptr(ln_shift), ptr(ln_scale), ln_ld
         p.ln_z, p.ln_ldz, p.ln_offz = ptr(ln_z), ln_ldz, ln_offz
         p.f32_split = getattr(self, "f32_split", 0)
+        p.debug = getattr(self, "conv_debug", 0)
+        if fin is not None:      # EPI_GNSILU_ADD_FINAL: final_conv (+ DDIM update) in the epilogue
+            p.fin_w, p.fin_b, p.fin_out = fin["w"].data_ptr(), float(fin["b"]), fin["out"].data_ptr()
+            p.fin_mode, p.fin_last = int(fin.get("mode", 0)), int(fin.get("last", 0))
+            p.fin_img = fin["img"].data_ptr() if fin.get("img") is not None else None
+            p.fin_xin = fin["xin"].data_ptr() if fin.get("xin") is not None else None
+            p.fin_alpha = float(fin.get("alpha", 0.0))
         if weight is None and cw is not None and getattr(cw, "w8", None) is not None:
             p.weight_f8, p.w_scale, p.act_scale = cw.w8.data_ptr(), cw.ws.data_ptr(), FP8_ACT_SCALE
         if probe == "kid":          # which kernel would run (include/founddiff_hip.h: fd_conv_kernel_id)
@@ -472,6 +482,23 @@ class DAEngine:
                 xm2 = self._b("xm", (B, H, W, Cc))
                 L.call("fd_ln_modulate", self.dt, _p(x1), None, None, 1e-6, mp(3), mp(4), ml, _p(xm2), B, hw, Cc, s)
                 self.conv(m["qkv"], xm2, B, H, W, qkv)
+            if L.lib().fd_dwconv_gram_ok(self.dt, Cc, H, W):
+                # qkv_dwconv of q and k straight into the Gram (fd_pwdw.hip: dwconv_gram_kernel): only v is written
+                nblk = L.lib().fd_dwconv_gram_nblk(H, W)
+                vbuf = self._b("attn_v", (B, H, W, Cc))
+                part = self._b("gram", (B, m["heads"], nblk, 1024 + 64), torch.float32)
+                L.call("fd_dwconv3x3", self.dt, _p(qkv), 3 * Cc, 2 * Cc, _p(m["qdw_w_v"]), None, 0, _p(vbuf), Cc, 0,
+                       B, H, W, Cc, s)
+                L.call("fd_dwconv_gram", self.dt, _p(qkv), 3 * Cc, Cc, _p(m["qdw_wm"]), _p(part), B, H, W, s)
+                self._pr(tag + ".qkv2", vbuf)
+                weff = self._b("weff", (B, Cc, Cc))
+                L.call("fd_chan_attn_weff", self.dt, _p(part), nblk, _p(m["temp"]), _p(m["wproj"]), _p(weff), B, Cc, s)
+                self._pr(tag + ".weff", weff)
+                x2 = self._b(tag + ".x2", (B, H, W, Cc))
+                self.conv(None, vbuf, B, H, W, x2, c0=Cc, ld0=Cc, off0=0, weight=weff, w_batch_stride=Cc * Cc,
+                          bias=None, Cout=Cc, KH=1, KW=1, epi=L.EPI_GATE_RES, res=x1, gate=mp(5), gate_ld=ml)
+                self._pr(tag, x2)
+                return x2
             L.call("fd_dwconv3x3", self.dt, _p(qkv), 3 * Cc, 0, _p(m["qdw_w"]), None, 0, _p(qkv2), 3 * Cc, 0,
                    B, H, W, 3 * Cc, s)
         self._pr(tag + ".qkv2", qkv2)
@@ -587,10 +614,12 @@ class DAEngine:
         self.mod_all = self.linear(tt, self.adaln_w, self.adaln_b,
                                    self._b("mod_all", (B, self.mod_total), torch.float32), pre_silu=True)
 
-    def forward(self, x_t, x_in, time, out=None, x_cond2=None):
+    def forward(self, x_t, x_in, time, out=None, x_cond2=None, sched=None):
         """x_t, x_in: (B,1,H,W) fp32 device tensors in [-1,1]; time (B,) fp32.  Returns the raw
         model output (B,1,H,W) fp32.  encode_condition(x_in) must have been called.  x_cond2: the
-        third input plane of an input_condition model (src/DADiff.py:1157-1158)."""
+        third input plane of an input_condition model (src/DADiff.py:1157-1158).  `sched` = (alpha, last): also
+        apply the DDIM update of src/DADiff.py:1203-1206, 1317-1318, 1344 to x_t IN PLACE (x_t <- x_t - alpha *
+        clamp(out), or clamp(x_in - clamp(out)) when `last`) -- in the bf16 mode inside the last kernel of the forward."""
         if (x_cond2 is not None) != (self.in_planes == 3):
             raise ValueError(f"this Unet's init_conv takes {self.in_planes} input planes "
                              f"(input_condition={'True' if self.in_planes == 3 else 'False'})")
@@ -608,9 +637,9 @@ class DAEngine:
         x = self._mid(x, B, h, w)
         for i in range(len(self.ups)):
             x, h, w = self._up(i, x, B, h, w)
-        return self._tail(x, r, B, H, W, out)
+        return self._tail(x, r, B, H, W, out, sched, x_t, x_in)
 
-    def forward_hybrid(self, inner, x_t, x_in, time, out=None, outer_levels=1):
+    def forward_hybrid(self, inner, x_t, x_in, time, out=None, outer_levels=1, sched=None):
         """One forward with THIS engine on the outermost `outer_levels` resolution levels (init_conv, the first
         down stages, the last up stages, final block) and `inner` -- another engine of the same weights, normally
         one precision class down -- on the levels in between; the activation crosses the boundary through a
@@ -636,7 +665,7 @@ class DAEngine:
         x = self._cast_from(x, inner, "hyb_out")
         for i in range(nu - k, nu):
             x, h, w = self._up(i, x, B, h, w)
-        return self._tail(x, r, B, H, W, out)
+        return self._tail(x, r, B, H, W, out, sched, x_t, x_in)
 
     def _cast_from(self, x, src, name):
         """x (a tensor of engine `src`) in this engine's storage type."""
@@ -698,11 +727,35 @@ class DAEngine:
         self._pr(f"u{i}s", o)
         return o, h, w
 
-    def _tail(self, x, r, B, H, W, out):
-        x = self.res_block(self.final_res, x, x.shape[-1], r, r.shape[-1], B, H, W, "finr")
+    def _tail(self, x, r, B, H, W, out, sched=None, x_t=None, x_in=None):
+        """final_res_block -> final_conv (src/DADiff.py:733-740) [-> the sampler's DDIM update of x_t, `sched`]."""
         if out is None:
             out = self._b("model_out", (B, 1, H, W), torch.float32)
-        L.call("fd_final_conv1", self.dt, _p(x), _p(self.final_w), _p(self.final_b), _p(out), B * H * W,
+        fr = self.final_res
+        cw, hw = fr["conv"], H * W
+        c0, c1 = x.shape[-1], r.shape[-1]
+        fin = dict(w=self.final_w, b=self.final_b_host, out=out)
+        if sched is not None:
+            fin.update(mode=1, alpha=sched[0], last=int(bool(sched[1])), img=x_t, xin=x_in)
+        kw = dict(c0=c0, in1=r, c1=c1)
+        if fr["res"] is not None and self.tdt == torch.bfloat16 and not self.probe and not os.environ.get("FOUNDDIFF_NO_FINAL_FOLD"):
+            mt = L.lib().fd_conv_mtiles(H, W)
+            hraw = self._b("res_h", (B, H, W, cw.Cout))
+            part = self._b("gn_part", (B, mt, cw.Cout, 2), torch.float32)
+            mr = self._b("gn_mr", (B, 8, 2), torch.float32)
+            ek = dict(epi=L.EPI_GNSILU_ADD_FINAL, h=hraw, gn=mr, gamma=fr["gamma"], beta=fr["beta"], groups=8, fin=fin)
+            if self.conv(fr["res"], x, B, H, W, out, probe=True, **kw, **ek):
+                # res_conv + GroupNorm/SiLU of the 3x3 output + final_conv (+ DDIM update) in ONE epilogue: the block's
+                # 64-channel output, its read by final_conv and the separate update kernel never happen
+                self.conv(cw, x, B, H, W, hraw, stats=part, **kw)
+                L.call("fd_gn_finalize", _p(part), B, mt, cw.Cout, 8, hw, 1e-5, _p(mr), self.stream)
+                self.conv(fr["res"], x, B, H, W, out, **kw, **ek)
+                return out
+        x = self.res_block(fr, x, c0, r, c1, B, H, W, "finr")
+        L.call("fd_final_conv1", self.dt, _p(x), _p(self.final_w), _p(self.final_b), _p(out), B * hw,
                x.shape[-1], self.stream)
         self._pr("out", out)
+        if sched is not None:
+            L.call("fd_res_ddim_step", _p(out), _p(x_t), _p(x_in), None, float(sched[0]), 0.0, int(bool(sched[1])), _p(x_t),
+                   x_t.numel(), self.stream)
         return out

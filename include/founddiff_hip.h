@@ -51,6 +51,12 @@ const char *fd_last_error(void);
 #define FD_EPI_GATE_RES 3   /* res[m,n] + gate[b,n] * (acc + bias)   adaLN-gated residual     */
 #define FD_EPI_RES_RELU 4   /* relu(acc + bias + res[m,n])           RN50 bottleneck tail     */
 #define FD_EPI_GNSILU_ADD 5 /* acc + bias + silu(GN(h[m,n]))         res_conv + Block output  */
+/* GNSILU_ADD, then the denoiser's last 1x1 (final_conv, Cout -> 1) and the sampler's update in the same pass: the
+ * block's Cout-channel output is never written.  o = fin_b + sum_n fin_w[n] * value[m,n] -> fin_out[b][m] (fp32);
+ * fin_mode 1: + the DDIM update of src/DADiff.py:1203-1206, 1317-1318, 1344 on the fp32 image planes:
+ *   pr = clamp(o, +-1);  fin_img[b][m] <- fin_last ? clamp(fin_xin - pr, +-1) : fin_img - fin_alpha * pr.
+ * Streaming row-GEMM only (bf16, fd_conv_prologue_ok).                                              */
+#define FD_EPI_GNSILU_ADD_FINAL 6
 
 typedef struct fd_conv_params {
     int32_t dtype;              /* FD_F32 | FD_BF16: type of in0/in1/weight/res/h            */
@@ -108,6 +114,16 @@ typedef struct fd_conv_params {
     /* fp32 storage only: 1 = split-bf16 contraction (x = hi + lo in bf16, hi.hi + hi.lo + lo.hi on the bf16 MFMA,
      * fp32 accumulation: ~2^-16 per product) instead of the exact-f32 MFMA.  The parity mode leaves it 0.       */
     int32_t f32_split;
+    /* development only (timing ablations of the 3x3 halo kernel, tools/kbench.py): must be 0.                   */
+    int32_t debug;
+    /* FD_EPI_GNSILU_ADD_FINAL                                                                                  */
+    const float *fin_w;                /* [Cout]                                              */
+    float fin_b;
+    float *fin_out;                    /* [B][H*W] fp32 model output                          */
+    int32_t fin_mode, fin_last;        /* 0: fin_out only; 1: + DDIM update of fin_img        */
+    float *fin_img;                    /* [B][H*W] fp32 x_t, updated in place                 */
+    const float *fin_xin;              /* [B][H*W] fp32 x_input                               */
+    float fin_alpha;
 } fd_conv_params;
 
 /* 1 if fd_conv2d would run `p` (weight_f8 / w_scale set) on the fp8 MFMA path.                        */
@@ -187,6 +203,15 @@ int fd_pw_dw3x3_gram(int dtype, const void *x, int ld_x, int off_x, int Cin, con
                      const float *ln_beta, float ln_eps, const float *ln_shift, const float *ln_scale,
                      int ln_ld, const void *w_pw, const uint32_t *w_dw, void *out_v, int ld_v, int off_v,
                      float *partial, int B, int H, int W, void *stream);
+
+/* ---- qkv_dwconv + L2 norms + q k^T for the wider blocks (C >= 128, src/DADiff.py:267-276): the depthwise 3x3 of the q
+ * and k channels of a qkv tensor [B,H,W,ld] (q at channel 0, k at channel C) feeding the per-head Gram directly -- q and k
+ * after the depthwise conv never reach HBM.  v keeps fd_dwconv3x3.  w_dw [5][3C] in fd_pw_dw3x3's tap-pair layout;
+ * partial [B][C/32][nblk][1024 + 64] in fd_chan_attn_gram's layout, nblk = fd_dwconv_gram_nblk(H, W).            */
+int fd_dwconv_gram_ok(int dtype, int C, int H, int W);
+int fd_dwconv_gram_nblk(int H, int W);
+int fd_dwconv_gram(int dtype, const void *qkv, int ld, int C, const uint32_t *w_dw, float *partial, int B, int H, int W,
+                   void *stream);
 
 /* ---- SS2D selective scan (replaces selective_scan_cuda_core.fwd, src/emamba2.py:154, together
  * with EfficientScan/EfficientMerge index maps 182-262, dt_proj einsum 340, softplus/bias).

@@ -122,6 +122,54 @@ def test_conv_concat_slices_epilogues(eng_factory, mode, tol):
     assert rel_err(nchw(og), refg) < tol
 
 
+def test_row_gemm_final_conv_ddim_epilogue(eng_factory):
+    """EPI_GNSILU_ADD_FINAL of the streaming row-GEMM: res_conv + SiLU(GN(h)) + final_conv (64 -> 1) + the DDIM
+    update in one epilogue (src/DADiff.py:733-740, 1203-1206, 1317-1318, 1344) against the unfused sequence
+    EPI_GNSILU_ADD -> fd_final_conv1 -> fd_res_ddim_step on the same inputs, and against the fp32 composition."""
+    from founddiff_amd import _lib as L
+    from founddiff_amd.engine import ConvW
+    e = eng_factory("bf16")
+    torch.manual_seed(41)
+    B, H, W, Ci, Co = 2, 128, 136, 128, 64                   # >= 16384 px: the row-GEMM path
+    x = rq(torch.randn(B, Ci, H, W), "bf16")
+    h = rq(torch.randn(B, Co, H, W) * 2 + 0.5, "bf16")
+    w = rq(torch.randn(Co, Ci, 1, 1) / Ci ** 0.5, "bf16")
+    bias, g, bb = torch.randn(Co), torch.randn(Co), torch.randn(Co)
+    fw, fb = torch.randn(Co) / 8, 0.3
+    hv = h.reshape(B, 8, -1)
+    mr = torch.stack([hv.mean(-1), torch.rsqrt(hv.var(-1, unbiased=False) + 1e-5)], -1).contiguous().cuda()
+    img, xin = torch.randn(B, 1, H, W).cuda(), torch.randn(B, 1, H, W).cuda().clamp(-1, 1)
+    cw = ConvW(w, bias, e.dev, e.tdt)
+    xd, hd = nhwc(x, e.tdt), nhwc(h, e.tdt)
+    xa, xb = xd[..., :64].contiguous(), xd[..., 64:].contiguous()
+    gd, bd, fwd = g.cuda(), bb.cuda(), fw.cuda()
+    kw = dict(c0=64, in1=xb, c1=64, h=hd, gn=mr, gamma=gd, beta=bd, groups=8)
+    # unfused
+    o64 = torch.empty(B, H, W, Co, device="cuda", dtype=e.tdt)
+    e.conv(cw, xa, B, H, W, o64, epi=L.EPI_GNSILU_ADD, **kw)
+    mo0 = torch.empty(B, 1, H, W, device="cuda")
+    fbd = torch.tensor([fb], device="cuda")
+    L.call("fd_final_conv1", e.dt, o64.data_ptr(), fwd.data_ptr(), fbd.data_ptr(), mo0.data_ptr(), B * H * W, Co, e.stream)
+    ref32 = (F.conv2d(x, w, bias) + F.silu(F.group_norm(h, 8, g, bb, 1e-5)))
+    ref_mo = (ref32 * fw[None, :, None, None]).sum(1, keepdim=True) + fb
+    for mode, lastf, alpha in ((0, 0, 0.0), (1, 0, 0.037), (1, 1, 0.0)):
+        mo1 = torch.full((B, 1, H, W), float("nan"), device="cuda")
+        im1, im0 = img.clone(), img.clone()
+        fin = dict(w=fwd, b=fb, out=mo1, mode=mode, last=lastf, alpha=alpha, img=im1, xin=xin)
+        assert e.conv(cw, xa, B, H, W, mo1, epi=L.EPI_GNSILU_ADD_FINAL, probe=True, fin=fin, **kw)
+        e.conv(cw, xa, B, H, W, mo1, epi=L.EPI_GNSILU_ADD_FINAL, fin=fin, **kw)
+        torch.cuda.synchronize()
+        assert float((mo1 - mo0).abs().max()) < 2e-5 * float(mo0.abs().max()) + 1e-5      # same rounding points: fp32 sum order
+        assert rel_err(mo1.cpu(), ref_mo) < 1e-2
+        if mode == 1:
+            L.call("fd_res_ddim_step", mo0.data_ptr(), im0.data_ptr(), xin.data_ptr(), None, alpha, 0.0, lastf, im0.data_ptr(),
+                   im0.numel(), e.stream)
+            torch.cuda.synchronize()
+            assert float((im1 - im0).abs().max()) < 1e-4
+        else:
+            assert torch.equal(im1, img)
+
+
 @pytest.mark.parametrize("mode,tol", MODES)
 def test_xproj_directions(eng_factory, mode, tol):
     """x_proj as 4 stride-2 1x1 convs with sub-grid origins == einsum over EfficientScan output."""
@@ -652,6 +700,44 @@ def test_pw_dw3x3_gram(eng_factory, hw):
     part2 = torch.empty_like(part1)
     L.call("fd_pw_dw3x3_gram", L.FD_BF16, xd.data_ptr(), Cin, 0, Cin, None, None, 1e-6, md.data_ptr(), md.data_ptr() + Cin * 4,
            6 * Cin, wpd.data_ptr(), wm.data_ptr(), v.data_ptr(), 64 + 8, 8, part2.data_ptr(), B, H, W, s)
+    torch.cuda.synchronize()
+    assert torch.equal(part1, part2)
+
+
+@pytest.mark.parametrize("cfg", [(128, 64, 48), (256, 24, 32), (512, 8, 16)])
+def test_dwconv_gram(eng_factory, cfg):
+    """fd_dwconv_gram (qkv_dwconv of q, k -> L2 norms + q k^T, C >= 128; src/DADiff.py:267-276) against the unfused HIP pair
+    fd_dwconv3x3 + fd_chan_attn_gram on the same qkv tensor, and the v slice through fd_dwconv3x3 with an offset."""
+    from founddiff_amd import _lib as L
+    from founddiff_amd.engine import DAEngine
+    Cc, H, W = cfg
+    torch.manual_seed(35)
+    B = 2
+    qkv = (torch.randn(B, H, W, 3 * Cc) * 0.7).to(torch.bfloat16).cuda()
+    wdw = (torch.randn(9, 3 * Cc) / 3).cuda()
+    wm = DAEngine._dw_masked(wdw)
+    s = torch.cuda.current_stream().cuda_stream
+    assert L.lib().fd_dwconv_gram_ok(L.FD_BF16, Cc, H, W)
+    full = torch.empty(B, H, W, 3 * Cc, device="cuda", dtype=torch.bfloat16)
+    L.call("fd_dwconv3x3", L.FD_BF16, qkv.data_ptr(), 3 * Cc, 0, wdw.data_ptr(), None, 0, full.data_ptr(), 3 * Cc, 0, B, H, W, 3 * Cc, s)
+    nb0 = L.lib().fd_chan_attn_nblk(H * W)
+    part0 = torch.empty(B, Cc // 32, nb0, 1088, device="cuda")
+    L.call("fd_chan_attn_gram", L.FD_BF16, full.data_ptr(), B, H * W, Cc, part0.data_ptr(), s)
+    nb1 = L.lib().fd_dwconv_gram_nblk(H, W)
+    part1 = torch.full((B, Cc // 32, nb1, 1088), float("nan"), device="cuda")
+    L.call("fd_dwconv_gram", L.FD_BF16, qkv.data_ptr(), 3 * Cc, Cc, wm.data_ptr(), part1.data_ptr(), B, H, W, s)
+    v = torch.empty(B, H, W, Cc, device="cuda", dtype=torch.bfloat16)
+    wv = wdw[:, 2 * Cc:].contiguous()
+    L.call("fd_dwconv3x3", L.FD_BF16, qkv.data_ptr(), 3 * Cc, 2 * Cc, wv.data_ptr(), None, 0, v.data_ptr(), Cc, 0, B, H, W, Cc, s)
+    torch.cuda.synchronize()
+    assert torch.equal(v, full[..., 2 * Cc:])
+    g0, g1 = part0.double().sum(2).cpu(), part1.double().sum(2).cpu()
+    assert bool(torch.isfinite(g1).all())
+    # the fused kernel's depthwise uses the tap-PAIR dot2 form of fd_pw_dw3x3 (bf16 weights, fp32 accumulation in another
+    # order than the standalone kernel's): q, k agree to bf16 rounding flips, the Gram to ~1e-3
+    assert rel_err(g1[..., :1024], g0[..., :1024]) < 3e-3 and rel_err(g1[..., 1024:], g0[..., 1024:]) < 3e-3
+    part2 = torch.empty_like(part1)
+    L.call("fd_dwconv_gram", L.FD_BF16, qkv.data_ptr(), 3 * Cc, Cc, wm.data_ptr(), part2.data_ptr(), B, H, W, s)
     torch.cuda.synchronize()
     assert torch.equal(part1, part2)
 

@@ -86,6 +86,39 @@ def bench_attn(B, sizes=((512, 512), (256, 256))):
               f"fused {fa:.1f} + weff {fc:.1f} = {fa + fc:.1f} us  (nblk {nb0} -> {nb1})", flush=True)
 
 
+def bench_conv3(B, shapes=None):
+    """3x3 halo convolutions of a 512x512 forward: (c0, c1, cout, OH, upsample)"""
+    from founddiff_amd import _lib as L
+    from founddiff_amd.engine import DAEngine, ConvW, _T
+
+    class Bare(DAEngine):
+        def __init__(self):
+            self.mode = "bf16"
+            self.dt, self.tdt = _T["bf16"]
+            self.dev = torch.device("cuda")
+            self.buf = {}
+    e = Bare()
+    e.conv_debug = int(os.environ.get("FD_CONV_DEBUG", "0"))
+    shapes = shapes or [(64, 0, 64, 512, False), (64, 64, 64, 512, False), (128, 0, 64, 512, True), (128, 64, 128, 256, False),
+                        (256, 0, 128, 256, True), (256, 128, 256, 128, False), (512, 0, 256, 128, True), (512, 256, 512, 64, False)]
+    for c0, c1, cout, OH, up in shapes:
+        torch.manual_seed(0)
+        H = OH // 2 if up else OH
+        cin = c0 + c1
+        cw = ConvW(torch.randn(cout, cin, 3, 3) / (3 * cin ** 0.5), torch.randn(cout), e.dev, e.tdt)
+        xa = torch.randn(B, H, H, c0, device="cuda").to(torch.bfloat16)
+        xb = torch.randn(B, H, H, c1, device="cuda").to(torch.bfloat16) if c1 else None
+        out = torch.empty(B, OH, OH, cout, device="cuda", dtype=torch.bfloat16)
+        part = torch.empty(B, L.lib().fd_conv_mtiles(OH, OH), cout, 2, device="cuda")
+        kw = dict(c0=c0, stats=part, upsample=up)
+        if c1:
+            kw.update(in1=xb, c1=c1)
+        assert e.conv(cw, xa, B, H, H, out, probe="kid", **kw) == 11
+        t = timeit(lambda: e.conv(cw, xa, B, H, H, out, **kw))
+        fl = 2.0 * B * OH * OH * cout * 9 * cin
+        print(f"conv3x3 {cin:4d}->{cout:4d} @{OH} up={int(up)} B={B}: {t:8.1f} us  {fl / t / 1e6:7.1f} TFLOP/s  ({fl / t / 1e6 / 2500:.3f} of peak)", flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("what")

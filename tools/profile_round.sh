@@ -7,12 +7,12 @@ TAG=${1:-rXX}
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o bench --output-format csv -- python3 bench.py --no-cpu-baseline --no-fp32-leg > $OUT/bench_prof.json 2> $OUT/bench_prof.err
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o bench --output-format csv -- python3 bench.py --no-cpu-baseline --no-fp32-leg --no-extra-legs > $OUT/bench_prof.json 2> $OUT/bench_prof.err
 find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 # the same bench on ONE stream at the sub-batch size (8): per-kernel durations are exclusive there (with the default two concurrent sub-batches a
 # kernel's duration includes the time it shares the chip with the other stream's kernels) -- the cross-check of roofline.avg_launch_us
 export FOUNDDIFF_STREAMS=1
-rocprofv3 --kernel-trace --stats -d $OUT/stats_s1 -o bench --output-format csv -- python3 bench.py --batch 8 --no-cpu-baseline --no-fp32-leg > $OUT/bench_prof_s1.json 2> $OUT/bench_prof_s1.err
+rocprofv3 --kernel-trace --stats -d $OUT/stats_s1 -o bench --output-format csv -- python3 bench.py --batch 8 --no-cpu-baseline --no-fp32-leg --no-extra-legs > $OUT/bench_prof_s1.json 2> $OUT/bench_prof_s1.err
 unset FOUNDDIFF_STREAMS
 find $OUT/stats_s1 -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_one_stream.csv \;
 for c in FETCH_SIZE WRITE_SIZE; do

@@ -38,7 +38,15 @@ def fam(prefix):
     return round(sum(per[k]["hbm_bytes_per_launch"] * per[k]["n"] for k in ks) / n) if n else None
 
 
+import glob as _g, hashlib, os
+_h = hashlib.sha256()
+for _f in sorted(_g.glob(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "founddiff_amd", "csrc", "*"))):
+    _h.update(open(_f, "rb").read())
+nfwd = int(os.environ.get("TRAFFIC_FORWARDS", "2"))          # tools/run_forward.py --n
 res = {"note": __doc__.strip(),
+       "csrc_sha": _h.hexdigest()[:16], "batch": int(os.environ.get("TRAFFIC_BATCH", "8")),
+       "total_hbm_bytes_per_forward": round(sum(v["hbm_bytes_per_launch"] * v["n"] for v in per.values()) / nfwd),
+       "pwdw_gram_hbm_bytes_per_launch": fam("pwdw_gram_kernel"),
        "pwdw_hbm_bytes_per_launch": fam("pwdw_kernel"),
        "dwconv3x3_bf16_hbm_bytes_per_launch": fam("dwconv3x3_bf16_kernel"),
        "conv3x3_halo_hbm_bytes_per_launch": fam("conv3x3_halo_kernel"),
