@@ -54,7 +54,7 @@ def save(name, spec=None, seed=SEED_W, **arrs):
     if spec is not None:
         out["spec_json"] = np.frombuffer(json.dumps(spec).encode(), dtype=np.uint8)
         out["weight_seed"] = np.asarray(seed)
-    path = os.path.join(HERE, name + ".npz")
+    path = os.path.join(os.environ.get("FD_GOLDEN_OUT", HERE), name + ".npz")     # tests regenerate into a temp dir
     np.savez_compressed(path, **out)
     print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
 
@@ -214,8 +214,11 @@ def _da_model(D, dim, mults, S, size):
     new = synth.synth_state_dict(spec, SEED_W)
     dif.load_state_dict(new, strict=False)   # only the 12 schedule buffers are left as built
     dif.init()
-    # the fixture only needs the live keys (dead: the unused second CLIP, Q7)
+    # the fixture only needs the live keys (dead: the unused second CLIP, Q7) -- plus the names / shapes of the 12
+    # schedule buffers, so that the fixture's spec is the reference's whole ResidualDiffusion.state_dict() layout
+    # (tests/test_host_cpu.py::test_module_state_dict_layout); synth skips them (they are re-derived by init())
     live = {k: v for k, v in spec.items() if ".unet0.clip_model." not in k}
+    live.update({k: v for k, v in synth.spec_of(full).items() if not k.startswith("model.") and not k.startswith("perceploss.")})
     return dif, live
 
 
@@ -327,30 +330,32 @@ def g_e2e_da_variants(D):
 
 
 def g_e2e_vanilla(D):
+    """BASELINE configs[0] geometry on the vanilla path: Unet(dim=32, dim_mults=(1,2)), 64x64, 10-step DDIM for the
+    three objectives + 6 ancestral steps."""
     from src import denoising_diffusion_pytorch as V
     net = V.Unet(32, dim_mults=(1, 2), channels=1)
     for obj, S in (("pred_noise", 10), ("pred_x0", 10), ("pred_v", 10)):
-        dif = V.GaussianDiffusion(net, image_size=32, timesteps=1000, sampling_timesteps=S,
+        dif = V.GaussianDiffusion(net, image_size=64, timesteps=1000, sampling_timesteps=S,
                                   objective=obj, beta_schedule="cosine").eval()
         sd = dif.state_dict()
         spec = {k: v for k, v in synth.spec_of(sd).items() if k.startswith("model.")}
         dif.load_state_dict(synth.synth_state_dict(spec, SEED_W), strict=False)  # schedule buffers kept
         if obj == "pred_noise":
             arrs = {}
-            x = rnd(2, 1, 32, 32, seed=41)
+            x = rnd(2, 1, 64, 64, seed=41)
             arrs["unet.x"], arrs["unet.t"] = x, torch.tensor([999, 17])
             arrs["unet.out"] = dif.model(x, torch.tensor([999, 17]))
         torch.manual_seed(5)
-        xT = torch.randn(2, 1, 32, 32)
+        xT = torch.randn(2, 1, 64, 64)
         torch.manual_seed(5)
         out = dif.sample(batch_size=2)
         arrs[f"ddim.{obj}.xT"], arrs[f"ddim.{obj}.out"] = xT, out[0]
     # ancestral, 6 steps
-    dif = V.GaussianDiffusion(net, image_size=32, timesteps=1000, objective="pred_noise",
+    dif = V.GaussianDiffusion(net, image_size=64, timesteps=1000, objective="pred_noise",
                               beta_schedule="linear").eval()
     dif.load_state_dict(synth.synth_state_dict(spec, SEED_W), strict=False)
     g = torch.Generator().manual_seed(78)
-    noises = torch.randn(6, 2, 1, 32, 32, generator=g)
+    noises = torch.randn(6, 2, 1, 64, 64, generator=g)
     img = xT.clone()
     import unittest.mock as um
     anc = []

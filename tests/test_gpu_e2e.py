@@ -379,6 +379,28 @@ def test_config4_512_ancestral_bf16_properties():
     assert torch.equal(img0, xs0)                       # coef3 = 1, coef1 = coef2 = 0, no noise at t = 0
 
 
+def test_config4_512_full_length_ancestral_keyed():
+    """BASELINE configs[3], one GPU's share at full length: the 1000-step ancestral p_sample_loop at 512x512 (full
+    architecture, bf16 production mode: graph chunks of 37 steps + the tail step on the higher-precision engine) with
+    the per-slice keyed step noise.  Size-independent properties: finite, in [0, 1], run-to-run bitwise, and a slice's
+    result is the same in a batch of 2 and alone (what sharding 64 slices over 8 ranks relies on)."""
+    import bench
+    from founddiff_amd import synth
+    dev = torch.device("cuda")
+    dif, _ = bench.build_model(dev, 512, 1000, "bf16")
+    assert not dif.is_ddim_sampling and dif.final_fp32_steps == 1
+    _, ld = synth.ct_phantom(2, 512, seed=10)
+    x = torch.from_numpy(ld).to(dev)
+    seeds = torch.tensor([64007, 64008])
+    a = dif.sample([x], batch_size=2, slice_seeds=seeds)[-1]
+    assert dif._anc_steps_run == 1000
+    assert torch.isfinite(a).all() and float(a.min()) >= 0.0 and float(a.max()) <= 1.0
+    one = dif.sample([x[1:2]], batch_size=1, slice_seeds=seeds[1:2])[-1]
+    assert torch.equal(one, a[1:2])
+    # the image is a denoised version of its input, not noise: closer to the clean phantom's scale than x_T was
+    assert float((a - x).abs().mean()) < 0.2
+
+
 def test_ancestral_steps_fp32(golden):
     g, dif = _tiny_model(golden, "fp32", S=1000)
     xi = (g["x_input"] * 2 - 1).cuda()

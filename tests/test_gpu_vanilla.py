@@ -68,7 +68,7 @@ def _model(golden, obj, S, sched="cosine", precision="fp32"):
     from founddiff_amd.denoising_diffusion_pytorch import GaussianDiffusion, Unet
     g = golden("e2e_vanilla_tiny")
     net = Unet(32, dim_mults=(1, 2), channels=1, precision=precision)
-    dif = GaussianDiffusion(net, image_size=32, timesteps=1000, sampling_timesteps=S, objective=obj, beta_schedule=sched)
+    dif = GaussianDiffusion(net, image_size=64, timesteps=1000, sampling_timesteps=S, objective=obj, beta_schedule=sched)
     missing, unexpected = dif.load_state_dict(g.weights("model."), strict=False)
     assert not [k for k in missing if k.startswith("model.")] and not unexpected
     return g, dif.to("cuda")
@@ -89,7 +89,9 @@ def test_vanilla_unet_and_ddim_fp32(golden):
     for obj in ("pred_noise", "pred_x0", "pred_v"):
         g, dif = _model(golden, obj, 10)
         res = dif.sample(batch_size=2, noise=g[f"ddim.{obj}.xT"].cuda())
-        assert rel_err(res[0].cpu(), g[f"ddim.{obj}.out"]) < 2e-3, obj
+        e_ = rel_err(res[0].cpu(), g[f"ddim.{obj}.out"])
+        print(obj, "ddim rel_err", e_)
+        assert e_ < 1e-3, (obj, e_)
 
 
 def test_vanilla_ancestral_fp32(golden):

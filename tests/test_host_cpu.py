@@ -146,3 +146,63 @@ def test_bench_self_launch_command(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_inspect_checkpoint_tool(tmp_path):
+    """tools/inspect_checkpoint.py: the key / shape diff of a `model-N.pt` / `Dose-CLIP.pth` against
+    arch.da_unet_spec, on synthetic checkpoints in the reference's format (src/DADiff.py:1626-1669): a good one with
+    dead weight and an ema-pytorch 0.0.10 'ema' entry; one of another geometry; one with a missing and a reshaped key."""
+    import importlib.util
+    import os
+    import torch
+    from founddiff_amd import arch, synth
+    from founddiff_amd.DADiff import residual_schedule
+    spec_ = importlib.util.spec_from_file_location("inspect_checkpoint", os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), "tools", "inspect_checkpoint.py"))
+    ic = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(ic)
+    clip = dict(layers=(2, 1, 1, 1), width=16, embed_dim=1024)
+    spec = arch.da_unet_spec(32, (1, 2), prefix="model.unet0.", clip=clip)
+    w = synth.synth_state_dict(spec, seed=3)
+    model = dict(w)
+    model.update(residual_schedule(1000))                                       # the 12 schedule buffers
+    model["model.unet0.clip_model.visual.conv1.weight"] = torch.zeros(8, 3, 3, 3)      # the unused second CLIP (dead)
+    model["model.unet0.dose_encoder.prompt_learner.ctx"] = torch.zeros(2, 16, 512)     # DA-CLIP text side (dead)
+    model["perceploss.net.lin0.model.1.weight"] = torch.zeros(1, 64, 1, 1)             # LPIPS (dead)
+    ema = {"ema_model." + k: v for k, v in model.items()}
+    ema.update({"online_model." + k: v for k, v in model.items()})
+    ema["initted"], ema["step"] = torch.tensor(True), torch.tensor(400000)
+    good = tmp_path / "model-400.pt"
+    torch.save({"step": 400000, "model": model, "opt0": {}, "ema": ema, "scaler": None}, good)
+    rep = ic.inspect_checkpoint(str(good), dim=32, dim_mults=(1, 2), clip=clip)
+    assert rep["ok"] and rep["step"] == 400000
+    assert rep["model"]["missing"] == [] and rep["model"]["unexpected"] == [] and len(rep["model"]["dead"]) == 3
+    assert rep["ema"]["layout_is_ema_pytorch_0_0_10"] and rep["ema"]["ok"] and rep["ema"]["n_online_model"] == len(model)
+    assert rep["schedule_buffers"]["present"] == 12 and rep["schedule_buffers"]["match_ctor"]
+    # another geometry: the shipped spec does not match a dim-32 checkpoint
+    rep = ic.inspect_checkpoint(str(good), dim=64, dim_mults=(1, 2, 4, 8), clip=clip)
+    assert not rep["ok"] and rep["model"]["missing"] and (rep["model"]["shape_mismatch"] or rep["model"]["unexpected"])
+    # one key missing, one reshaped, one unknown
+    bad = dict(model)
+    bad.pop("model.unet0.final_conv.weight")
+    bad["model.unet0.init_conv.weight"] = torch.zeros(32, 3, 7, 7)
+    bad["model.unet0.some_new_module.weight"] = torch.zeros(4)
+    badp = tmp_path / "model-1.pt"
+    torch.save({"step": 1, "model": bad, "opt0": {}, "ema": None, "scaler": None}, badp)
+    rep = ic.inspect_checkpoint(str(badp), dim=32, dim_mults=(1, 2), clip=clip)
+    assert not rep["ok"] and rep["model"]["missing"] == ["model.unet0.final_conv.weight"]
+    assert rep["model"]["shape_mismatch"][0][0] == "model.unet0.init_conv.weight"
+    assert rep["model"]["unexpected"] == ["model.unet0.some_new_module.weight"] and not rep["ema"]["present"]
+    # not a checkpoint dict at all
+    torch.save({"weights": 1}, tmp_path / "x.pt")
+    assert not ic.inspect_checkpoint(str(tmp_path / "x.pt"))["ok"]
+    # Dose-CLIP.pth: CLIPIQA.state_dict()
+    iqa = {k[len("model.unet0.dose_encoder."):]: v for k, v in w.items() if k.startswith("model.unet0.dose_encoder.")}
+    iqa["prompt_learner.ctx"] = torch.zeros(2, 16, 512)
+    torch.save(iqa, tmp_path / "Dose-CLIP.pth")
+    rep = ic.inspect_dose_clip(str(tmp_path / "Dose-CLIP.pth"), clip=clip)
+    assert rep["ok"] and rep["dead"] == ["dose_encoder.prompt_learner.ctx"]
+    iqa.pop("head1.0.weight")
+    torch.save(iqa, tmp_path / "Dose-CLIP.pth")
+    rep = ic.inspect_dose_clip(str(tmp_path / "Dose-CLIP.pth"), clip=clip)
+    assert not rep["ok"] and rep["missing"] == ["dose_encoder.head1.0.weight"]

@@ -1,5 +1,7 @@
 """Pin the CPU oracle (oracle/) against golden vectors captured from the reference itself
 (tests/golden/make_golden.py).  CPU only."""
+import os
+
 import pytest
 import torch
 
@@ -256,3 +258,23 @@ def test_metrics_oracle_vs_scipy():
     m = ((2 * mu1 * mu2 + 1e-4) * (2 * s12 + 9e-4)) / ((mu1 ** 2 + mu2 ** 2 + 1e-4) * (s1 + s2 + 9e-4))
     assert abs(float(om.ssim(a, b)) - float(np.clip(m, 0, 1).mean())) < 1e-5
     assert abs(float(om.psnr(a, b)) - 10 * np.log10(1.0 / np.mean((x - y) ** 2))) < 1e-4
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="the reference only exists in the build container")
+def test_fixtures_regenerate_from_the_reference(tmp_path):
+    """Where /root/reference is present, two fixtures are regenerated from it (tests/golden/make_golden.py: schedule,
+    modules_odd) into a temp dir and compared with the committed files array by array, spec included: the goldens
+    are reproducible outputs of the reference, not hand-kept data (spec_json drift)."""
+    import subprocess
+    import sys
+    import numpy as np
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    env = dict(os.environ, FD_GOLDEN_OUT=str(tmp_path), PYTHONDONTWRITEBYTECODE="1")
+    for what in ("schedule", "modules_odd"):
+        r = subprocess.run([sys.executable, os.path.join(here, "make_golden.py"), what], env=env, capture_output=True, text=True,
+                           timeout=900)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        new, old = np.load(tmp_path / f"{what}.npz"), np.load(os.path.join(here, f"{what}.npz"))
+        assert sorted(new.files) == sorted(old.files)
+        for k in old.files:
+            assert np.array_equal(new[k], old[k]), (what, k)
