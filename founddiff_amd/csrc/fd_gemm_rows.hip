@@ -86,15 +86,14 @@ __global__ __launch_bounds__(NT) void gemm_rows_kernel(const fd_conv_params p, i
     auto load_tile = [&](int wt, bf16x8 (&xb)[S][KS]) {
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-            const int64_t m = (int64_t)wt * (16 * S) + 16 * s + fr;
-            const bool ok = m < hw;
+            // rows beyond the image (ragged last tile) read the last row instead: their results are never stored, and
+            // unconditional loads keep the tile body one basic block (the scheduling fences below need that)
+            const int64_t m = min((int64_t)wt * (16 * S) + 16 * s + fr, hw - 1);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const int c = ks * 32 + fg * 8;
-                bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (ok) v = c < p.c0 ? *(const bf16x8 *)(in0 + m * p.ld0 + c)
-                                     : *(const bf16x8 *)(in1 + m * p.ld1 + (c - p.c0));
-                xb[s][ks] = v;
+                const bf16 *src = c < p.c0 ? in0 + m * p.ld0 + c : in1 + m * p.ld1 + (c - p.c0);
+                xb[s][ks] = *(const bf16x8 *)src;
             }
         }
     };
@@ -106,6 +105,12 @@ __global__ __launch_bounds__(NT) void gemm_rows_kernel(const fd_conv_params p, i
         bf16x8 xb[S][KS];
         load_tile(wt, xb);
         if (PRO != 0) {
+            // the prologue vectors of a lane (its 8 channels of every K32 step) do not depend on the tile: hoisted out of
+            // the pixel loop they were 2-3 x KS x 8 permanently live registers (out_proj: 182 VGPRs, 2 waves per SIMD;
+            // K = 256: 256 + 116 spilled to AGPRs, ONE wave per SIMD) on kernels that live on waves hiding each other's
+            // HBM latency.  An opaque copy of fg keeps the (cheap, broadcast-free) LDS reads inside the loop.
+            int fgo = fg;
+            asm volatile("" : "+v"(fgo));
 #pragma unroll
             for (int s = 0; s < S; ++s) {
                 // three cheap unpack passes instead of one fp32 copy of the row kept live across the
@@ -132,10 +137,10 @@ __global__ __launch_bounds__(NT) void gemm_rows_kernel(const fd_conv_params p, i
                 q += __shfl_xor(q, 16, 64);
                 q += __shfl_xor(q, 32, 64);
                 const float rstd = rsqrtf(q * (1.f / K) + p.ln_eps);
-                const int64_t m = (int64_t)wt * (16 * S) + 16 * s + fr;
+                const int64_t m = min((int64_t)wt * (16 * S) + 16 * s + fr, hw - 1);
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    const int c = ks * 32 + fg * 8;
+                    const int c = ks * 32 + fgo * 8;
                     float f[8], g8[8], b8[8];
                     unpack8(xb[s][ks], f);
                     load8(sV + c, g8);
@@ -145,14 +150,21 @@ __global__ __launch_bounds__(NT) void gemm_rows_kernel(const fd_conv_params p, i
                         for (int e = 0; e < 8; ++e) f[e] = (f[e] - mean) * rstd * g8[e] + b8[e];
                     } else {
                         float z8[8], l8[8];
-                        bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-                        if (m < hw) z = *(const bf16x8 *)(zin + m * p.ln_ldz + c);
+                        const bf16x8 z = *(const bf16x8 *)(zin + m * p.ln_ldz + c);
                         unpack8(z, z8);
                         load8(sV + 2 * K + c, l8);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) f[e] = ((f[e] - mean) * rstd * g8[e] + b8[e]) * z8[e] + l8[e];
                     }
                     xb[s][ks] = pack8(f);
+                    // one K32 step at a time: left to itself the compiler issues the gamma / beta / local / z loads of
+                    // ALL steps first and sinks the arithmetic to the MFMA loop: ~100 more live registers (2 instead
+                    // of 4 waves per SIMD on an HBM-bound kernel).  The empty asm pins this step's result here.
+                    if (PRO == 2) {
+                        u32x4 pin = __builtin_bit_cast(u32x4, xb[s][ks]);
+                        asm volatile("" : "+v"(pin));
+                        xb[s][ks] = __builtin_bit_cast(bf16x8, pin);
+                    }
                 }
             }
         }
@@ -168,10 +180,14 @@ __global__ __launch_bounds__(NT) void gemm_rows_kernel(const fd_conv_params p, i
 #pragma unroll
                 for (int s = 0; s < S; ++s) acc[t][s] = (f32x4){0.f, 0.f, 0.f, 0.f};
             const int rowa = 32 * ng + 8 * (fr >> 2) + (fr & 3);
+            // LN_GATE prologue (out_proj): the weight fragments, too, stay LDS reads per tile instead of N*K/256 hoisted
+            // registers per lane -- this variant needs its registers for waves (HBM latency), not for a 16-64 KB matrix
+            int fgw = fg;
+            if (PRO == 2) asm volatile("" : "+v"(fgw));
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 wa = *(const bf16x8 *)(sW + w_off(rowa, ks * 4 + fg, RS));
-                const bf16x8 wb = *(const bf16x8 *)(sW + w_off(rowa + 4, ks * 4 + fg, RS));
+                const bf16x8 wa = *(const bf16x8 *)(sW + w_off(rowa, ks * 4 + fgw, RS));
+                const bf16x8 wb = *(const bf16x8 *)(sW + w_off(rowa + 4, ks * 4 + fgw, RS));
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
                     acc[0][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb[s][ks], acc[0][s], 0, 0, 0);
