@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libfounddiff_hip.so")
+LIB_PATH = os.environ.get("FOUNDDIFF_LIB") or os.path.join(HERE, "lib", "libfounddiff_hip.so")   # override: A/B of two builds
 
 FD_F32, FD_BF16 = 0, 1
 FD_OPT_LOW_LATENCY = 0x100

@@ -12,7 +12,6 @@
 // next slab's halo is in flight during the current slab's 9 taps.
 // Epilogue = the generic kernel's (LDS-staged accumulators, row-contiguous 16-byte stores,
 // deterministic per-tile GroupNorm partial sums).
-#include <stdlib.h>
 #include "fd_common.h"
 
 namespace {
@@ -47,15 +46,8 @@ __device__ __forceinline__ int swz(int row, int chunk) {
 // the LDS fragment bytes, half the weight DMA and a quarter of the MFMA instructions of the bf16 form.
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 
-// Persistent over `tpw` consecutive tiles (round 3).  One tile of a 64 -> 64 layer is 9 taps = ~4.6k matrix-pipe
-// cycles per wave between a prologue that waits for the halo from HBM and an LDS-staged epilogue: half of a
-// workgroup's lifetime was outside the MFMA loop.  Now, during the LAST slab of a tile, the next tile's first halo
-// slab is requested into registers (tap 0) and its first two weight tiles into the ring (taps 7, 8) exactly as a next
-// slab's would be; the epilogue stages the accumulators through the HALO region only (in NP passes of HALO_B bytes:
-// the ring keeps the requested tiles) behind LDS-only barriers (no vmcnt(0): the output stores stay in flight), and
-// the next tile starts with `halo_lstore` + one counted wait.  Results are bit-identical to the one-tile form.
 template <int BN, int TH, bool F8>
-__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_params p, const int tpw) {
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_params p) {
     constexpr int BM = TH * TW, HY = TH + 2, HP = HY * HX;
     constexpr int HL = (HP * 8 + 255) / 256;          // halo 16-byte LDS chunks per thread
     constexpr int SLABC = F8 ? 128 : 64;              // channels per K slab
@@ -67,17 +59,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
     constexpr int WT_B = BN * ROWB;
     constexpr int NWB = 3;                         // weight-tile ring (LDS-DMA, two taps ahead)
     constexpr int LOOP_B = HALO_B + NWB * WT_B;    // ONE halo buffer (the next slab waits in registers)
-    // epilogue staging in NP passes of PR tile rows each, inside the halo region (the ring above it stays intact)
-    constexpr int NP = (BM * BN * 4 + HALO_B - 1) / HALO_B <= 2 ? 2 : 4;
-    constexpr int PR = BM / NP;
-    static_assert(PR * BN * 4 <= HALO_B && PR % 16 == 0, "epilogue pass must fit the halo region");
-    constexpr int SM_B = LOOP_B;
+    constexpr int C_B = BM * BN * 4;
+    constexpr int SM_B = LOOP_B > C_B ? LOOP_B : C_B;
     __shared__ __attribute__((aligned(16))) unsigned char smem[SM_B];
     __shared__ float s_stat[4][BN][2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tiles_x = p.OW / TW, ntiles = tiles_x * (p.OH / TH);
-    const int tile0 = blockIdx.x * tpw;
-    int ty0 = (tile0 / tiles_x) * TH, tx0 = (tile0 % tiles_x) * TW;
+    const int tiles_x = p.OW / TW;
+    const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
     const int nt = blockIdx.y, b = blockIdx.z;
     const int Cin = p.c0 + p.c1, K = 9 * Cin, nslab = Cin / SLABC;
     const int Hs = p.OH, Ws = p.OW;                   // conv input grid == output grid (stride 1, pad 1)
@@ -90,24 +78,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
     // padding): the s_waitcnt bookkeeping of the weight ring below counts wave-level VMEM instructions.
     int hoff[HL];          // element offset of the (clamped) source pixel inside the image
     uint32_t hvalid = 0;
-    auto halo_geom = [&](int ty, int tx) {            // of the tile whose halo is loaded NEXT
-        hvalid = 0;
-        int tg = tid;                                 // opaque: the (hy, hx) of a thread's chunks are recomputed per tile
-        asm volatile("" : "+v"(tg));                  // instead of living (spilled) across the MFMA loop
 #pragma unroll
-        for (int i = 0; i < HL; ++i) {
-            const int hid = tg + 256 * i;
-            const int hp = min(hid >> 3, HP - 1);
-            const int hy = hp / HX, hx = hp - hy * HX;
-            int y = ty + hy - 1, x = tx + hx - 1;
-            if (y >= 0 && y < Hs && x >= 0 && x < Ws) hvalid |= 1u << i;
-            y = min(max(y, 0), Hs - 1);
-            x = min(max(x, 0), Ws - 1);
-            if (p.upsample) { y >>= 1; x >>= 1; }
-            hoff[i] = y * p.W + x;
-        }
-    };
-    halo_geom(ty0, tx0);
+    for (int i = 0; i < HL; ++i) {
+        const int hid = tid + 256 * i;
+        const int hp = min(hid >> 3, HP - 1);
+        const int hy = hp / HX, hx = hp - hy * HX;
+        int y = ty0 + hy - 1, x = tx0 + hx - 1;
+        if (y >= 0 && y < Hs && x >= 0 && x < Ws) hvalid |= 1u << i;
+        y = min(max(y, 0), Hs - 1);
+        x = min(max(x, 0), Ws - 1);
+        if (p.upsample) { y >>= 1; x >>= 1; }
+        hoff[i] = y * p.W + x;
+    }
     u32x4 rh[HL][HG];
     auto halo_gload = [&](int slab) {
         const int c = slab * SLABC + (tid & 7) * (SLABC / 8);     // a thread's 8 (16) channels come from ONE source
@@ -115,7 +97,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
         int ld, cc;
         if (c < p.c0) { src = in0; ld = p.ld0; cc = c; }
         else { src = in1; ld = p.ld1; cc = c - p.c0; }
-        if (p.debug & 2) return;                      // ablation: no halo loads
 #pragma unroll
         for (int i = 0; i < HL; ++i)
 #pragma unroll
@@ -174,7 +155,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
     const unsigned lds_w = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)smem + HALO_B +
                            __builtin_amdgcn_readfirstlane(wave) * NB * 1024;
     auto w_dma = [&](int slab, int tap, int buf) {
-        if (p.debug & 4) return;                      // ablation: no weight DMA
         const char *wb = (const char *)(wgt + (tap * Cin + slab * SLABC) * ESZ);
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
@@ -217,43 +197,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
         boff[j] = r * ROWB + swz<F8>(r, F8 ? 2 * fg : fg);
     }
 
-    auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-    constexpr int VPR = BN / 8, RPP = 256 / VPR;
-    constexpr int NSTORE = BM / RPP;                  // output store instructions per wave and tile (epilogue)
-    bf16 *outp = (bf16 *)p.out + (int64_t)b * p.OH * p.OW * p.ldo + p.offo;
-
     w_dma(0, 0, 0);
     w_dma(0, 1, 1);
     halo_gload(0);
     halo_lstore();                                   // consumes the youngest loads: everything above has landed
     FD_WAIT_VM(0);
     __syncthreads();
-    for (int tt = 0; tt < tpw; ++tt) {
-    const int tile = tile0 + tt;
-    if (tile >= ntiles) break;                       // workgroup-uniform
-    const bool next_tile = tt + 1 < tpw && tile + 1 < ntiles;
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int slab = 0; slab < nslab; ++slab) {
-        // "next": the next slab of this tile, or slab 0 of the workgroup's next tile -- the prefetches are the same
-        const bool has_next = slab + 1 < nslab || next_tile;
-        const int nslab_i = slab + 1 < nslab ? slab + 1 : 0;
+        const bool has_next = slab + 1 < nslab;
         const unsigned char *sH = smem;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const bool last_tap = tap == 8;
             // request tile q+2 into the buffer tile q-1 was read from (all waves are past that barrier)
             const bool dma = tap + 2 < 9 || has_next;
-            if (tap == 0 && has_next) {                           // in flight during this slab's 9 taps
-                if (slab + 1 == nslab) {                          // the next tile's geometry (this tile's is dead: its
-                    const int tn = tile + 1;                      // last halo_lstore is behind us)
-                    halo_geom((tn / tiles_x) * TH, (tn % tiles_x) * TW);
-                }
-                halo_gload(nslab_i);
-            }
-            if (dma) w_dma(tap + 2 < 9 ? slab : nslab_i, (tap + 2) % 9, (tap + 2) % NWB);
+            if (tap == 0 && has_next) halo_gload(slab + 1);       // in flight during this slab's 9 taps
+            if (dma) w_dma(tap + 2 < 9 ? slab : slab + 1, (tap + 2) % 9, (tap + 2) % NWB);
             const unsigned char *sB = smem + HALO_B + (tap % NWB) * WT_B;
             const int kh = tap / 3, kw = tap - kh * 3;
             if constexpr (F8) {
@@ -289,13 +248,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
                     af[i] = *(const bf16x8 *)(sH + (aoff[i + kh][kw] ^ (ks << 6)));
 #pragma unroll
                 for (int j = 0; j < NT; ++j) bfr[j] = *(const bf16x8 *)(sB + (boff[j] ^ (ks << 6)));
-                if (!(p.debug & 8))                                  // ablation: no MFMAs (fragment reads stay)
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-                else acc[0][0][0] += (float)af[ks][0] + (float)bfr[ks][0];
             }
             }
             // tile q+1 (requested one tap ago) must have landed before the barrier publishes it.  vmcnt retires
@@ -305,25 +262,32 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
             if (dma) { if (halo_young) FD_WAIT_VM(NB + HL * HG); else FD_WAIT_VM(NB); }
             else FD_WAIT_VM(0);
             __syncthreads();
-            if (last_tap && slab + 1 < nslab) {     // every wave is done with this slab's halo
+            if (last_tap && has_next) {             // every wave is done with this slab's halo
                 halo_lstore();
                 __syncthreads();
             }
         }
     }
+#undef FD_WAIT_VM
     // F8: the last inline-asm MFMAs must have written their accumulators before the epilogue reads them (the
     // compiler's hazard recognizer does not see into asm); volatile + memory clobber keeps the LDS stores below it
     if constexpr (F8) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 
-    // ---- epilogue: accumulators -> LDS (halo region only, NP passes of PR tile rows) -> row-contiguous 16-byte
-    // stores + GroupNorm partial sums.  Row r of a pass = tile pixel (ty = r >> 4, tx = r & 15).  LDS-only
-    // barriers: the stores of one pass stay in flight behind the next.
+    // ---- stage accumulators, row r = tile pixel (ty = r >> 4, tx = r & 15)
     float *sC = (float *)smem;
-    // (an opaque copy of tid: hoisted out of the tile loop, the per-thread bias / scale vectors would be 16 more live
-    // registers across the MFMA loop, which has none to spare)
-    int te = tid;
-    asm volatile("" : "+v"(te));
-    const int v = te % VPR, r0 = te / VPR;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 64 * wm + 16 * i + fg * 4 + e;
+                const int cc = (BN / WNW) * wn + 16 * j + fr;
+                sC[r * BN + cc] = acc[i][j][e];
+            }
+    __syncthreads();
+    constexpr int VPR = BN / 8, RPP = 256 / VPR;
+    const int v = tid % VPR, r0 = tid / VPR;
     const int n0 = nt * BN + v * 8;
     float bias[8], ssum[8], ssq[8], wsc[8];
 #pragma unroll
@@ -332,42 +296,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
         wsc[e] = (F8 && n0 + e < p.Cout) ? p.w_scale[n0 + e] / p.act_scale : 1.f;
         ssum[e] = ssq[e] = 0.f;
     }
+    bf16 *outp = (bf16 *)p.out + (int64_t)b * p.OH * p.OW * p.ldo + p.offo;
+    if (n0 < p.Cout) {
+        for (int r = r0; r < BM; r += RPP) {
+            const int y = ty0 + (r >> 4), x = tx0 + (r & 15);
+            float val[8];
 #pragma unroll
-    for (int ps = 0; ps < NP; ++ps) {
-        // the wave row group wm owns tile rows [64 wm, 64 wm + 64): its m-tiles inside this pass
+            for (int e = 0; e < 8; ++e) val[e] = F8 ? sC[r * BN + v * 8 + e] * wsc[e] + bias[e] : sC[r * BN + v * 8 + e] + bias[e];
+            if (p.epilogue == FD_EPI_RELU) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int rr = 64 * wm + 16 * i - ps * PR;          // first row of m-tile i relative to the pass
-            if (rr >= 0 && rr < PR) {
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int cc = (BN / WNW) * wn + 16 * j + fr;
-                        sC[(rr + fg * 4 + e) * BN + cc] = acc[i][j][e];
-                    }
+                for (int e = 0; e < 8; ++e) val[e] = fmaxf(val[e], 0.f);
             }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { ssum[e] += val[e]; ssq[e] += val[e] * val[e]; }
+            store8(outp + ((int64_t)y * p.OW + x) * p.ldo + n0, val);
         }
-        lds_barrier();
-        if (n0 < p.Cout) {
-#pragma unroll
-            for (int k = 0; k < PR / RPP; ++k) {
-                const int rl = r0 + k * RPP, r = ps * PR + rl;
-                const int y = ty0 + (r >> 4), x = tx0 + (r & 15);
-                float val[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) val[e] = F8 ? sC[rl * BN + v * 8 + e] * wsc[e] + bias[e] : sC[rl * BN + v * 8 + e] + bias[e];
-                if (p.epilogue == FD_EPI_RELU) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) val[e] = fmaxf(val[e], 0.f);
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { ssum[e] += val[e]; ssq[e] += val[e] * val[e]; }
-                if (!(p.debug & 1) || val[0] == 12345.f)             // ablation: no output stores
-                store8(outp + ((int64_t)y * p.OW + x) * p.ldo + n0, val);
-            }
-        }
-        lds_barrier();                               // the next pass (or the next tile's halo) rewrites the region
     }
     if (p.stats_partial) {
 #pragma unroll
@@ -385,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
                 s_stat[wave][lane * 8 + e][1] = ssq[e];
             }
         }
-        lds_barrier();
+        __syncthreads();
         if (tid < BN) {
             const int n = nt * BN + tid;
             if (n < p.Cout) {
@@ -395,7 +338,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
                 // the workspace holds one entry per 64 output pixels (fd_conv_mtiles): this BM-pixel
                 // tile fills its first entry and zeroes the other BM/64 - 1
                 constexpr int EPT = BM / 64;
-                float *sp = p.stats_partial + (((int64_t)b * EPT * ntiles + EPT * tile) * p.Cout + n) * 2;
+                float *sp = p.stats_partial + (((int64_t)b * EPT * gridDim.x + EPT * blockIdx.x) * p.Cout + n) * 2;
                 sp[0] = s;
                 sp[1] = q;
 #pragma unroll
@@ -405,20 +348,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
                 }
             }
         }
-        // (s_stat is rewritten only after the next tile's tap barriers)
     }
-    if (next_tile) {
-        // the next tile: its first halo slab waits in registers, its first two weight tiles were requested at taps 7 / 8
-        // of the last slab.  Everything this wave issued BEFORE its NSTORE output stores must have landed -- the stores
-        // (and, with GroupNorm sums, the few stat stores of the first waves: counted as well) may stay in flight.
-        ty0 = ((tile + 1) / tiles_x) * TH;
-        tx0 = ((tile + 1) % tiles_x) * TW;
-        halo_lstore();
-        FD_WAIT_VM(NSTORE + 2);
-        __syncthreads();
-    }
-    }
-#undef FD_WAIT_VM
 }
 
 }  // namespace
@@ -449,33 +379,18 @@ int fd_conv3x3_fp8_ok(const fd_conv_params &p) {
     return (p.c0 + p.c1) % 128 == 0 && p.c0 % 16 == 0 && (p.in1 == nullptr || p.c1 % 16 == 0);
 }
 
-// tiles per workgroup (results do not depend on it: every tile's arithmetic and its GroupNorm partial are the same
-// whichever workgroup runs it).  MEASURED (round 3, batch 8, kbench conv3 + A/B of the whole bench on one box): the
-// persistent loop with the next tile's halo and first weight tiles in flight buys nothing -- 64->64 @512: 266 us at 4
-// tiles per workgroup, 260 at 1; whole bench 11.49 vs 11.57 slices/s.  Reason (timing ablations, FD_CONV_DEBUG):
-// vmcnt retires in order, so the wait for the weight tile of tap t + 1 also waits for the halo loads issued before
-// it -- a prefetched halo gets two taps (~0.5 us) to land whatever the loop structure; and with ALL memory traffic
-// and the MFMAs removed the kernel still takes 127 of its 271 us (fragment reads, LDS staging, 9 barriers per slab).
-// Default 1; FD_CONV3_TPW overrides for experiments.
-static int conv3_tpw(int ntiles) {
-    static const int env = [] { const char *e = getenv("FD_CONV3_TPW"); return e ? atoi(e) : 0; }();
-    (void)ntiles;
-    return env > 0 ? env : 1;
-}
-
 int fd_conv3x3_launch(const fd_conv_params &p, hipStream_t s) {
     const bool wide = p.Cout > 64;
     const int th = (!wide && p.OH % 16 == 0) ? 16 : 8;
-    const int ntiles = (p.OH / th) * (p.OW / TW), tpw = conv3_tpw(ntiles);
-    dim3 grid(cdiv(ntiles, tpw), cdiv(p.Cout, wide ? 128 : 64), p.B), block(256);
+    dim3 grid((p.OH / th) * (p.OW / TW), cdiv(p.Cout, wide ? 128 : 64), p.B), block(256);
     if (fd_conv3x3_fp8_ok(p)) {
-        if (wide) hipLaunchKernelGGL((conv3x3_halo_kernel<128, 8, true>), grid, block, 0, s, p, tpw);
-        else if (th == 16) hipLaunchKernelGGL((conv3x3_halo_kernel<64, 16, true>), grid, block, 0, s, p, tpw);
-        else hipLaunchKernelGGL((conv3x3_halo_kernel<64, 8, true>), grid, block, 0, s, p, tpw);
+        if (wide) hipLaunchKernelGGL((conv3x3_halo_kernel<128, 8, true>), grid, block, 0, s, p);
+        else if (th == 16) hipLaunchKernelGGL((conv3x3_halo_kernel<64, 16, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((conv3x3_halo_kernel<64, 8, true>), grid, block, 0, s, p);
         return 0;
     }
-    if (wide) hipLaunchKernelGGL((conv3x3_halo_kernel<128, 8, false>), grid, block, 0, s, p, tpw);
-    else if (th == 16) hipLaunchKernelGGL((conv3x3_halo_kernel<64, 16, false>), grid, block, 0, s, p, tpw);
-    else hipLaunchKernelGGL((conv3x3_halo_kernel<64, 8, false>), grid, block, 0, s, p, tpw);
+    if (wide) hipLaunchKernelGGL((conv3x3_halo_kernel<128, 8, false>), grid, block, 0, s, p);
+    else if (th == 16) hipLaunchKernelGGL((conv3x3_halo_kernel<64, 16, false>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((conv3x3_halo_kernel<64, 8, false>), grid, block, 0, s, p);
     return 0;
 }

@@ -50,6 +50,8 @@ struct PwDwParams {
     bf16 *out_dw; int ld_dw, off_dw;
     int Cz; bf16 *out_z; int ld_z, off_z;
     int H, W;
+    int tpw, ntiles;                  // consecutive tiles per workgroup (round 3: the tap weights / modulation vectors are
+                                      // staged once per workgroup, the 1x1 weight prefetch runs across tiles)
 };
 
 __global__ __launch_bounds__(256, 3) void pwdw_kernel(const PwDwParams p) {
@@ -62,13 +64,12 @@ __global__ __launch_bounds__(256, 3) void pwdw_kernel(const PwDwParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const int tiles_x = p.W / PT_W;
-    const int ty0 = (blockIdx.x / tiles_x) * PT_H, tx0 = (blockIdx.x % tiles_x) * PT_W;
     const int64_t img = blockIdx.y;
     const bf16 *xin = p.x + img * p.H * p.W * p.ld_x + p.off_x;                 // wave-uniform image bases
     bf16 *zout = p.Cz > 0 ? p.out_z + img * p.H * p.W * p.ld_z + p.off_z : nullptr;
     bf16 *dwout = p.out_dw + img * p.H * p.W * p.ld_dw + p.off_dw;
 
-    // ---- phase 0: halo load -> LayerNorm + modulate -> xs
+    // ---- once per workgroup: modulation vectors, tap weights
     if (tid < 64) {
         const float sc = 1.f + p.ln_scale[img * p.ln_ld + tid], sh = p.ln_shift[img * p.ln_ld + tid];
         const float g = p.ln_gamma ? p.ln_gamma[tid] : 1.f, be = p.ln_beta ? p.ln_beta[tid] : 0.f;
@@ -79,23 +80,49 @@ __global__ __launch_bounds__(256, 3) void pwdw_kernel(const PwDwParams p) {
     for (int i = tid; i < p.Cdw; i += 256) sW[5 * p.Cdw + i] = p.b_dw ? __builtin_bit_cast(uint32_t, p.b_dw[i]) : 0u;
     constexpr int NLD = (PMT * 16 * 8) / 256;         // 6 chunks per thread cover all 192 rows
     const int v = tid & 7;
+    // weight rows of a 32-channel group, permuted so that a lane ends up with 8 consecutive channels
+    const int rperm = 8 * (fr >> 2) + (fr & 3);
+    // The 1x1 weights are consumed in 32-row groups: first the Cz/32 pass-through groups (rows Cdw + 32g),
+    // then two groups per depthwise chunk (rows 32g).  Group g+1 is loaded (L2) while group g is in the
+    // MFMAs -- loaded right before use, each group exposed a full L2 round trip (~15k cycles per workgroup).
+    const int nz = p.Cz / 32, ngroups = nz + p.Cdw / 32;
+    bf16x8 wnext[4];
+    auto wload = [&](int g) {
+        const int rb = g < nz ? p.Cdw + 32 * g : 32 * (g - nz);
+        const bf16 *wr = p.w_pw + (int64_t)(rb + rperm) * 64 + fg * 8;
+        wnext[0] = *(const bf16x8 *)(wr);
+        wnext[1] = *(const bf16x8 *)(wr + 32);
+        wnext[2] = *(const bf16x8 *)(wr + 4 * 64);
+        wnext[3] = *(const bf16x8 *)(wr + 4 * 64 + 32);
+    };
+    wload(0);
+    lds_barrier();                                   // sV, sW
+    const int tile0 = blockIdx.x * p.tpw;
+    for (int tt = 0; tt < p.tpw; ++tt) {
+    const int tile = tile0 + tt;
+    if (tile >= p.ntiles) break;                     // workgroup-uniform
+    const int ty0 = (tile / tiles_x) * PT_H, tx0 = (tile % tiles_x) * PT_W;
+    // the halo geometry of a thread does not depend on the tile: an opaque copy of tid keeps it (and ~40 registers)
+    // from being hoisted out of the tile loop (see pwdw_gram_kernel)
+    int tl = tid;
+    asm volatile("" : "+v"(tl));
+    // ---- phase 0: halo load -> LayerNorm + modulate -> xs
     u32x4 raw[NLD];
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
-        const int hp = (tid + k * 256) >> 3;
+        const int hp = (tl + k * 256) >> 3;
         const int hy = div18(hp), hx = hp - hy * PH_X;
         const int yc = min(max(ty0 + hy - 1, 0), p.H - 1), xc = min(max(tx0 + hx - 1, 0), p.W - 1);
         // 32-bit element offsets from a per-image scalar base, 24-bit multiplies: the 64-bit form of this address
         // cost 3 v_mad_u64_u32 + 4 v_mul_lo_u32 (quarter rate) per load
         raw[k] = *(const u32x4 *)(xin + (__umul24(__umul24(yc, p.W) + xc, p.ld_x) + v * 8));
     }
-    lds_barrier();                                   // sV
     float g8[8], b8[8];
     load8(&sV[0][v * 8], g8);
     load8(&sV[1][v * 8], b8);
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
-        const int hp = (tid + k * 256) >> 3;
+        const int hp = (tl + k * 256) >> 3;
         float f[8];
         const bf16x8 xv = __builtin_bit_cast(bf16x8, raw[k]);
 #pragma unroll
@@ -124,30 +151,13 @@ __global__ __launch_bounds__(256, 3) void pwdw_kernel(const PwDwParams p) {
     uint32_t inside = 0;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const int hp = (3 * wave + i) * 16 + fr;
+        const int hp = (3 * (tl >> 6) + i) * 16 + (tl & 15);
         const int hy = div18(hp), hx = hp - hy * PH_X;
         const int yy = ty0 + hy - 1, xx = tx0 + hx - 1;
         if (hp < PHP && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) inside |= 1u << i;
     }
     lds_barrier();
-
-    // weight rows of a 32-channel group, permuted so that a lane ends up with 8 consecutive channels
-    const int rperm = 8 * (fr >> 2) + (fr & 3);
-    // The 1x1 weights are consumed in 32-row groups: first the Cz/32 pass-through groups (rows Cdw + 32g),
-    // then two groups per depthwise chunk (rows 32g).  Group g+1 is loaded (L2) while group g is in the
-    // MFMAs -- loaded right before use, each group exposed a full L2 round trip (~15k cycles per workgroup).
-    const int nz = p.Cz / 32, ngroups = nz + p.Cdw / 32;
-    bf16x8 wnext[4];
-    auto wload = [&](int g) {
-        const int rb = g < nz ? p.Cdw + 32 * g : 32 * (g - nz);
-        const bf16 *wr = p.w_pw + (int64_t)(rb + rperm) * 64 + fg * 8;
-        wnext[0] = *(const bf16x8 *)(wr);
-        wnext[1] = *(const bf16x8 *)(wr + 32);
-        wnext[2] = *(const bf16x8 *)(wr + 4 * 64);
-        wnext[3] = *(const bf16x8 *)(wr + 4 * 64 + 32);
-    };
     int gi = 0;
-    wload(0);
 
     // ---- phase Z: pass-through channels (z), interior pixels only, accumulators -> HBM
     if (p.Cz > 0) {
@@ -160,7 +170,8 @@ __global__ __launch_bounds__(256, 3) void pwdw_kernel(const PwDwParams p) {
         }
         for (int ng = 0; ng < nz; ++ng) {
             const bf16x8 wa[2] = {wnext[0], wnext[1]}, wb[2] = {wnext[2], wnext[3]};
-            if (++gi < ngroups) wload(gi);
+            ++gi;
+            wload(gi < ngroups ? gi : 0);               // after the last group: the next tile's first
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
@@ -213,7 +224,8 @@ __global__ __launch_bounds__(256, 3) void pwdw_kernel(const PwDwParams p) {
 #pragma unroll
         for (int ng = 0; ng < 2; ++ng) {
             const bf16x8 wa[2] = {wnext[0], wnext[1]}, wb[2] = {wnext[2], wnext[3]};
-            if (++gi < ngroups) wload(gi);
+            ++gi;
+            wload(gi < ngroups ? gi : 0);               // after the last group: the next tile's first
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
@@ -283,7 +295,8 @@ __global__ __launch_bounds__(256, 3) void pwdw_kernel(const PwDwParams p) {
             const int y = ty0 + 4 * rh + rr, x = tx0 + px;
             store8(dwout + (__umul24(__umul24(y, p.W) + x, p.ld_dw) + c0), acc);
         }
-        lds_barrier();                               // ts is rewritten by the next chunk
+        lds_barrier();                               // ts is rewritten by the next chunk (xs by the next tile)
+    }
     }
 }
 
@@ -792,7 +805,10 @@ extern "C" int fd_pw_dw3x3(int dtype, const void *x, int ld_x, int off_x, int Ci
     p.out_dw = (bf16 *)out_dw; p.ld_dw = ld_dw; p.off_dw = off_dw;
     p.Cz = Cz; p.out_z = (bf16 *)out_z; p.ld_z = ld_z; p.off_z = off_z;
     p.H = H; p.W = W;
-    dim3 grid((H / PT_H) * (W / PT_W), B), block(256);
+    p.ntiles = (H / PT_H) * (W / PT_W);
+    static const int tpw_env = [] { const char *e = getenv("FD_PWDW_TPW"); return e ? atoi(e) : 0; }();
+    p.tpw = tpw_env > 0 ? tpw_env : 4;
+    dim3 grid((p.ntiles + p.tpw - 1) / p.tpw, B), block(256);
     hipLaunchKernelGGL(pwdw_kernel, grid, block, 0, (hipStream_t)stream, p);
     FD_LAUNCH_OK("fd_pw_dw3x3");
     return FD_OK;

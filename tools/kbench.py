@@ -119,6 +119,29 @@ def bench_conv3(B, shapes=None):
         print(f"conv3x3 {cin:4d}->{cout:4d} @{OH} up={int(up)} B={B}: {t:8.1f} us  {fl / t / 1e6:7.1f} TFLOP/s  ({fl / t / 1e6 / 2500:.3f} of peak)", flush=True)
 
 
+def bench_pwdw(B, sizes=((512, 512), (256, 256))):
+    """in_proj variant of the fused LN -> 1x1 -> depthwise kernel (Cdw = 128 + SiLU, Cz = 128)"""
+    from founddiff_amd import _lib as L
+    from founddiff_amd.engine import DAEngine
+    s = torch.cuda.current_stream().cuda_stream
+    for H, W in sizes:
+        torch.manual_seed(0)
+        x = torch.randn(B, H, W, 64, device="cuda").to(torch.bfloat16)
+        mod = torch.randn(B, 384, device="cuda") * 0.5
+        g, be = torch.randn(64, device="cuda"), torch.randn(64, device="cuda")
+        wpw = (torch.randn(256, 64, device="cuda") / 8).to(torch.bfloat16)
+        wm = DAEngine._dw_masked((torch.randn(128, 9, device="cuda") / 3).t().contiguous())
+        bdw = torch.randn(128, device="cuda")
+        xc = torch.empty(B, H, W, 128, device="cuda", dtype=torch.bfloat16)
+        xz = torch.empty(B, H, W, 256, device="cuda", dtype=torch.bfloat16)
+
+        def run():
+            L.call("fd_pw_dw3x3", L.FD_BF16, x.data_ptr(), 64, 0, 64, g.data_ptr(), be.data_ptr(), 1e-5, mod.data_ptr(), mod.data_ptr() + 256,
+                   384, wpw.data_ptr(), 128, wm.data_ptr(), bdw.data_ptr(), 1, xc.data_ptr(), 128, 0, 128, xz.data_ptr(), 256, 128, B, H, W, s)
+        t = timeit(run)
+        print(f"pwdw in_proj {H}x{W} B={B}: {t:8.1f} us  chk={float(xc.float().abs().mean()):.5f} {float(xz[..., 128:].float().abs().mean()):.5f}", flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("what")
