@@ -26,6 +26,40 @@ constexpr int PT_H = 8, PT_W = 16, PH_Y = PT_H + 2, PH_X = PT_W + 2, PHP = PH_Y 
 constexpr int PMT = (PHP + 15) / 16;                                                      // 12 m-tiles
 constexpr int XS_B = PMT * 16 * 128, TS_B = PHP * 128;
 typedef __attribute__((ext_vector_type(2))) __bf16 pd_bf16x2;
+typedef _Float16 pd_h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 pd_h8 __attribute__((ext_vector_type(8)));
+
+// ---- the depthwise 3x3 on PACKED fp16 (round 3).  The 1x1 output t lives in LDS as fp16 channel pairs (11 mantissa
+// bits instead of bf16's 8: the tile never leaves the CU, so its format is free), the tap weights are fp16 channel
+// pairs, and one v_pk_fma_f16 does a tap for TWO channels: 36 instructions per row of 8 channels instead of 32 v_perm +
+// 40 v_dot2 (the bf16 form had to gather tap pairs per channel because the dot product contracts WITHIN a register).
+// The 9-term sum is accumulated in fp16 (~7e-4 rms relative, below the bf16 rounding of the output it feeds; the
+// input side gains 3 bits).  v_cvt_pkrtz_f16_f32 saturates instead of producing infinities (|t| > 65504).
+__device__ __forceinline__ uint32_t pk_h2(float a, float b) { return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a, b)); }
+
+__device__ __forceinline__ void dw_row_f16(const uint32_t (&win)[3][3][4], int rr, const uint32_t (&wt)[9][4],
+                                           const uint32_t (&b2)[4], uint32_t (&out)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        pd_h2 acc = __builtin_bit_cast(pd_h2, b2[j]);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+                acc = __builtin_elementwise_fma(__builtin_bit_cast(pd_h2, win[(rr + dy) % 3][dx][j]),
+                                                __builtin_bit_cast(pd_h2, wt[dy * 3 + dx][j]), acc);
+        out[j] = __builtin_bit_cast(uint32_t, acc);
+    }
+}
+
+__device__ __forceinline__ void unpack_h8(const uint32_t (&a)[4], float (&f)[8]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const pd_h2 v = __builtin_bit_cast(pd_h2, a[j]);
+        f[2 * j] = (float)v.x;
+        f[2 * j + 1] = (float)v.y;
+    }
+}
 
 // row & 7 (not the generic kernel's (row >> 1) & 7): conflict-free for 16 consecutive rows starting at ANY row -- the
 // z phase reads its fragments from tile rows that start at odd halo pixels (fd_conv3x3.hip, swz)
@@ -58,7 +92,7 @@ __global__ __launch_bounds__(256, 3) void pwdw_kernel(const PwDwParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char xs[XS_B];     // LN'd input halo, [192][64] bf16
     __shared__ __attribute__((aligned(16))) unsigned char ts[TS_B];     // 1x1 output of one chunk, [180][64] bf16
     __shared__ float sV[2][64];
-    // tap-pair words [5][Cdw] + bias [Cdw] of the depthwise conv, staged once: a global load issued after a phase's
+    // fp16 tap weights [9][Cdw/2] (+ bias [Cdw] at word 5 Cdw) of the depthwise conv, staged once: a global load issued after a phase's
     // stores cannot be waited for without waiting for those stores too (vmcnt retires in order)
     __shared__ __attribute__((aligned(16))) uint32_t sW[6 * 192];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -76,7 +110,7 @@ __global__ __launch_bounds__(256, 3) void pwdw_kernel(const PwDwParams p) {
         sV[0][tid] = g * sc;
         sV[1][tid] = be * sc + sh;
     }
-    for (int i = tid; i < 5 * p.Cdw; i += 256) sW[i] = p.w_dw[i];
+    for (int i = tid; i < 9 * p.Cdw / 2; i += 256) sW[i] = p.w_dw[i];         // [9][Cdw/2] fp16 channel pairs
     for (int i = tid; i < p.Cdw; i += 256) sW[5 * p.Cdw + i] = p.b_dw ? __builtin_bit_cast(uint32_t, p.b_dw[i]) : 0u;
     constexpr int NLD = (PMT * 16 * 8) / 256;         // 6 chunks per thread cover all 192 rows
     const int v = tid & 7;
@@ -204,15 +238,16 @@ __global__ __launch_bounds__(256, 3) void pwdw_kernel(const PwDwParams p) {
         // tap weights of this chunk ([5][Cdw] words, see fd_pw_dw3x3): issued
         // before the MFMAs so they arrive during phase 1
         const int c0 = 64 * ch + cv * 8;
-        uint32_t wt[5][8];
+        uint32_t wt[9][4], b2[4];
         float bs[8];
 #pragma unroll
-        for (int t = 0; t < 5; ++t) {
-            const u32x4 w0 = *(const u32x4 *)(sW + t * p.Cdw + c0), w1 = *(const u32x4 *)(sW + t * p.Cdw + c0 + 4);
+        for (int t = 0; t < 9; ++t) {
+            const u32x4 w0 = *(const u32x4 *)(sW + t * (p.Cdw / 2) + c0 / 2);
             wt[t][0] = w0.x; wt[t][1] = w0.y; wt[t][2] = w0.z; wt[t][3] = w0.w;
-            wt[t][4] = w1.x; wt[t][5] = w1.y; wt[t][6] = w1.z; wt[t][7] = w1.w;
         }
         load8((const float *)(sW + 5 * p.Cdw + c0), bs);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b2[j] = pk_h2(bs[2 * j], bs[2 * j + 1]);
         // phase 1: t[hp][64 ch] = W_chunk . xn, 3 m-tiles per wave (fragments re-read per chunk: registers
         // are the scarce resource of this kernel, LDS bandwidth is not)
         bf16x8 xh[3][2];
@@ -236,13 +271,10 @@ __global__ __launch_bounds__(256, 3) void pwdw_kernel(const PwDwParams p) {
                 }
                 const int hp = (3 * wave + i) * 16 + fr;
                 const bool in = (inside >> i) & 1;
-                bf16x8 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    o[e] = (bf16)(in ? a0[e] : 0.f);
-                    o[4 + e] = (bf16)(in ? a1[e] : 0.f);
-                }
-                if (hp < PHP) *(bf16x8 *)(ts + ts_off(hp, 4 * ng + fg)) = o;
+                // fp16 pairs (dw_row_f16); out-of-image halo pixels are the depthwise conv's zero padding
+                u32x4 o = {pk_h2(a0[0], a0[1]), pk_h2(a0[2], a0[3]), pk_h2(a1[0], a1[1]), pk_h2(a1[2], a1[3])};
+                if (!in) o = (u32x4){0, 0, 0, 0};
+                if (hp < PHP) *(u32x4 *)(ts + ts_off(hp, 4 * ng + fg)) = o;
             }
         }
         lds_barrier();
@@ -263,31 +295,10 @@ __global__ __launch_bounds__(256, 3) void pwdw_kernel(const PwDwParams p) {
                 uint32_t *wr_ = win[(rr + 2) % 3][dx];
                 wr_[0] = t4.x; wr_[1] = t4.y; wr_[2] = t4.z; wr_[3] = t4.w;
             }
+            uint32_t o2[4];
+            dw_row_f16(win, rr, wt, b2, o2);
             float acc[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] = bs[e];
-            // tap pairs: the dot2 contracts TWO taps of one channel -- v_perm gathers the channel's
-            // two tap inputs into one word; the weight word holds the two tap weights (40 weight
-            // registers per 8 channels instead of 72 pre-masked ones, same instruction count)
-#pragma unroll
-            for (int pr = 0; pr < 4; ++pr)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t xa = pr < 3 ? win[rr % 3][pr][j] : win[(rr + 2) % 3][0][j];
-                    const uint32_t xb = pr < 3 ? win[(rr + 1) % 3][pr][j] : win[(rr + 2) % 3][1][j];
-                    const uint32_t lo = __builtin_amdgcn_perm(xb, xa, 0x05040100);    // (xa.lo, xb.lo): channel 2j
-                    const uint32_t hi = __builtin_amdgcn_perm(xb, xa, 0x07060302);    // (xa.hi, xb.hi): channel 2j+1
-                    acc[2 * j] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(pd_bf16x2, lo),
-                        __builtin_bit_cast(pd_bf16x2, wt[pr][2 * j]), acc[2 * j], false);
-                    acc[2 * j + 1] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(pd_bf16x2, hi),
-                        __builtin_bit_cast(pd_bf16x2, wt[pr][2 * j + 1]), acc[2 * j + 1], false);
-                }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {              // the ninth tap alone: weight in the channel's half, 0 in the other
-                const pd_bf16x2 xv = __builtin_bit_cast(pd_bf16x2, win[(rr + 2) % 3][2][j]);
-                acc[2 * j] = __builtin_amdgcn_fdot2_f32_bf16(xv, __builtin_bit_cast(pd_bf16x2, wt[4][2 * j]), acc[2 * j], false);
-                acc[2 * j + 1] = __builtin_amdgcn_fdot2_f32_bf16(xv, __builtin_bit_cast(pd_bf16x2, wt[4][2 * j + 1]), acc[2 * j + 1], false);
-            }
+            unpack_h8(o2, acc);
             if (p.dw_silu) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) acc[e] = fd_silu(acc[e]);
@@ -323,7 +334,7 @@ struct PwGramParams {
     const bf16 *x; int ld_x, off_x;
     const float *ln_gamma, *ln_beta, *ln_shift, *ln_scale; int ln_ld; float ln_eps;
     const bf16 *w_pw;                 // [192][64]: q | k | v rows
-    const uint32_t *w_dw;             // [5][192]
+    const uint32_t *w_dw;             // [9][96] fp16 channel pairs
     bf16 *out_v; int ld_v, off_v;
     float *part; int nblk;            // [B][2 heads][nblk][1024 + 64]
     int H, W, tpw, ntiles;
@@ -357,7 +368,7 @@ __global__ __launch_bounds__(256, 3) void pwdw_gram_kernel(const PwGramParams p)
         sV[0][tid] = g * sc;
         sV[1][tid] = be * sc + sh;
     }
-    for (int i = tid; i < 5 * CDW; i += 256) sW[i] = p.w_dw[i];
+    for (int i = tid; i < 9 * CDW / 2; i += 256) sW[i] = p.w_dw[i];           // [9][96] fp16 channel pairs
     constexpr int NLD = (PMT * 16 * 8) / 256;
     const int v = tid & 7;
     const int rperm = 8 * (fr >> 2) + (fr & 3);
@@ -468,13 +479,9 @@ __global__ __launch_bounds__(256, 3) void pwdw_gram_kernel(const PwGramParams p)
                     }
                     const int hp = (3 * wave + i) * 16 + fr;
                     const bool in = (inside >> i) & 1;
-                    bf16x8 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        o[e] = (bf16)(in ? a0[e] : 0.f);
-                        o[4 + e] = (bf16)(in ? a1[e] : 0.f);
-                    }
-                    if (hp < PHP) *(bf16x8 *)(ts + ts_off(hp, 4 * ng + fg)) = o;
+                    u32x4 o = {pk_h2(a0[0], a0[1]), pk_h2(a0[2], a0[3]), pk_h2(a1[0], a1[1]), pk_h2(a1[2], a1[3])};
+                    if (!in) o = (u32x4){0, 0, 0, 0};
+                    if (hp < PHP) *(u32x4 *)(ts + ts_off(hp, 4 * ng + fg)) = o;
                 }
             }
             lds_barrier();
@@ -484,14 +491,14 @@ __global__ __launch_bounds__(256, 3) void pwdw_gram_kernel(const PwGramParams p)
                 for (int rr = 0; rr < 4; ++rr)
                     *(u32x4 *)(xs + gt_off((4 * rh + rr) * PT_W + px, cv)) = pk[rr];
             }
-            // phase 2: depthwise 3x3 on ts
+            // phase 2: depthwise 3x3 on ts (packed fp16, dw_row_f16)
             const int c0 = 64 * ch + cv * 8;
-            uint32_t wt[5][8];
+            uint32_t wt[9][4];
+            const uint32_t b2[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-            for (int t = 0; t < 5; ++t) {
-                const u32x4 w0 = *(const u32x4 *)(sW + t * CDW + c0), w1 = *(const u32x4 *)(sW + t * CDW + c0 + 4);
+            for (int t = 0; t < 9; ++t) {
+                const u32x4 w0 = *(const u32x4 *)(sW + t * (CDW / 2) + c0 / 2);
                 wt[t][0] = w0.x; wt[t][1] = w0.y; wt[t][2] = w0.z; wt[t][3] = w0.w;
-                wt[t][4] = w1.x; wt[t][5] = w1.y; wt[t][6] = w1.z; wt[t][7] = w1.w;
             }
             uint32_t win[3][3][4];
 #pragma unroll
@@ -509,36 +516,15 @@ __global__ __launch_bounds__(256, 3) void pwdw_gram_kernel(const PwGramParams p)
                     uint32_t *wr_ = win[(rr + 2) % 3][dx];
                     wr_[0] = t4.x; wr_[1] = t4.y; wr_[2] = t4.z; wr_[3] = t4.w;
                 }
-                float acc[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-#pragma unroll
-                for (int pr = 0; pr < 4; ++pr)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const uint32_t xa = pr < 3 ? win[rr % 3][pr][j] : win[(rr + 2) % 3][0][j];
-                        const uint32_t xb = pr < 3 ? win[(rr + 1) % 3][pr][j] : win[(rr + 2) % 3][1][j];
-                        const uint32_t lo = __builtin_amdgcn_perm(xb, xa, 0x05040100);
-                        const uint32_t hi = __builtin_amdgcn_perm(xb, xa, 0x07060302);
-                        acc[2 * j] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(pd_bf16x2, lo),
-                            __builtin_bit_cast(pd_bf16x2, wt[pr][2 * j]), acc[2 * j], false);
-                        acc[2 * j + 1] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(pd_bf16x2, hi),
-                            __builtin_bit_cast(pd_bf16x2, wt[pr][2 * j + 1]), acc[2 * j + 1], false);
-                    }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const pd_bf16x2 xv = __builtin_bit_cast(pd_bf16x2, win[(rr + 2) % 3][2][j]);
-                    acc[2 * j] = __builtin_amdgcn_fdot2_f32_bf16(xv, __builtin_bit_cast(pd_bf16x2, wt[4][2 * j]), acc[2 * j], false);
-                    acc[2 * j + 1] = __builtin_amdgcn_fdot2_f32_bf16(xv, __builtin_bit_cast(pd_bf16x2, wt[4][2 * j + 1]), acc[2 * j + 1], false);
-                }
+                uint32_t o2[4];
+                dw_row_f16(win, rr, wt, b2, o2);
                 if (ci == 0) {
+                    float acc[8];
+                    unpack_h8(o2, acc);
                     const int y = ty0 + 4 * rh + rr, x = tx0 + px;
                     store8(vout + (__umul24(__umul24(y, p.W) + x, p.ld_v) + cv * 8), acc);
                 } else {
-                    bf16x8 o;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (bf16)acc[e];
-                    pk[rr] = __builtin_bit_cast(u32x4, o);
+                    pk[rr] = (u32x4){o2[0], o2[1], o2[2], o2[3]};      // q / k stay fp16: the Gram runs on the f16 MFMA
                 }
             }
             lds_barrier();                               // every read of ts is done
@@ -560,14 +546,15 @@ __global__ __launch_bounds__(256, 3) void pwdw_gram_kernel(const PwGramParams p)
                 b0[hf] = lds_tr16(ts + rowb + ((ck0 ^ sw) << 4) + sub);
                 b1[hf] = lds_tr16(ts + rowb + ((ck1 ^ sw) << 4) + sub);
             }
-            const bf16x8 A = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a[0], a[1], 0, 1, 2, 3, 4, 5, 6, 7));
-            const bf16x8 B0 = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0[0], b0[1], 0, 1, 2, 3, 4, 5, 6, 7));
-            const bf16x8 B1 = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b1[0], b1[1], 0, 1, 2, 3, 4, 5, 6, 7));
-            gacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B0, gacc[0], 0, 0, 0);
-            gacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B1, gacc[1], 0, 0, 0);
-            gnq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, A, gnq, 0, 0, 0);
-            const bf16x8 Bm = mb ? B1 : B0;
-            gnk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bm, Bm, gnk, 0, 0, 0);
+            // q, k tiles hold fp16 (the depthwise accumulators as they are): the f16 MFMA, same rate as bf16
+            const pd_h8 A = __builtin_bit_cast(pd_h8, __builtin_shufflevector(a[0], a[1], 0, 1, 2, 3, 4, 5, 6, 7));
+            const pd_h8 B0 = __builtin_bit_cast(pd_h8, __builtin_shufflevector(b0[0], b0[1], 0, 1, 2, 3, 4, 5, 6, 7));
+            const pd_h8 B1 = __builtin_bit_cast(pd_h8, __builtin_shufflevector(b1[0], b1[1], 0, 1, 2, 3, 4, 5, 6, 7));
+            gacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B0, gacc[0], 0, 0, 0);
+            gacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B1, gacc[1], 0, 0, 0);
+            gnq = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, A, gnq, 0, 0, 0);
+            const pd_h8 Bm = mb ? B1 : B0;
+            gnk = __builtin_amdgcn_mfma_f32_16x16x32_f16(Bm, Bm, gnk, 0, 0, 0);
         }
         lds_barrier();                                   // the next tile's phase 0 rewrites xs
     }
@@ -606,7 +593,7 @@ __global__ __launch_bounds__(256, 3) void pwdw_gram_kernel(const PwGramParams p)
 struct DwGramParams {
     const bf16 *qkv; int ld;          // [B,H,W,ld]: q at channel 0, k at channel C
     int C;
-    const uint32_t *w_dw;             // [5][3C] tap-pair words (fd_pw_dw3x3's layout)
+    const uint32_t *w_dw;             // [9][3C/2] fp16 channel pairs (fd_pw_dw3x3's layout)
     float *part; int nblk;            // [B][C/32 heads][nblk][1024 + 64]
     int H, W, tpw, ntiles;
 };
@@ -622,11 +609,11 @@ __global__ __launch_bounds__(256, 3) void dwconv_gram_kernel(const DwGramParams 
     const bf16 *base = p.qkv + img * p.H * p.W * p.ld;
     const int cv = tid & 7, px = (tid >> 3) & 15, rh = tid >> 7;
     const int C3 = 3 * p.C;
-    // tap-pair words of the 64 q and the 64 k channels, staged once: [2][5][64] words
-    __shared__ __attribute__((aligned(16))) uint32_t sWd[2 * 5 * 64];
-    for (int i = tid; i < 2 * 5 * 64; i += 256) {
-        const int qk = i / 320, t = (i % 320) / 64, c = i % 64;
-        sWd[i] = p.w_dw[t * C3 + qk * p.C + 64 * hp2 + c];
+    // fp16 tap weights (channel pairs) of the 64 q and the 64 k channels, staged once: [2][9][32] words
+    __shared__ __attribute__((aligned(16))) uint32_t sWd[2 * 9 * 32];
+    for (int i = tid; i < 2 * 9 * 32; i += 256) {
+        const int qk = i / 288, t = (i % 288) / 32, c2 = i % 32;
+        sWd[i] = p.w_dw[t * (C3 / 2) + (qk * p.C + 64 * hp2) / 2 + c2];
     }
     int toff[6][3];
 #pragma unroll
@@ -640,11 +627,12 @@ __global__ __launch_bounds__(256, 3) void dwconv_gram_kernel(const DwGramParams 
 
     // one depthwise pass over the halo image in hs: this thread's 4 rows x 8 channels, packed bf16
     auto dw = [&](int qk, u32x4 (&pk)[4]) {
-        uint32_t wt[5][8];
+        uint32_t wt[9][4];
+        const uint32_t b2[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int t = 0; t < 5; ++t) {
-            const u32x4 a0 = *(const u32x4 *)(sWd + (qk * 5 + t) * 64 + cv * 8), a1 = *(const u32x4 *)(sWd + (qk * 5 + t) * 64 + cv * 8 + 4);
-            wt[t][0] = a0.x; wt[t][1] = a0.y; wt[t][2] = a0.z; wt[t][3] = a0.w; wt[t][4] = a1.x; wt[t][5] = a1.y; wt[t][6] = a1.z; wt[t][7] = a1.w;
+        for (int t = 0; t < 9; ++t) {
+            const u32x4 a0 = *(const u32x4 *)(sWd + (qk * 9 + t) * 32 + cv * 4);
+            wt[t][0] = a0.x; wt[t][1] = a0.y; wt[t][2] = a0.z; wt[t][3] = a0.w;
         }
         uint32_t win[3][3][4];
 #pragma unroll
@@ -662,32 +650,9 @@ __global__ __launch_bounds__(256, 3) void dwconv_gram_kernel(const DwGramParams 
                 uint32_t *wr_ = win[(rr + 2) % 3][dx];
                 wr_[0] = t4.x; wr_[1] = t4.y; wr_[2] = t4.z; wr_[3] = t4.w;
             }
-            float acc[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-#pragma unroll
-            for (int pr = 0; pr < 4; ++pr)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t xa = pr < 3 ? win[rr % 3][pr][j] : win[(rr + 2) % 3][0][j];
-                    const uint32_t xb = pr < 3 ? win[(rr + 1) % 3][pr][j] : win[(rr + 2) % 3][1][j];
-                    const uint32_t lo = __builtin_amdgcn_perm(xb, xa, 0x05040100);
-                    const uint32_t hi = __builtin_amdgcn_perm(xb, xa, 0x07060302);
-                    acc[2 * j] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(pd_bf16x2, lo),
-                        __builtin_bit_cast(pd_bf16x2, wt[pr][2 * j]), acc[2 * j], false);
-                    acc[2 * j + 1] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(pd_bf16x2, hi),
-                        __builtin_bit_cast(pd_bf16x2, wt[pr][2 * j + 1]), acc[2 * j + 1], false);
-                }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const pd_bf16x2 xv = __builtin_bit_cast(pd_bf16x2, win[(rr + 2) % 3][2][j]);
-                acc[2 * j] = __builtin_amdgcn_fdot2_f32_bf16(xv, __builtin_bit_cast(pd_bf16x2, wt[4][2 * j]), acc[2 * j], false);
-                acc[2 * j + 1] = __builtin_amdgcn_fdot2_f32_bf16(xv, __builtin_bit_cast(pd_bf16x2, wt[4][2 * j + 1]), acc[2 * j + 1], false);
-            }
-            bf16x8 o;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (bf16)acc[e];
-            pk[rr] = __builtin_bit_cast(u32x4, o);
+            uint32_t o2[4];
+            dw_row_f16(win, rr, wt, b2, o2);
+            pk[rr] = (u32x4){o2[0], o2[1], o2[2], o2[3]};
         }
     };
 
@@ -717,7 +682,15 @@ __global__ __launch_bounds__(256, 3) void dwconv_gram_kernel(const DwGramParams 
             for (int k = 0; k < NLD; ++k) {
                 const int idx = tl + k * 256, hp = idx >> 3;
                 const u32x4 z4 = {0, 0, 0, 0};
-                if (hp < PHP) *(u32x4 *)(hs + ts_off(hp, idx & 7)) = ((okm >> k) & 1) ? r[k] : z4;
+                // bf16 (HBM) -> fp16 pairs (dw_row_f16): exact for |x| < 65504 with <= 11 significant bits -- every bf16 is
+                const u32x4 rv = r[k];
+                const uint32_t rw[4] = {rv.x, rv.y, rv.z, rv.w};
+                uint32_t hw4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    hw4[e] = pk_h2(__builtin_bit_cast(float, rw[e] << 16), __builtin_bit_cast(float, rw[e] & 0xffff0000u));
+                const u32x4 h4 = {hw4[0], hw4[1], hw4[2], hw4[3]};
+                if (hp < PHP) *(u32x4 *)(hs + ts_off(hp, idx & 7)) = ((okm >> k) & 1) ? h4 : z4;
             }
         };
         u32x4 pk[4];
@@ -746,14 +719,15 @@ __global__ __launch_bounds__(256, 3) void dwconv_gram_kernel(const DwGramParams 
                 b0[hf] = lds_tr16(hs + rowb + ((ck0 ^ sw) << 4) + sub);
                 b1[hf] = lds_tr16(hs + rowb + ((ck1 ^ sw) << 4) + sub);
             }
-            const bf16x8 A = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a[0], a[1], 0, 1, 2, 3, 4, 5, 6, 7));
-            const bf16x8 B0 = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0[0], b0[1], 0, 1, 2, 3, 4, 5, 6, 7));
-            const bf16x8 B1 = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b1[0], b1[1], 0, 1, 2, 3, 4, 5, 6, 7));
-            gacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B0, gacc[0], 0, 0, 0);
-            gacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B1, gacc[1], 0, 0, 0);
-            gnq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, A, gnq, 0, 0, 0);
-            const bf16x8 Bm = mb ? B1 : B0;
-            gnk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bm, Bm, gnk, 0, 0, 0);
+            // q, k tiles hold fp16 (the depthwise accumulators as they are): the f16 MFMA, same rate as bf16
+            const pd_h8 A = __builtin_bit_cast(pd_h8, __builtin_shufflevector(a[0], a[1], 0, 1, 2, 3, 4, 5, 6, 7));
+            const pd_h8 B0 = __builtin_bit_cast(pd_h8, __builtin_shufflevector(b0[0], b0[1], 0, 1, 2, 3, 4, 5, 6, 7));
+            const pd_h8 B1 = __builtin_bit_cast(pd_h8, __builtin_shufflevector(b1[0], b1[1], 0, 1, 2, 3, 4, 5, 6, 7));
+            gacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B0, gacc[0], 0, 0, 0);
+            gacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B1, gacc[1], 0, 0, 0);
+            gnq = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, A, gnq, 0, 0, 0);
+            const pd_h8 Bm = mb ? B1 : B0;
+            gnk = __builtin_amdgcn_mfma_f32_16x16x32_f16(Bm, Bm, gnk, 0, 0, 0);
         }
         lds_barrier();                                  // the next tile's halo rewrites hs
     }

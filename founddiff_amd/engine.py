@@ -138,12 +138,11 @@ class DAEngine:
 
     @staticmethod
     def _dw_masked(w9c):
-        """[9][C] fp32 taps (tap = 3*dy + dx) -> [5][C] int32 words of bf16 pairs in the layout
-        include/founddiff_hip.h documents for fd_pw_dw3x3."""
-        b = w9c.to(torch.bfloat16).view(torch.int16).to(torch.int32) & 0xFFFF
-        odd = (torch.arange(w9c.shape[1], device=w9c.device) & 1).to(torch.int32) * 16
-        rows = [b[p] | (b[3 + p] << 16) for p in range(3)] + [b[6] | (b[7] << 16), b[8] << odd]
-        return torch.stack(rows).contiguous()
+        """[9][C] fp32 taps (tap = 3*dy + dx) -> [9][C/2] int32 words of fp16 CHANNEL pairs (low half = channel 2j, high =
+        2j + 1): the operand layout of the packed-fp16 depthwise of fd_pw_dw3x3 / fd_pw_dw3x3_gram / fd_dwconv_gram
+        (include/founddiff_hip.h)."""
+        h = w9c.to(torch.float16).view(torch.int16).to(torch.int32) & 0xFFFF
+        return (h[:, 0::2] | (h[:, 1::2] << 16)).contiguous()
 
     def _pack_mamba(self, s):
         m = s.sub("mamba.")

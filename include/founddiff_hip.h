@@ -178,10 +178,9 @@ int fd_dwconv3x3(int dtype, const void *in, int ld_in, int off_in, const float *
  *   x      [B,H,W,ld_x] channels [off_x, +Cin)
  *   w_pw   bf16 [Cdw + Cz][Cin]: rows [0, Cdw) feed the depthwise conv, rows [Cdw, Cdw+Cz) are passed
  *          through SiLU to out_z (Cz = 0: none)
- *   w_dw   [5][Cdw] 32-bit words of bf16 tap weights k[dy][dx], packed for v_dot2c_f32_bf16:
- *          word p = 0..2: (low, high) = (k[0][p], k[1][p]);  word 3: (k[2][0], k[2][1]);
- *          word 4: k[2][2] in the LOW half for even channels, in the HIGH half for odd ones.
- *          b_dw [Cdw] fp32 or NULL
+ *   w_dw   [9][Cdw/2] 32-bit words of fp16 tap weights, tap = 3*dy + dx, word j = (channel 2j low, 2j+1 high): the
+ *          depthwise runs on v_pk_fma_f16 (the 1x1 output is kept in LDS as fp16 channel pairs, the 9-tap sum is
+ *          accumulated in fp16; bias and SiLU in fp32).  b_dw [Cdw] fp32 or NULL
  *   ln_*   as fd_conv_params' LN_MOD prologue (gamma/beta may be NULL)
  * fd_pw_dw3x3_ok: 1 if the shape is served (callers fall back to fd_conv2d + fd_dwconv3x3).   */
 int fd_pw_dw3x3_ok(int dtype, int Cin, int Cdw, int Cz, int H, int W);
@@ -196,7 +195,7 @@ int fd_pw_dw3x3(int dtype, const void *x, int ld_x, int off_x, int Cin, const fl
  * reach HBM: only v (out_v, [B,H,W,ld_v] channels [off_v, +64)) and one partial per workgroup do --
  * partial [B][2 heads][nblk][1024 + 64] fp32 in fd_chan_attn_gram's layout (Gram rows = q channels; then sum q^2,
  * sum k^2), nblk = fd_pw_dw3x3_gram_nblk(H, W), reduced in fixed order by fd_chan_attn_weff.  bf16, Cin = 64 (two
- * heads), w_pw [192][64] (q | k | v rows), w_dw [5][192] as for fd_pw_dw3x3, no bias.                       */
+ * heads), w_pw [192][64] (q | k | v rows), w_dw [9][96] as for fd_pw_dw3x3, no bias; q and k are fp16 on chip (f16 MFMA).                       */
 int fd_pw_dw3x3_gram_ok(int dtype, int Cin, int H, int W);
 int fd_pw_dw3x3_gram_nblk(int H, int W);
 int fd_pw_dw3x3_gram(int dtype, const void *x, int ld_x, int off_x, int Cin, const float *ln_gamma,
@@ -206,7 +205,7 @@ int fd_pw_dw3x3_gram(int dtype, const void *x, int ld_x, int off_x, int Cin, con
 
 /* ---- qkv_dwconv + L2 norms + q k^T for the wider blocks (C >= 128, src/DADiff.py:267-276): the depthwise 3x3 of the q
  * and k channels of a qkv tensor [B,H,W,ld] (q at channel 0, k at channel C) feeding the per-head Gram directly -- q and k
- * after the depthwise conv never reach HBM.  v keeps fd_dwconv3x3.  w_dw [5][3C] in fd_pw_dw3x3's tap-pair layout;
+ * after the depthwise conv never reach HBM.  v keeps fd_dwconv3x3.  w_dw [9][3C/2] in fd_pw_dw3x3's fp16 layout;
  * partial [B][C/32][nblk][1024 + 64] in fd_chan_attn_gram's layout, nblk = fd_dwconv_gram_nblk(H, W).            */
 int fd_dwconv_gram_ok(int dtype, int C, int H, int W);
 int fd_dwconv_gram_nblk(int H, int W);

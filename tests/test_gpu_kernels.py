@@ -690,12 +690,19 @@ def test_pw_dw3x3_gram(eng_factory, hw):
     assert torch.equal(v[..., 8:], qkv2[..., 128:]) and float(v[..., :8].float().abs().max()) == 0.0
     g0, g1 = part0.double().sum(2).cpu(), part1.double().sum(2).cpu()
     assert bool(torch.isfinite(g1).all())
-    assert rel_err(g1[..., :1024], g0[..., :1024]) < 1e-5 and rel_err(g1[..., 1024:], g0[..., 1024:]) < 1e-5
-    # fp32 composition from the stored q, k (the Gram of exactly those bf16 values)
-    q, k = qkv2[..., :64].float().cpu().reshape(B, H * W, 2, 32), qkv2[..., 64:128].float().cpu().reshape(B, H * W, 2, 32)
+    # the unfused pair rounds q, k to bf16 on their way through HBM; fused they stay fp16 on chip (3 more bits): the
+    # Gram entries (sums over all pixels of products with random signs) agree to ~1e-3 of the largest entry
+    assert rel_err(g1[..., :1024], g0[..., :1024]) < 3e-3 and rel_err(g1[..., 1024:], g0[..., 1024:]) < 3e-3
+    # fp32 composition (LayerNorm -> 1x1 -> depthwise in fp32 from the same bf16 inputs / weights): the fused kernel is the
+    # CLOSER of the two
+    xn = F.layer_norm(x, (Cin,), None, None, 1e-6) * (1 + mod[:, None, None, Cin:2 * Cin]) + mod[:, None, None, :Cin]
+    t = F.linear(bf(xn), wpw)
+    dwo = F.conv2d(t.permute(0, 3, 1, 2), wdw, None, padding=1, groups=192).permute(0, 2, 3, 1)
+    q, k = dwo[..., :64].reshape(B, H * W, 2, 32), dwo[..., 64:128].reshape(B, H * W, 2, 32)
     gram = torch.einsum("bphi,bphj->bhij", q.double(), k.double()).reshape(B, 2, 1024)
-    assert rel_err(g1[..., :1024], gram) < 1e-5
-    assert rel_err(g1[..., 1024:1056], (q.double() ** 2).sum(1)) < 1e-5 and rel_err(g1[..., 1056:], (k.double() ** 2).sum(1)) < 1e-5
+    e_f, e_u = rel_err(g1[..., :1024], gram), rel_err(g0[..., :1024], gram)
+    assert e_f < 4e-3 and e_f < 1.5 * e_u + 1e-4, (e_f, e_u)
+    assert rel_err(g1[..., 1024:1056], (q.double() ** 2).sum(1)) < 4e-3 and rel_err(g1[..., 1056:], (k.double() ** 2).sum(1)) < 4e-3
     # deterministic
     part2 = torch.empty_like(part1)
     L.call("fd_pw_dw3x3_gram", L.FD_BF16, xd.data_ptr(), Cin, 0, Cin, None, None, 1e-6, md.data_ptr(), md.data_ptr() + Cin * 4,
@@ -733,9 +740,17 @@ def test_dwconv_gram(eng_factory, cfg):
     assert torch.equal(v, full[..., 2 * Cc:])
     g0, g1 = part0.double().sum(2).cpu(), part1.double().sum(2).cpu()
     assert bool(torch.isfinite(g1).all())
-    # the fused kernel's depthwise uses the tap-PAIR dot2 form of fd_pw_dw3x3 (bf16 weights, fp32 accumulation in another
-    # order than the standalone kernel's): q, k agree to bf16 rounding flips, the Gram to ~1e-3
-    assert rel_err(g1[..., :1024], g0[..., :1024]) < 3e-3 and rel_err(g1[..., 1024:], g0[..., 1024:]) < 3e-3
+    # the unfused pair rounds q, k to bf16 on their way through HBM (and its taps to bf16); fused, the depthwise runs on
+    # packed fp16 and q, k stay fp16 on chip.  Both against the fp32 depthwise + Gram of the same qkv tensor: the fused
+    # kernel is at least as close
+    dwo = F.conv2d(qkv.float().cpu().permute(0, 3, 1, 2), wdw.cpu().t().reshape(3 * Cc, 1, 3, 3), None, padding=1, groups=3 * Cc)
+    q = dwo[:, :Cc].reshape(B, Cc // 32, 32, H * W).double()
+    k = dwo[:, Cc:2 * Cc].reshape(B, Cc // 32, 32, H * W).double()
+    gram = (q @ k.transpose(-1, -2)).reshape(B, Cc // 32, 1024)
+    e_f, e_u = rel_err(g1[..., :1024], gram), rel_err(g0[..., :1024], gram)
+    assert e_f < 4e-3 and e_f < 1.5 * e_u + 1e-4, (e_f, e_u)
+    assert rel_err(g1[..., 1024:1056], (q ** 2).sum(-1)) < 4e-3 and rel_err(g1[..., 1056:], (k ** 2).sum(-1)) < 4e-3
+    assert rel_err(g1[..., :1024], g0[..., :1024]) < 8e-3
     part2 = torch.empty_like(part1)
     L.call("fd_dwconv_gram", L.FD_BF16, qkv.data_ptr(), 3 * Cc, Cc, wm.data_ptr(), part2.data_ptr(), B, H, W, s)
     torch.cuda.synchronize()
