@@ -467,10 +467,13 @@ __global__ __launch_bounds__(256) void scan_seq_kernel(const T *__restrict__ xc,
     const int odd = k & 1, ph = k & 1, pw = k >> 1;
     const float *xb = xdbl + ((int64_t)k * g.B + b) * g.L * CD;       // [4][B][L][CD], row = h2 * W2 + w2
 
-    f32x2 w[RS / 2], a2[NS / 2], h[NS / 2];
+    // dt_proj: every lane holds the channel's FULL rank-R weight row -- the four lanes of a quad compute the dt of four
+    // DIFFERENT steps each (dt_of_row below) instead of a quarter of every step's contraction plus a quad all-reduce and
+    // a 4x replicated softplus: 28 instead of 56 lane-slots per (channel, position)
+    f32x2 w[R / 2], a2[NS / 2], h[NS / 2];
 #pragma unroll
-    for (int r = 0; r < RS / 2; ++r)
-        w[r] = f32x2{dtw[(int64_t)kd * R + sub * RS + 2 * r], dtw[(int64_t)kd * R + sub * RS + 2 * r + 1]} * WS;
+    for (int r = 0; r < R / 2; ++r)
+        w[r] = f32x2{dtw[(int64_t)kd * R + 2 * r], dtw[(int64_t)kd * R + 2 * r + 1]} * WS;
 #pragma unroll
     for (int n = 0; n < NS / 2; ++n) {
         a2[n] = f32x2{A[(int64_t)kd * N + sub * NS + 2 * n], A[(int64_t)kd * N + sub * NS + 2 * n + 1]} * AS;
@@ -562,34 +565,34 @@ __global__ __launch_bounds__(256) void scan_seq_kernel(const T *__restrict__ xc,
 
     // a step's slices of its x_dbl row, in registers: loaded one step ahead of their use (the LDS round trip of a
     // read issued right before its consumer was most of a step's time at one or two waves per SIMD)
-    struct RowRegs { f32x2 wr[RS / 2], br[NS / 2], cr[NS / 2]; };
+    struct RowRegs { f32x2 br[NS / 2], cr[NS / 2]; };
     auto load_row = [&](const float *xr, RowRegs &q) {
-        const f32x2 *wr2 = (const f32x2 *)(xr + sub * RS);
         const f32x2 *br2 = (const f32x2 *)(xr + R + sub * NS);
         const f32x2 *cr2 = (const f32x2 *)(xr + R + N + sub * NS);
 #pragma unroll
-        for (int r = 0; r < RS / 2; ++r) q.wr[r] = wr2[r];
-#pragma unroll
         for (int n = 0; n < NS / 2; ++n) { q.br[n] = br2[n]; q.cr[n] = cr2[n]; }
     };
-    // A step in two halves.  pre(): everything that does not depend on the state -- dt_proj + quad all-reduce,
-    // softplus, the N/4 decay factors exp2(A dt) and inputs B dt u.  post(): the recurrence itself, the C contraction,
+    // dt of the position whose row is `xr`: the whole contraction + softplus in this lane
+    auto dt_of_row = [&](const float *xr) -> float {
+        const f32x2 *wr2 = (const f32x2 *)xr;
+        f32x2 dv2 = {0.f, 0.f}, dv3 = {0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < R / 2; ++r) {
+            if (r & 1) dv3 = w[r] * wr2[r] + dv3;
+            else dv2 = w[r] * wr2[r] + dv2;
+        }
+        const float dv = ((dv2.x + dv3.x) + (dv2.y + dv3.y)) + bias;
+        if constexpr (LOG2U) return __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(fminf(dv, 126.f)));
+        else return fd_softplus_fast(dv);
+    };
+    // A step in two halves.  pre(): everything that does not depend on the state -- the N/4 decay factors exp2(A dt) and
+    // inputs B dt u (dt: this step's lane of the quad, broadcast).  post(): the recurrence itself, the C contraction,
     // the quad all-reduce of y and the store.  run() issues pre(s + 1) next to post(s): two independent dependency
     // chains for the scheduler to interleave (a lone wave spent ~500 cycles per step walking one chain of ~30
     // dependent instructions; the state update is only the last third of it).
     struct PreOut { f32x2 da[NS / 2], bdu[NS / 2]; float du; };
-    auto pre = [&](const RowRegs &q, uint32_t uraw, PreOut &o) {
+    auto pre = [&](const RowRegs &q, uint32_t uraw, float dt, PreOut &o) {
         const float u = cvt_u(uraw);
-        f32x2 dv2 = {0.f, 0.f}, dv3 = {0.f, 0.f};
-#pragma unroll
-        for (int r = 0; r < RS / 2; ++r) {
-            if (r & 1) dv3 = w[r] * q.wr[r] + dv3;
-            else dv2 = w[r] * q.wr[r] + dv2;
-        }
-        const float dv = quad_sum((dv2.x + dv3.x) + (dv2.y + dv3.y)) + bias;
-        float dt;
-        if constexpr (LOG2U) dt = __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(fminf(dv, 126.f)));
-        else dt = fd_softplus_fast(dv);
         const float dtu = dt * u;
         o.du = Dd * u;
 #pragma unroll
@@ -620,18 +623,31 @@ __global__ __launch_bounds__(256) void scan_seq_kernel(const T *__restrict__ xc,
 #pragma unroll
         for (int s = 0; s < U; ++s) u[s] = ld_u(pix[s]);
     };
+    // lane `sub` of a quad -> the value lane i of the quad holds (i: compile-time)
+    auto quad_bcast = [&](float v, int i) -> float {
+        const int x = __builtin_bit_cast(int, v);
+        int r;
+        if (i == 0) r = __builtin_amdgcn_update_dpp(0, x, 0x00, 0xF, 0xF, true);
+        else if (i == 1) r = __builtin_amdgcn_update_dpp(0, x, 0x55, 0xF, 0xF, true);
+        else if (i == 2) r = __builtin_amdgcn_update_dpp(0, x, 0xAA, 0xF, 0xF, true);
+        else r = __builtin_amdgcn_update_dpp(0, x, 0xFF, 0xF, 0xF, true);
+        return __builtin_bit_cast(float, r);
+    };
     auto run = [&](int gi, const int (&pix)[U], const uint32_t (&u)[U]) {
         const float *rows = &sx[(gi >> 2) & 1][((gi & 3) * U) * CD];
         RowRegs q[3];
         PreOut o[2];
+        float dtq[U / 4];                                // dt of step 4 b + sub of block b, in lane `sub`
         load_row(rows, q[0]);
         load_row(rows + CD, q[1]);
-        pre(q[0], u[0], o[0]);
+        dtq[0] = dt_of_row(rows + sub * CD);
+        pre(q[0], u[0], quad_bcast(dtq[0], 0), o[0]);
 #pragma unroll
         for (int s = 0; s < U; ++s) {
             if (s + 2 < U) load_row(rows + (s + 2) * CD, q[(s + 2) % 3]);
             __builtin_amdgcn_sched_barrier(0);           // the reads stay two steps ahead of their use
-            if (s + 1 < U) pre(q[(s + 1) % 3], u[s + 1], o[(s + 1) & 1]);
+            if ((s & 3) == 0 && s + 4 < U) dtq[s / 4 + 1] = dt_of_row(rows + (s + 4 + sub) * CD);    // next block's dt
+            if (s + 1 < U) pre(q[(s + 1) % 3], u[s + 1], quad_bcast(dtq[(s + 1) / 4], (s + 1) & 3), o[(s + 1) & 1]);
             post(q[s % 3], o[s & 1], pix[s]);
         }
     };
@@ -659,8 +675,9 @@ __global__ __launch_bounds__(256) void scan_seq_kernel(const T *__restrict__ xc,
         advance(soff);
         RowRegs q;
         PreOut o;
-        load_row(&sx[(l / SP) & 1][(l % SP) * CD], q);
-        pre(q, ld_u(soff), o);
+        const float *xr = &sx[(l / SP) & 1][(l % SP) * CD];
+        load_row(xr, q);
+        pre(q, ld_u(soff), dt_of_row(xr), o);
         post(q, o, soff);
     }
 }
