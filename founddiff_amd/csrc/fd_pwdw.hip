@@ -88,13 +88,20 @@ struct PwDwParams {
                                       // staged once per workgroup, the 1x1 weight prefetch runs across tiles)
 };
 
-__global__ __launch_bounds__(256, 3) void pwdw_kernel(const PwDwParams p) {
-    __shared__ __attribute__((aligned(16))) unsigned char xs[XS_B];     // LN'd input halo, [192][64] bf16
-    __shared__ __attribute__((aligned(16))) unsigned char ts[TS_B];     // 1x1 output of one chunk, [180][64] bf16
-    __shared__ float sV[2][64];
+// CIN = 64 (round 1: levels 0-1, three workgroups per CU) or 128 (round 3: the C = 128 blocks at 256x256; the halo tile
+// is 48 KB, rows of 256 bytes swizzled over their 16 chunks, K = 128 in four K32 steps; two workgroups per CU).
+template <int CIN>
+__global__ __launch_bounds__(256, CIN == 64 ? 3 : 2) void pwdw_kernel(const PwDwParams p) {
+    constexpr int CH = CIN / 8, KS = CIN / 32, LCH = CIN == 64 ? 3 : 4;      // 16-byte chunks per pixel row, K32 steps
+    __shared__ __attribute__((aligned(16))) unsigned char xs[PMT * 16 * CIN * 2];   // LN'd input halo, [192][CIN] bf16
+    __shared__ __attribute__((aligned(16))) unsigned char ts[TS_B];     // 1x1 output of one chunk, [180][64] fp16
+    __shared__ float sV[2][CIN];
+    // row & (CH - 1): conflict-free for 16 consecutive rows starting at ANY row (the z phase reads tile rows that start
+    // at odd halo pixels)
+    auto xs_off = [](int row, int chunk) -> int { return row * (CIN * 2) + ((chunk ^ (row & (CH - 1))) << 4); };
     // fp16 tap weights [9][Cdw/2] (+ bias [Cdw] at word 5 Cdw) of the depthwise conv, staged once: a global load issued after a phase's
     // stores cannot be waited for without waiting for those stores too (vmcnt retires in order)
-    __shared__ __attribute__((aligned(16))) uint32_t sW[6 * 192];
+    __shared__ __attribute__((aligned(16))) uint32_t sW[6 * (CIN == 64 ? 192 : 256)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const int tiles_x = p.W / PT_W;
@@ -104,7 +111,7 @@ __global__ __launch_bounds__(256, 3) void pwdw_kernel(const PwDwParams p) {
     bf16 *dwout = p.out_dw + img * p.H * p.W * p.ld_dw + p.off_dw;
 
     // ---- once per workgroup: modulation vectors, tap weights
-    if (tid < 64) {
+    if (tid < CIN) {
         const float sc = 1.f + p.ln_scale[img * p.ln_ld + tid], sh = p.ln_shift[img * p.ln_ld + tid];
         const float g = p.ln_gamma ? p.ln_gamma[tid] : 1.f, be = p.ln_beta ? p.ln_beta[tid] : 0.f;
         sV[0][tid] = g * sc;
@@ -112,22 +119,23 @@ __global__ __launch_bounds__(256, 3) void pwdw_kernel(const PwDwParams p) {
     }
     for (int i = tid; i < 9 * p.Cdw / 2; i += 256) sW[i] = p.w_dw[i];         // [9][Cdw/2] fp16 channel pairs
     for (int i = tid; i < p.Cdw; i += 256) sW[5 * p.Cdw + i] = p.b_dw ? __builtin_bit_cast(uint32_t, p.b_dw[i]) : 0u;
-    constexpr int NLD = (PMT * 16 * 8) / 256;         // 6 chunks per thread cover all 192 rows
-    const int v = tid & 7;
+    constexpr int NLD = (PMT * 16 * CH) / 256;        // 6 (12) chunks per thread cover all 192 rows
+    const int v = tid & (CH - 1);
     // weight rows of a 32-channel group, permuted so that a lane ends up with 8 consecutive channels
     const int rperm = 8 * (fr >> 2) + (fr & 3);
     // The 1x1 weights are consumed in 32-row groups: first the Cz/32 pass-through groups (rows Cdw + 32g),
     // then two groups per depthwise chunk (rows 32g).  Group g+1 is loaded (L2) while group g is in the
     // MFMAs -- loaded right before use, each group exposed a full L2 round trip (~15k cycles per workgroup).
     const int nz = p.Cz / 32, ngroups = nz + p.Cdw / 32;
-    bf16x8 wnext[4];
+    bf16x8 wnext[2 * KS];                            // [row set a | b][ks]
     auto wload = [&](int g) {
         const int rb = g < nz ? p.Cdw + 32 * g : 32 * (g - nz);
-        const bf16 *wr = p.w_pw + (int64_t)(rb + rperm) * 64 + fg * 8;
-        wnext[0] = *(const bf16x8 *)(wr);
-        wnext[1] = *(const bf16x8 *)(wr + 32);
-        wnext[2] = *(const bf16x8 *)(wr + 4 * 64);
-        wnext[3] = *(const bf16x8 *)(wr + 4 * 64 + 32);
+        const bf16 *wr = p.w_pw + (int64_t)(rb + rperm) * CIN + fg * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            wnext[ks] = *(const bf16x8 *)(wr + 32 * ks);
+            wnext[KS + ks] = *(const bf16x8 *)(wr + 4 * CIN + 32 * ks);
+        }
     };
     wload(0);
     lds_barrier();                                   // sV, sW
@@ -144,7 +152,7 @@ __global__ __launch_bounds__(256, 3) void pwdw_kernel(const PwDwParams p) {
     u32x4 raw[NLD];
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
-        const int hp = (tl + k * 256) >> 3;
+        const int hp = (tl + k * 256) >> LCH;
         const int hy = div18(hp), hx = hp - hy * PH_X;
         const int yc = min(max(ty0 + hy - 1, 0), p.H - 1), xc = min(max(tx0 + hx - 1, 0), p.W - 1);
         // 32-bit element offsets from a per-image scalar base, 24-bit multiplies: the 64-bit form of this address
@@ -156,7 +164,7 @@ __global__ __launch_bounds__(256, 3) void pwdw_kernel(const PwDwParams p) {
     load8(&sV[1][v * 8], b8);
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
-        const int hp = (tl + k * 256) >> 3;
+        const int hp = (tl + k * 256) >> LCH;
         float f[8];
         const bf16x8 xv = __builtin_bit_cast(bf16x8, raw[k]);
 #pragma unroll
@@ -167,14 +175,16 @@ __global__ __launch_bounds__(256, 3) void pwdw_kernel(const PwDwParams p) {
         s += __shfl_xor(s, 1, 64);
         s += __shfl_xor(s, 2, 64);
         s += __shfl_xor(s, 4, 64);
-        const float mean = s * (1.f / 64);
+        if (CH == 16) s += __shfl_xor(s, 8, 64);
+        const float mean = s * (1.f / CIN);
         float q = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) { const float d = f[e] - mean; q += d * d; }
         q += __shfl_xor(q, 1, 64);
         q += __shfl_xor(q, 2, 64);
         q += __shfl_xor(q, 4, 64);
-        const float rstd = rsqrtf(q * (1.f / 64) + p.ln_eps);
+        if (CH == 16) q += __shfl_xor(q, 8, 64);
+        const float rstd = rsqrtf(q * (1.f / CIN) + p.ln_eps);
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (bf16)((f[e] - mean) * rstd * g8[e] + b8[e]);
@@ -195,22 +205,24 @@ __global__ __launch_bounds__(256, 3) void pwdw_kernel(const PwDwParams p) {
 
     // ---- phase Z: pass-through channels (z), interior pixels only, accumulators -> HBM
     if (p.Cz > 0) {
-        bf16x8 xb[2][2];                               // [tile row][ks]
+        bf16x8 xb[2][KS];                              // [tile row][ks]
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = (2 * wave + i + 1) * PH_X + 1 + fr;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) xb[i][ks] = *(const bf16x8 *)(xs + xs_off(row, ks * 4 + fg));
+            for (int ks = 0; ks < KS; ++ks) xb[i][ks] = *(const bf16x8 *)(xs + xs_off(row, ks * 4 + fg));
         }
         for (int ng = 0; ng < nz; ++ng) {
-            const bf16x8 wa[2] = {wnext[0], wnext[1]}, wb[2] = {wnext[2], wnext[3]};
+            bf16x8 wa[KS], wb[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) { wa[ks] = wnext[ks]; wb[ks] = wnext[KS + ks]; }
             ++gi;
             wload(gi < ngroups ? gi : 0);               // after the last group: the next tile's first
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
+                for (int ks = 0; ks < KS; ++ks) {
                     a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ks], xb[i][ks], a0, 0, 0, 0);
                     a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[ks], xb[i][ks], a1, 0, 0, 0);
                 }
@@ -250,22 +262,24 @@ __global__ __launch_bounds__(256, 3) void pwdw_kernel(const PwDwParams p) {
         for (int j = 0; j < 4; ++j) b2[j] = pk_h2(bs[2 * j], bs[2 * j + 1]);
         // phase 1: t[hp][64 ch] = W_chunk . xn, 3 m-tiles per wave (fragments re-read per chunk: registers
         // are the scarce resource of this kernel, LDS bandwidth is not)
-        bf16x8 xh[3][2];
+        bf16x8 xh[3][KS];
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+            for (int ks = 0; ks < KS; ++ks)
                 xh[i][ks] = *(const bf16x8 *)(xs + xs_off((3 * wave + i) * 16 + fr, ks * 4 + fg));
 #pragma unroll
         for (int ng = 0; ng < 2; ++ng) {
-            const bf16x8 wa[2] = {wnext[0], wnext[1]}, wb[2] = {wnext[2], wnext[3]};
+            bf16x8 wa[KS], wb[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) { wa[ks] = wnext[ks]; wb[ks] = wnext[KS + ks]; }
             ++gi;
             wload(gi < ngroups ? gi : 0);               // after the last group: the next tile's first
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
+                for (int ks = 0; ks < KS; ++ks) {
                     a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ks], xh[i][ks], a0, 0, 0, 0);
                     a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[ks], xh[i][ks], a1, 0, 0, 0);
                 }
@@ -755,7 +769,9 @@ __global__ __launch_bounds__(256, 3) void dwconv_gram_kernel(const DwGramParams 
 }  // namespace
 
 extern "C" int fd_pw_dw3x3_ok(int dtype, int Cin, int Cdw, int Cz, int H, int W) {
-    return dtype == FD_BF16 && Cin == 64 && Cdw > 0 && Cdw <= 192 && Cdw % 64 == 0 && Cz >= 0 && Cz % 32 == 0 && H % PT_H == 0 &&
+    static const bool no128 = getenv("FD_NO_PWDW128") != nullptr;        // development switch
+    const bool c64 = Cin == 64 && Cdw <= 192, c128 = Cin == 128 && Cdw <= 256 && Cz <= 256 && !no128;
+    return dtype == FD_BF16 && (c64 || c128) && Cdw > 0 && Cdw % 64 == 0 && Cz >= 0 && Cz % 32 == 0 && H % PT_H == 0 &&
            W % PT_W == 0 && (int64_t)H * W >= 32768 && (int64_t)H * W * 256 < (1ll << 31);   // 32-bit element offsets
 }
 
@@ -765,7 +781,7 @@ extern "C" int fd_pw_dw3x3(int dtype, const void *x, int ld_x, int off_x, int Ci
                            int dw_silu, void *out_dw, int ld_dw, int off_dw, int Cz, void *out_z, int ld_z,
                            int off_z, int B, int H, int W, void *stream) {
     FD_REQUIRE(fd_pw_dw3x3_ok(dtype, Cin, Cdw, Cz, H, W),
-               "fd_pw_dw3x3: unsupported shape (bf16, Cin=64, Cdw%%64, Cz%%32, H%%8, W%%16, >= 32768 px): "
+               "fd_pw_dw3x3: unsupported shape (bf16, Cin=64|128, Cdw%%64, Cz%%32, H%%8, W%%16, >= 32768 px): "
                "Cin=%d Cdw=%d Cz=%d H=%d W=%d", Cin, Cdw, Cz, H, W);
     FD_REQUIRE(x && ln_shift && ln_scale && w_pw && w_dw && out_dw && (Cz == 0 || out_z), "fd_pw_dw3x3: null pointer");
     FD_REQUIRE(ld_x % 8 == 0 && off_x % 8 == 0 && ld_dw % 8 == 0 && off_dw % 8 == 0 && ld_z % 8 == 0 && off_z % 8 == 0,
@@ -783,7 +799,8 @@ extern "C" int fd_pw_dw3x3(int dtype, const void *x, int ld_x, int off_x, int Ci
     static const int tpw_env = [] { const char *e = getenv("FD_PWDW_TPW"); return e ? atoi(e) : 0; }();
     p.tpw = tpw_env > 0 ? tpw_env : 4;
     dim3 grid((p.ntiles + p.tpw - 1) / p.tpw, B), block(256);
-    hipLaunchKernelGGL(pwdw_kernel, grid, block, 0, (hipStream_t)stream, p);
+    if (Cin == 64) hipLaunchKernelGGL(pwdw_kernel<64>, grid, block, 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(pwdw_kernel<128>, grid, block, 0, (hipStream_t)stream, p);
     FD_LAUNCH_OK("fd_pw_dw3x3");
     return FD_OK;
 }

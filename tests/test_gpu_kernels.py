@@ -606,7 +606,9 @@ def test_conv3x3_halo(eng_factory, cfg):
 
 
 @pytest.mark.parametrize("cfg", [dict(cdw=128, cz=128, silu=1, bias=True, affine=True, hw=(128, 256)),     # SS2D in_proj + conv2d
-                                 dict(cdw=192, cz=0, silu=0, bias=False, affine=False, hw=(256, 128))])   # qkv + qkv_dwconv
+                                 dict(cdw=192, cz=0, silu=0, bias=False, affine=False, hw=(256, 128)),    # qkv + qkv_dwconv
+                                 dict(cdw=256, cz=256, silu=1, bias=True, affine=True, hw=(128, 256), cin=128),   # C = 128 in_proj
+                                 dict(cdw=256, cz=256, silu=1, bias=True, affine=True, hw=(264, 144), cin=128)])  # ragged tile count
 def test_pw_dw3x3_fused(eng_factory, cfg):
     """Fused LN+modulate -> 1x1 -> depthwise 3x3 (bf16) against the unfused fp32 composition; borders
     included (the depthwise conv zero-pads the 1x1 OUTPUT)."""
@@ -614,13 +616,13 @@ def test_pw_dw3x3_fused(eng_factory, cfg):
     from founddiff_amd.engine import DAEngine
     e = eng_factory("bf16")
     torch.manual_seed(31)
-    B, (H, W), Cin = 2, cfg["hw"], 64
+    B, (H, W), Cin = 2, cfg["hw"], cfg.get("cin", 64)
     cdw, cz = cfg["cdw"], cfg["cz"]
     bf = lambda t: t.to(torch.bfloat16).float()
     x = bf(torch.randn(B, H, W, Cin) * 1.3 + 0.2)
     g, be = (torch.randn(Cin), torch.randn(Cin)) if cfg["affine"] else (None, None)
     mod = torch.randn(B, 6 * Cin) * 0.5
-    wpw = bf(torch.randn(cdw + cz, Cin) / 8)
+    wpw = bf(torch.randn(cdw + cz, Cin) / Cin ** 0.5)
     wdw = torch.randn(cdw, 1, 3, 3) / 3
     bdw = torch.randn(cdw) if cfg["bias"] else None
     eps = 1e-5 if cfg["affine"] else 1e-6
