@@ -120,8 +120,8 @@ def forward_bounds(eng, H, W, traffic, t_measured_ms):
 
 def roofline_leg(dif, x, noise, t_measured_ms=None):
     """Roofline of the dominant kernel symbol of one UNet forward -- the symbol with the largest total time, which is
-    also the top symbol of the rocprofv3 --stats summary of this command (profiles/).  Candidates: pwdw_kernel and
-    pwdw_gram_kernel (fused LayerNorm+modulate -> 1x1 -> depthwise 3x3 [-> Gram] of the 64-channel Mamba blocks: HBM
+    also the top symbol of the rocprofv3 --stats summary of this command (profiles/).  Candidates: pwdw_kernel<64|128> and
+    pwdw_gram_kernel (fused LayerNorm+modulate -> 1x1 -> depthwise 3x3 [-> Gram] of the 64- / 128-channel Mamba blocks: HBM
     roofline), the two instantiations of conv3x3_halo_kernel (MFMA roofline) and dwconv3x3_bf16_kernel (HBM).  Each is
     measured by replaying exactly its launches of one forward between HIP events on the launch stream; the largest
     becomes `roofline`, the rest `roofline.others`.  `forward`: the whole-forward bounds (forward_bounds)."""
@@ -158,10 +158,12 @@ def roofline_leg(dif, x, noise, t_measured_ms=None):
     cands = []
     # fused 1x1 -> depthwise.  args = (dtype, x, ld_x, off_x, Cin, gamma, beta, eps, shift, scale, ln_ld,
     #      w_pw, Cdw, w_dw, b_dw, silu, out_dw, ld_dw, off_dw, Cz, out_z, ld_z, off_z, B, H, W, stream)
-    pw = [(n, a) for n, a in trace if n == "fd_pw_dw3x3"]
-    if pw:
-        pw_bytes = sum(1.0 * a[23] * a[24] * a[25] * (a[4] + a[12] + a[19]) * esz for _, a in pw)   # in + dw out + z out, once
-        cands.append(hbm_entry("pwdw_kernel", pw, pw_bytes, "pwdw_hbm_bytes_per_launch"))
+    # (two symbols: pwdw_kernel<64> serves the 64-channel blocks, <128> the C = 128 block at 256x256)
+    for cin in (64, 128):
+        pw = [(n, a) for n, a in trace if n == "fd_pw_dw3x3" and a[4] == cin]
+        if pw:
+            pw_bytes = sum(1.0 * a[23] * a[24] * a[25] * (a[4] + a[12] + a[19]) * esz for _, a in pw)   # in + dw out + z out, once
+            cands.append(hbm_entry("pwdw_kernel<%d>" % cin, pw, pw_bytes, "pwdw%d_hbm_bytes_per_launch" % cin))
     # ... with the Gram: args = (dtype, x, ld_x, off_x, Cin, gamma, beta, eps, shift, scale, ln_ld, w_pw, w_dw, out_v, ld_v,
     #      off_v, partial, B, H, W, stream): reads 64 channels, writes v (64 channels) + one Gram partial per workgroup
     pg = [(n, a) for n, a in trace if n == "fd_pw_dw3x3_gram"]

@@ -40,7 +40,7 @@ class ConvParams(C.Structure):
         ("prologue", i32), ("ln_eps", f32),
         ("ln_gamma", vp), ("ln_beta", vp), ("ln_shift", vp), ("ln_scale", vp), ("ln_ld", i32),
         ("ln_z", vp), ("ln_ldz", i32), ("ln_offz", i32),
-        ("weight_f8", vp), ("w_scale", vp), ("act_scale", f32), ("f32_split", i32), ("debug", i32),
+        ("weight_f8", vp), ("w_scale", vp), ("act_scale", f32), ("f32_split", i32),
         ("fin_w", vp), ("fin_b", f32), ("fin_out", vp), ("fin_mode", i32), ("fin_last", i32), ("fin_img", vp),
         ("fin_xin", vp), ("fin_alpha", f32),
     ]

@@ -814,7 +814,7 @@ static int gram_tpw() {
 
 extern "C" int fd_pw_dw3x3_gram_ok(int dtype, int Cin, int H, int W) {
     static const bool off = getenv("FD_NO_GRAM_FUSE") != nullptr;      // development switch
-    return !off && fd_pw_dw3x3_ok(dtype, Cin, 192, 0, H, W);
+    return !off && Cin == 64 && fd_pw_dw3x3_ok(dtype, Cin, 192, 0, H, W);      // pwdw_gram_kernel is the 64-channel form
 }
 
 extern "C" int fd_pw_dw3x3_gram_nblk(int H, int W) {

@@ -333,7 +333,6 @@ class DAEngine:
         p.ln_shift, p.ln_scale, p.ln_ld = ptr(ln_shift), ptr(ln_scale), ln_ld
         p.ln_z, p.ln_ldz, p.ln_offz = ptr(ln_z), ln_ldz, ln_offz
         p.f32_split = getattr(self, "f32_split", 0)
-        p.debug = getattr(self, "conv_debug", 0)
         if fin is not None:      # EPI_GNSILU_ADD_FINAL: final_conv (+ DDIM update) in the epilogue
             p.fin_w, p.fin_b, p.fin_out = fin["w"].data_ptr(), float(fin["b"]), fin["out"].data_ptr()
             p.fin_mode, p.fin_last = int(fin.get("mode", 0)), int(fin.get("last", 0))

@@ -114,8 +114,6 @@ typedef struct fd_conv_params {
     /* fp32 storage only: 1 = split-bf16 contraction (x = hi + lo in bf16, hi.hi + hi.lo + lo.hi on the bf16 MFMA,
      * fp32 accumulation: ~2^-16 per product) instead of the exact-f32 MFMA.  The parity mode leaves it 0.       */
     int32_t f32_split;
-    /* development only (timing ablations of the 3x3 halo kernel, tools/kbench.py): must be 0.                   */
-    int32_t debug;
     /* FD_EPI_GNSILU_ADD_FINAL                                                                                  */
     const float *fin_w;                /* [Cout]                                              */
     float fin_b;

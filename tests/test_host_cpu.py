@@ -100,6 +100,23 @@ def test_cabi_exports_every_declared_symbol():
     assert lib.fd_scan_ws_floats(1, 512, 512, 128, 4) > 0
 
 
+def test_fused_kernel_eligibility_rules():
+    """Which Mamba-block shapes the fused kernels accept (pure host logic of the library).  The Gram-fused qkv kernel
+    is the 64-channel form only: when fd_pw_dw3x3 learnt C = 128 its eligibility test (which asked fd_pw_dw3x3_ok about
+    a 192-channel depthwise part) silently started to accept C = 128 blocks too."""
+    from founddiff_amd import _lib as L
+    lib = L.lib()
+    bf = L.FD_BF16
+    assert lib.fd_pw_dw3x3_ok(bf, 64, 128, 128, 512, 512) and lib.fd_pw_dw3x3_ok(bf, 64, 192, 0, 256, 256)
+    assert lib.fd_pw_dw3x3_ok(bf, 128, 256, 256, 256, 256)              # C = 128 in_proj at 256x256
+    assert not lib.fd_pw_dw3x3_ok(bf, 128, 384, 0, 256, 256)            # its qkv (3C = 384) stays on the row-GEMM
+    assert not lib.fd_pw_dw3x3_ok(bf, 128, 256, 256, 128, 128)          # too few tiles
+    assert not lib.fd_pw_dw3x3_ok(bf, 256, 512, 512, 256, 256)
+    assert lib.fd_pw_dw3x3_gram_ok(bf, 64, 512, 512)
+    assert not lib.fd_pw_dw3x3_gram_ok(bf, 128, 256, 256)
+    assert lib.fd_dwconv_gram_ok(bf, 128, 256, 256)
+
+
 def test_no_cpu_fallback():
     """The product path must fail loudly without a GPU, never fall back to torch/oracle."""
     from founddiff_amd import _lib as L

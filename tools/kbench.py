@@ -98,7 +98,6 @@ def bench_conv3(B, shapes=None):
             self.dev = torch.device("cuda")
             self.buf = {}
     e = Bare()
-    e.conv_debug = int(os.environ.get("FD_CONV_DEBUG", "0"))
     shapes = shapes or [(64, 0, 64, 512, False), (64, 64, 64, 512, False), (128, 0, 64, 512, True), (128, 64, 128, 256, False),
                         (256, 0, 128, 256, True), (256, 128, 256, 128, False), (512, 0, 256, 128, True), (512, 256, 512, 64, False)]
     for c0, c1, cout, OH, up in shapes:
