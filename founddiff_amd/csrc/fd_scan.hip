@@ -90,7 +90,15 @@ __global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 8 ? (CPL == 2 ? 4 : 5) : 
             constexpr int MB = (CD + 15) / 16;
             const int fr = lane & 15, fg = lane >> 4;
             const int nblk = (l1 - l0 + 15) >> 4;
-            for (int nb = wave; nb < nblk; nb += nw) {
+            // Every pixel load of a 16-position block is in flight before its first MFMA, and the NEXT block's loads
+            // are issued in front of the current block's MFMAs.  (With the K loop's trip count a runtime value the loop
+            // was not unrolled and each K32 step waited for its own pixel load: a chain of d_inner / 32 HBM round trips
+            // per block, 32 of them per workgroup at level 0 -- several times the 128 steps of recurrence that follow;
+            // PMC of phase A: VALU 64 % busy, 53 % of wave time parked, against 87 % / 36 % in phase C.)
+            constexpr int KSM = CPL == 2 ? 4 : 8;                   // K32 steps: d_inner <= 128 (CPL == 2, launcher) / <= 256
+            const int nks = g.D >> 5;
+            struct BlkPos { int l, lrow; };
+            auto fetch = [&](int nb, BlkPos &q, bf16x8 (&bq)[KSM]) {
                 const int l = l0 + nb * 16 + fr;
                 int h2, w2;
                 if (odd) { w2 = l / g.H2; h2 = l - w2 * g.H2; }
@@ -98,29 +106,48 @@ __global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 8 ? (CPL == 2 ? 4 : 5) : 
                 const int hh = 2 * h2 + ph, ww = 2 * w2 + pw;
                 const bool inimg = l < l1 && hh < g.H && ww < g.W;      // odd sizes: padded positions are zero rows
                 const bf16 *px = ubx + ((int64_t)hh * g.W + ww) * g.D + 8 * fg;
-                f32x4 acc[MB];
+                q.l = l;
+                q.lrow = h2 * g.W2 + w2;
 #pragma unroll
-                for (int mb = 0; mb < MB; ++mb) acc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                for (int ks = 0; ks < g.D / 32; ++ks) {
-                    bf16x8 bfr = {0, 0, 0, 0, 0, 0, 0, 0};
-                    if (inimg) bfr = *(const bf16x8 *)(px + 32 * ks);
+                for (int ks = 0; ks < KSM; ++ks) {
+                    bq[ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                    if (ks < nks && inimg) bq[ks] = *(const bf16x8 *)(px + 32 * ks);
+                }
+            };
+            // (the second register set only where it is free: 16 registers at d_inner = 128; at 256 the N >= 8 kernels
+            // sit at their 96-register occupancy step and the workgroup's waves share the blocks anyway)
+            constexpr bool DB = KSM == 4;
+            BlkPos cur, nxt;
+            bf16x8 bcur[KSM], bnxt[DB ? KSM : 1];
+            if (DB && wave < nblk) fetch(wave, cur, bcur);
+            for (int nb = wave; nb < nblk; nb += nw) {
+                const bool more = DB && nb + nw < nblk;
+                if constexpr (DB) { if (more) fetch(nb + nw, nxt, bnxt); }
+                else fetch(nb, cur, bcur);
 #pragma unroll
-                    for (int mb = 0; mb < MB; ++mb) {
-                        const int e = mb * 16 + fr;
-                        bf16x8 afr = {0, 0, 0, 0, 0, 0, 0, 0};
-                        if (e < CD) afr = *(const bf16x8 *)(Wk + (int64_t)e * g.D + 32 * ks + 8 * fg);
-                        acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr, acc[mb], 0, 0, 0);
+                for (int mb = 0; mb < MB; ++mb) {
+                    const int e = mb * 16 + fr;
+                    bf16x8 afr[KSM];
+#pragma unroll
+                    for (int ks = 0; ks < KSM; ++ks) {
+                        afr[ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                        if (ks < nks && e < CD) afr[ks] = *(const bf16x8 *)(Wk + (int64_t)e * g.D + 32 * ks + 8 * fg);
+                    }
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < KSM; ++ks)
+                        if (ks < nks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[ks], bcur[ks], acc, 0, 0, 0);
+                    const int e0 = mb * 16 + 4 * fg;                    // CD % 4 == 0 (launcher): all four or none
+                    if (cur.l < l1 && e0 < CD) {
+                        *(f32x4 *)&sx[(nb * 16 + fr) * CDP + e0] = acc;
+                        *(f32x4 *)&xo[(int64_t)cur.lrow * CD + e0] = acc;
                     }
                 }
-                if (l < l1) {
-                    const int lrow = h2 * g.W2 + w2;
+                if constexpr (DB) {
+                    if (more) {
+                        cur = nxt;
 #pragma unroll
-                    for (int mb = 0; mb < MB; ++mb) {
-                        const int e0 = mb * 16 + 4 * fg;                // CD % 4 == 0 (launcher): all four or none
-                        if (e0 < CD) {
-                            *(f32x4 *)&sx[(nb * 16 + fr) * CDP + e0] = acc[mb];
-                            *(f32x4 *)&xo[(int64_t)lrow * CD + e0] = acc[mb];
-                        }
+                        for (int ks = 0; ks < KSM; ++ks) bcur[ks] = bnxt[ks];
                     }
                 }
             }
@@ -236,13 +263,25 @@ __global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 8 ? (CPL == 2 ? 4 : 5) : 
     int co = __builtin_amdgcn_readfirstlane(l0 / NI);
     __syncthreads();
 
-    auto step = [&](const float *xr, uint32_t uraw, int soff) {
+    // CPL == 2: a step's row ([dt_r | B | C], the C part only in phase C) comes in REGISTERS, read from LDS one step
+    // ahead by run() below (phase A waited s_waitcnt lgkmcnt(0) in every step: the broadcast read sat directly in
+    // front of its use, an LDS round trip per ~100-cycle step that only the other waves could cover)
+    constexpr int NXV = CPL == 2 ? ((FINAL ? CD : R + N) + 3) / 4 : 1;
+    struct RowV { f32x4 v[NXV]; };
+    auto ld_row = [&](int li) -> RowV {
+        RowV q;
+#pragma unroll
+        for (int c = 0; c < NXV; ++c) q.v[c] = *(const f32x4 *)&sx[li * CDP + 4 * c];
+        return q;
+    };
+    auto step = [&](const float *xr_lds, const RowV &rq, uint32_t uraw, int soff) {
         if constexpr (CPL == 2) {
             // row = [dt_r (R) | B (N) | C (N)] broadcast scalars; every pair below is (channel d, channel d + 1)
+            const auto xr = [&](int i) -> float { return rq.v[i >> 2][i & 3]; };
             const f32x2 u2 = {__builtin_bit_cast(float, uraw << 16), __builtin_bit_cast(float, uraw & 0xffff0000u)};
             f32x2 dv2 = bias2;
 #pragma unroll
-            for (int r = 0; r < R; ++r) dv2 = w[r] * xr[r] + dv2;
+            for (int r = 0; r < R; ++r) dv2 = w[r] * xr(r) + dv2;
             f32x2 dt2;
             dt2.x = __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(fminf(dv2.x, 126.f)));
             dt2.y = __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(fminf(dv2.y, 126.f)));
@@ -253,13 +292,13 @@ __global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 8 ? (CPL == 2 ? 4 : 5) : 
             for (int n = 0; n < N; ++n) {
                 const f32x2 t = a2[n] * dt2;
                 const f32x2 da = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
-                h[n] = da * h[n] + dtu2 * xr[R + n];
-                if (FINAL) acc2 = h[n] * xr[R + N + n] + acc2;
+                h[n] = da * h[n] + dtu2 * xr(R + n);
+                if (FINAL) acc2 = h[n] * xr(R + N + n) + acc2;
             }
             if (FINAL) st_y2(soff, acc2);
         } else {
         const float u = cvt_u(uraw);
-        const f32x2 *xr2 = (const f32x2 *)xr;          // row = [dt_r (R) | B (N) | C (N)], all even
+        const f32x2 *xr2 = (const f32x2 *)xr_lds;      // row = [dt_r (R) | B (N) | C (N)], all even
         f32x2 dv2 = {bias, 0.f};
 #pragma unroll
         for (int r = 0; r < R / 2; ++r) dv2 = w[r] * xr2[r] + dv2;
@@ -304,8 +343,21 @@ __global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 8 ? (CPL == 2 ? 4 : 5) : 
         for (int s = 0; s < U; ++s) u[s] = ld_u(pix[s]);
     };
     auto run = [&](const int (&pix)[U], const uint32_t (&u)[U]) {
+        if constexpr (CPL == 2) {
+            RowV r0 = ld_row(l - l0);
 #pragma unroll
-        for (int s = 0; s < U; ++s) step(sx + (l - l0 + s) * CDP, u[s], pix[s]);
+            for (int s = 0; s < U; ++s) {
+                RowV r1 = r0;
+                if (s + 1 < U) r1 = ld_row(l - l0 + s + 1);
+                __builtin_amdgcn_sched_barrier(0);          // the read stays a step ahead of its use
+                step(nullptr, r0, u[s], pix[s]);
+                r0 = r1;
+            }
+        } else {
+            const RowV none = {};
+#pragma unroll
+            for (int s = 0; s < U; ++s) step(sx + (l - l0 + s) * CDP, none, u[s], pix[s]);
+        }
         l += U;
     };
     if (ngroups > 0) fetch(pixA, uA);
@@ -320,7 +372,7 @@ __global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 8 ? (CPL == 2 ? 4 : 5) : 
     for (; l < l1; ++l) {
         int soff;
         advance(soff);
-        step(sx + (l - l0) * CDP, ld_u(soff), soff);
+        step(sx + (l - l0) * CDP, ld_row(l - l0), ld_u(soff), soff);
     }
     if (!FINAL) {
         // chunk decay P[n] = exp2(a2[n] * sum dt): only the sum is stored ([bk][chunk][d], N x smaller than
@@ -716,7 +768,8 @@ void launch_scan(const T *xc, const float *xdbl, const float *dtw, const float *
     // two channels per lane where the kernel is VALU-bound and the state is small (bf16, N <= 8); a function of the
     // shape only
     constexpr int CPL = (sizeof(T) == 2 && N <= 4) ? 2 : 1;     // N = 8: measured slower (305 vs 293 us at 256x256, batch 8)
-    const bool two = CPL == 2 && g.D % 128 == 0 && scan_cpl2_on();
+    // (with the x_proj einsum inside phase A the two-channel form holds d_inner / 32 <= 4 pixel fragments per block)
+    const bool two = CPL == 2 && g.D % 128 == 0 && (!g.xw || g.D == 128) && scan_cpl2_on();
     const int cw = two ? 128 : 64;                     // channels per wave
     const int nw = g.D >= 4 * cw ? 4 : g.D / cw;       // waves per workgroup
     dim3 grid(g.nch * (g.D / (cw * nw)), g.B * 4), block(64 * nw);

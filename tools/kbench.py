@@ -47,6 +47,33 @@ def bench_scan(B, shapes=None):
         print(f"scan D={D} N={N} R={R} {H}x{W} B={B}: {t:8.1f} us  ({t / B / 1e3:.4f} ms/slice)  y_sum={float(y.float().abs().mean()):.6f}", flush=True)
 
 
+def bench_scanx(B):
+    """selective scan with the x_proj einsum inside phase A (levels 0-2 of a 512x512 forward)"""
+    from founddiff_amd import _lib as L
+    s = torch.cuda.current_stream().cuda_stream
+    for D, N, R, H, W in [(128, 4, 4, 512, 512), (128, 8, 4, 256, 256), (256, 8, 8, 256, 256), (256, 16, 8, 128, 128)]:
+        if not L.lib().fd_selective_scan_plan(L.FD_BF16, D, N, R, H, W):
+            print(f"scanx D={D} N={N} R={R} {H}x{W}: not fused", flush=True)
+            continue
+        torch.manual_seed(0)
+        CD, Lq = R + 2 * N, (H // 2) * (W // 2)
+        xc = (torch.randn(B, H, W, D, device="cuda") * 0.5).to(torch.bfloat16)
+        xw = (torch.randn(4, CD, D, device="cuda") * D ** -0.5).to(torch.bfloat16)
+        xdbl = torch.empty(4, B, Lq, CD, device="cuda")
+        dtw = ((torch.rand(4, D, R, device="cuda") * 2 - 1) * R ** -0.5)
+        dtb = torch.randn(4, D, device="cuda") * 0.5 - 3
+        A = -torch.exp(torch.log(torch.arange(1, N + 1, device="cuda").float())[None].repeat(4 * D, 1))
+        Ds = torch.ones(4 * D, device="cuda")
+        ws = torch.empty(L.lib().fd_scan_ws_floats(B, H, W, D, N), device="cuda")
+        y = torch.empty(B, H, W, D, device="cuda", dtype=torch.bfloat16)
+
+        def run():
+            L.call("fd_selective_scan_xproj", L.FD_BF16, xc.data_ptr(), xw.data_ptr(), xdbl.data_ptr(), dtw.data_ptr(),
+                   dtb.data_ptr(), A.data_ptr(), Ds.data_ptr(), y.data_ptr(), ws.data_ptr(), B, H, W, D, N, R, s)
+        t = timeit(run)
+        print(f"scanx D={D} N={N} R={R} {H}x{W} B={B}: {t:8.1f} us  ({t / B / 1e3:.4f} ms/slice)  y={float(y.float().abs().mean()):.6f} xdbl={float(xdbl.abs().mean()):.6f}", flush=True)
+
+
 def bench_attn(B, sizes=((512, 512), (256, 256))):
     """channel-attention branch of a 64-channel Mamba block: fused (qkv+dw+Gram) vs unfused (qkv+dw, Gram)"""
     from founddiff_amd import _lib as L
