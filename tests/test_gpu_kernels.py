@@ -76,6 +76,54 @@ def test_conv(eng_factory, mode, tol, cfg):
     assert rel_err(nchw(out), ref) < tol
 
 
+@pytest.mark.parametrize("cfg", [
+    dict(c0=512, c1=0, cout=2048, hw=(64, 64), epi="silu_split"),       # in_proj of the 512-channel blocks
+    dict(c0=1024, c1=0, cout=512, hw=(64, 64), epi="gate_res"),         # out_proj: gated residual
+    dict(c0=256, c1=192, cout=328, hw=(60, 52), epi="none"),            # two sources, ragged M and N tiles
+])
+def test_pointwise_gemm_256_tile(eng_factory, cfg):
+    """1x1 convolutions that run on the 256x256 tile of the generic kernel (fd_conv_kernel_id == 5: the dense layers of
+    the 64x64 / 128x128 levels at batch 8) against the fp32 composition, with the pointwise epilogues they use, two
+    sources, ragged M and N tiles; repeated launches reproduce the first one bit for bit."""
+    from founddiff_amd import _lib as L
+    from founddiff_amd.engine import ConvW
+    e = eng_factory("bf16")
+    torch.manual_seed(5)
+    B, (H, W) = 8, cfg["hw"]
+    c0, c1, cout = cfg["c0"], cfg["c1"], cfg["cout"]
+    bf = lambda t: t.to(torch.bfloat16).float()
+    a = bf(torch.randn(B, H, W, c0))
+    a1 = bf(torch.randn(B, H, W, c1)) if c1 else None
+    w = bf(torch.randn(cout, c0 + c1) / (c0 + c1) ** 0.5)
+    bias = torch.randn(cout)
+    xin = torch.cat((a, a1), -1) if c1 else a
+    ref = F.linear(xin, w, bias)
+    cw = ConvW(w, bias, e.dev, e.tdt)
+    out = torch.zeros(B, H, W, cout, device="cuda", dtype=torch.bfloat16)
+    kw = dict(c0=c0)
+    if c1:
+        kw.update(in1=a1.cuda().to(torch.bfloat16), c1=c1)
+    if cfg["epi"] == "silu_split":
+        kw.update(epi=L.EPI_SILU_SPLIT, split=cout // 2)
+        ref[..., cout // 2:] = F.silu(ref[..., cout // 2:])
+    elif cfg["epi"] == "gate_res":
+        res = bf(torch.randn(B, H, W, cout))
+        gate = torch.randn(B, cout)
+        kw.update(epi=L.EPI_GATE_RES, res=res.cuda().to(torch.bfloat16), gate=gate.cuda(), gate_ld=cout)
+        ref = res + gate[:, None, None, :] * ref
+    ad = a.cuda().to(torch.bfloat16)
+    assert e.conv(cw, ad, B, H, W, out, probe="kid", **kw) == 5
+    e.conv(cw, ad, B, H, W, out, **kw)
+    torch.cuda.synchronize()
+    assert rel_err(out.float().cpu(), ref) < 6e-3
+    first = out.clone()
+    for _ in range(8):
+        out.zero_()
+        e.conv(cw, ad, B, H, W, out, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(out, first)
+
+
 @pytest.mark.parametrize("mode,tol", MODES)
 def test_conv_concat_slices_epilogues(eng_factory, mode, tol):
     from founddiff_amd import _lib as L

@@ -145,6 +145,28 @@ def bench_conv3(B, shapes=None):
         print(f"conv3x3 {cin:4d}->{cout:4d} @{OH} up={int(up)} B={B}: {t:8.1f} us  {fl / t / 1e6:7.1f} TFLOP/s  ({fl / t / 1e6 / 2500:.3f} of peak)", flush=True)
 
 
+def bench_pw(B):
+    """1x1 convolutions of the deep levels (64x64, 128x128): (cin, cout, HW)"""
+    from founddiff_amd.engine import DAEngine, ConvW, _T
+
+    class Bare(DAEngine):
+        def __init__(self):
+            self.mode = "bf16"
+            self.dt, self.tdt = _T["bf16"]
+            self.dev = torch.device("cuda")
+            self.buf = {}
+    e = Bare()
+    for cin, cout, hw in [(512, 2048, 64), (1024, 512, 64), (512, 1536, 64), (512, 512, 64), (256, 1024, 128), (512, 256, 128), (256, 768, 128)]:
+        torch.manual_seed(0)
+        cw = ConvW(torch.randn(cout, cin) / cin ** 0.5, torch.randn(cout), e.dev, e.tdt)
+        x = torch.randn(B, hw, hw, cin, device="cuda").to(torch.bfloat16)
+        out = torch.empty(B, hw, hw, cout, device="cuda", dtype=torch.bfloat16)
+        kid = e.conv(cw, x, B, hw, hw, out, probe="kid")
+        t = timeit(lambda: e.conv(cw, x, B, hw, hw, out))
+        fl = 2.0 * B * hw * hw * cout * cin
+        print(f"pw {cin:4d}->{cout:4d} @{hw} B={B} kid={kid}: {t:8.1f} us  {fl / t / 1e6:7.1f} TFLOP/s  ({fl / t / 1e6 / 2500:.3f} of peak)  chk={float(out.float().abs().mean()):.5f}", flush=True)
+
+
 def bench_pwdw(B, sizes=((512, 512), (256, 256))):
     """in_proj variant of the fused LN -> 1x1 -> depthwise kernel (Cdw = 128 + SiLU, Cz = 128)"""
     from founddiff_amd import _lib as L
