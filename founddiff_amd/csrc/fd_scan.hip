@@ -509,7 +509,10 @@ __global__ __launch_bounds__(256) void scan_seq_kernel(const T *__restrict__ xc,
     constexpr bool LOG2U = sizeof(T) == 2;                           // see scan_chunk_kernel: dt in base-2 units
     constexpr float WS = LOG2U ? 1.4426950408889634f : 1.f;
     constexpr float AS = LOG2U ? 1.f : 1.4426950408889634f;
-    __shared__ __attribute__((aligned(16))) float sx[2][SP * CD];
+    // LDS row stride: the four lanes of a quad read the dt_r parts of four DIFFERENT rows (dt_of_row); with a stride of
+    // CD = 96 floats all four fall on the same banks (PMC: 24 % of the LDS cycles were conflicts)
+    constexpr int CDS = CD + 4;
+    __shared__ __attribute__((aligned(16))) float sx[2][SP * CDS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int sub = lane & 3;
@@ -610,7 +613,7 @@ __global__ __launch_bounds__(256) void scan_seq_kernel(const T *__restrict__ xc,
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
             const int idx = tid + j * 256;
-            if (idx < SP * CD4) *(f32x4 *)&sx[buf][4 * idx] = stg[j];
+            if (idx < SP * CD4) *(f32x4 *)&sx[buf][(idx / CD4) * CDS + 4 * (idx % CD4)] = stg[j];
         }
     };
     auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
@@ -686,19 +689,19 @@ __global__ __launch_bounds__(256) void scan_seq_kernel(const T *__restrict__ xc,
         return __builtin_bit_cast(float, r);
     };
     auto run = [&](int gi, const int (&pix)[U], const uint32_t (&u)[U]) {
-        const float *rows = &sx[(gi >> 2) & 1][((gi & 3) * U) * CD];
+        const float *rows = &sx[(gi >> 2) & 1][((gi & 3) * U) * CDS];
         RowRegs q[3];
         PreOut o[2];
         float dtq[U / 4];                                // dt of step 4 b + sub of block b, in lane `sub`
         load_row(rows, q[0]);
-        load_row(rows + CD, q[1]);
-        dtq[0] = dt_of_row(rows + sub * CD);
+        load_row(rows + CDS, q[1]);
+        dtq[0] = dt_of_row(rows + sub * CDS);
         pre(q[0], u[0], quad_bcast(dtq[0], 0), o[0]);
 #pragma unroll
         for (int s = 0; s < U; ++s) {
-            if (s + 2 < U) load_row(rows + (s + 2) * CD, q[(s + 2) % 3]);
+            if (s + 2 < U) load_row(rows + (s + 2) * CDS, q[(s + 2) % 3]);
             __builtin_amdgcn_sched_barrier(0);           // the reads stay two steps ahead of their use
-            if ((s & 3) == 0 && s + 4 < U) dtq[s / 4 + 1] = dt_of_row(rows + (s + 4 + sub) * CD);    // next block's dt
+            if ((s & 3) == 0 && s + 4 < U) dtq[s / 4 + 1] = dt_of_row(rows + (s + 4 + sub) * CDS);    // next block's dt
             if (s + 1 < U) pre(q[(s + 1) % 3], u[s + 1], quad_bcast(dtq[(s + 1) / 4], (s + 1) & 3), o[(s + 1) & 1]);
             post(q[s % 3], o[s & 1], pix[s]);
         }
@@ -727,7 +730,7 @@ __global__ __launch_bounds__(256) void scan_seq_kernel(const T *__restrict__ xc,
         advance(soff);
         RowRegs q;
         PreOut o;
-        const float *xr = &sx[(l / SP) & 1][(l % SP) * CD];
+        const float *xr = &sx[(l / SP) & 1][(l % SP) * CDS];
         load_row(xr, q);
         pre(q, ld_u(soff), dt_of_row(xr), o);
         post(q, o, soff);
