@@ -72,11 +72,34 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const fd_conv_
     static_assert(TMW == 64 || (BM == 64 && TMW == 32), "GroupNorm partials are written per 64-row band");
     __shared__ __attribute__((aligned(16))) unsigned char smem[SM_BYTES];
     __shared__ float s_stat[NWAVE][BN][2];
+    // pointwise epilogue: the per-channel operands (bias; gate | GroupNorm gamma, beta, mean, rstd) of the channel tile,
+    // fetched once at kernel start.  Loaded inside the epilogue they were 4-8 dependent global round trips per workgroup
+    // AFTER its last MFMA (one per 32-channel group), sitting behind whatever else was in flight -- with the K loop
+    // removed the kernel still took 40 % of its time
+    __shared__ __attribute__((aligned(16))) float s_ep[PWE ? 5 : 1][PWE ? BN : 1];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int mt = blockIdx.x, nt = blockIdx.y;
     const int b = blockIdx.z / p.ndir, dir = blockIdx.z % p.ndir;
+    if constexpr (PWE) {
+        for (int c = tid; c < BN; c += NTHR) {
+            const int n = nt * BN + c;
+            const bool ok = n < p.Cout;
+            s_ep[0][c] = (p.bias && ok) ? p.bias[n] : 0.f;
+            float e0 = 0.f, e1 = 0.f, gm = 0.f, gr = 0.f;
+            if (ok && p.epilogue == FD_EPI_GATE_RES) e0 = p.gate[(int64_t)b * p.gate_ld + n];
+            else if (ok && p.epilogue == FD_EPI_GNSILU_ADD) {
+                e0 = p.gn_gamma[n];
+                e1 = p.gn_beta[n];
+                const int g = n / (p.Cout / p.gn_groups);
+                gm = p.gn_mean_rstd[((int64_t)b * p.gn_groups + g) * 2];
+                gr = p.gn_mean_rstd[((int64_t)b * p.gn_groups + g) * 2 + 1];
+            }
+            s_ep[1][c] = e0; s_ep[2][c] = e1; s_ep[3][c] = gm; s_ep[4][c] = gr;
+        }
+        // (published by the barriers of the K loop: every launch has at least one K step)
+    }
     const int Cin = p.c0 + p.c1;
     const int K = p.KH * p.KW * Cin;
     const int OHW = p.OH * p.OW;
@@ -334,26 +357,19 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const fd_conv_
         // selects PW when Cout, strides and offsets are multiples of 8 and no GroupNorm sums are wanted.
         const int64_t obase_pw = 0;
         (void)obase_pw;
-        const int cpg = p.gn_groups > 0 ? p.Cout / p.gn_groups : 1;
 #pragma unroll
         for (int jp = 0; jp < NT / 2; ++jp) {
             const int n0 = nt * BN + TNW * wn + 32 * jp + 8 * fg;
             if (n0 >= p.Cout) continue;
             float bias8[8], ev0[8], ev1[8], gm = 0.f, gr = 0.f;
-            if (p.bias) load8(p.bias + n0, bias8);
-            else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
-            }
-            if (p.epilogue == FD_EPI_GATE_RES) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) ev0[e] = p.gate[(int64_t)b * p.gate_ld + n0 + e];
-            } else if (p.epilogue == FD_EPI_GNSILU_ADD) {
-                load8(p.gn_gamma + n0, ev0);
-                load8(p.gn_beta + n0, ev1);
-                const int g = n0 / cpg;             // channels-per-group is a multiple of 8 (dispatcher)
-                gm = p.gn_mean_rstd[((int64_t)b * p.gn_groups + g) * 2];
-                gr = p.gn_mean_rstd[((int64_t)b * p.gn_groups + g) * 2 + 1];
+            const int cl = TNW * wn + 32 * jp + 8 * fg;          // channel inside the tile
+            load8(&s_ep[0][cl], bias8);
+            if (p.epilogue == FD_EPI_GATE_RES) load8(&s_ep[1][cl], ev0);
+            else if (p.epilogue == FD_EPI_GNSILU_ADD) {
+                load8(&s_ep[1][cl], ev0);
+                load8(&s_ep[2][cl], ev1);
+                gm = s_ep[3][cl];                               // channels-per-group is a multiple of 8 (dispatcher)
+                gr = s_ep[4][cl];
             }
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
