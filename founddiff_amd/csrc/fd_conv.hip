@@ -648,6 +648,8 @@ extern "C" int fd_conv_kernel_id(const fd_conv_params *pp) {
     if (fd_conv_prologue_ok(pp)) return 10;
     if (fd_conv3x3_ok(*pp)) return fd_conv3x3_fp8_ok(*pp) ? 12 : 11;
     const bool wide = pp->Cout > 64, tall = conv_bm((int64_t)pp->OH * pp->OW) == 128;
+    static const int force = [] { const char *e = getenv("FD_CONV_KID"); return e ? atoi(e) : -1; }();   // development: tile experiments
+    if (force >= 0 && !pp->stats_partial && pp->KH == 1 && pp->Cout >= 256) return force;
     // 8-wave 128x256 tile (id 4) for the dense layers of the 64x64 / 128x128 levels: it halves the operand
     // traffic from beyond L2 (+15..30 % at batch 8) but launches 4x fewer workgroups, so it is chosen only
     // when the batch fills the chip.  This choice may depend on the batch size without breaking batch
@@ -658,8 +660,9 @@ extern "C" int fd_conv_kernel_id(const fd_conv_params *pp) {
     //  tile already launches plenty of workgroups per A tile)
     // 256x256 (id 5, 8 waves of 64x128): a CU sustains only ~20 B/clk of L2-hit loads, so the MFMA rate of
     // these K-streaming tiles is set by FLOP per loaded byte = BM*BN/(BM+BN): 600-680 TFLOP/s against 560
-    // for every smaller tile (measured, batch 8; K >= 384 so the 8-step prologue/epilogue amortises).
-    if (!tall && !pp->stats_partial && pp->Cout >= 256 && pp->KH * pp->KW * (pp->c0 + pp->c1) >= 384 &&
+    // for every smaller tile (measured, batch 8).  Round 3: also at K = 256 (the in_proj / qkv of the 256-channel blocks at
+    // 128x128: 176 -> 140 us and 120 -> 99 us at batch 8 against the 64x128 tile, `FD_CONV_KID` experiments).
+    if (!tall && !pp->stats_partial && pp->Cout >= 256 && pp->KH * pp->KW * (pp->c0 + pp->c1) >= 256 &&
         (int64_t)pp->B * pp->ndir * cdiv((int64_t)pp->OH * pp->OW, 256) * cdiv(pp->Cout, 256) >= 192)
         return 5;
     if (!tall && pp->Cout >= 256 && pp->Cout <= 512 && !pp->stats_partial && pp->KH * pp->KW * (pp->c0 + pp->c1) >= 256) {
