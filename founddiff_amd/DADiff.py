@@ -9,6 +9,7 @@ reference (`/root/reference/src/DADiff.py`; contract in SURVEY.md section 8b), s
 through `founddiff_amd.engine.DAEngine`.  Training (`p_losses`, optimiser, EMA update) is out of
 scope (inference engine).
 """
+import ctypes as C
 import math
 import os
 import random
@@ -354,6 +355,9 @@ class ResidualDiffusion(nn.Module):
         # scan, HBM row-GEMMs, MFMA convolutions) overlap when they come from independent launch sequences
         # (measured: 2 x 8 slices on two streams 1.79 ms per slice-forward, one stream of 8 or 16: 1.90 / 1.84)
         self.streams = int(os.environ.get("FOUNDDIFF_STREAMS", "2"))
+        # phase offset between the concurrent sub-batches (microseconds; sub-batch k starts k * offset late): identical
+        # launch sequences that start together pair every kernel with its twin, which is bound by the same resource
+        self.stream_offset_us = float(os.environ.get("FOUNDDIFF_STREAM_OFFSET_US", "0"))
         self._side_streams = {}
 
     def init(self):
@@ -711,6 +715,7 @@ class ResidualDiffusion(nn.Module):
             L.call("fd_res_posterior_step_keyed", _p(mo), _p(img), _p(x_in), _p(gco), _p(t_dev), _p(gse), _p(img), None,
                    B, npix, _stream(img))
 
+        K = max(0, min(int(K), T))                                # a tail longer than the loop is the whole loop
         n_main = T - K
         if not (self.use_graph and last):
             for i in range(T):
@@ -718,19 +723,24 @@ class ResidualDiffusion(nn.Module):
                 if not last:
                     img_list.append(img.clone())
             return
-        G = max([g for g in range(8, 65) if n_main % g == 0] or [1])
+        # G steps per captured chunk: the largest divisor of n_main in [8, 64]; when there is none (n_main prime or
+        # small) a fixed 40 with the n_main % 40 leftover steps run eagerly in front of the replays
+        G = max([g for g in range(8, 65) if n_main > 0 and n_main % g == 0] or [40])
         graphs = eng.__dict__.setdefault("anc_graphs", {})
         key = (tuple(img.shape), eng.mode, eng.gen, G, K, e32.gen if e32 else 0, self.final_outer_levels, T)
+        reps, rem = n_main // G, n_main % G
         if key not in graphs:
             start, t0 = img.clone(), t_dev.clone()
             eng.forward(img, x_in, time_buf, out=mo)              # warm-up: every workspace buffer exists
             if e32 is not None:
                 self._tail_forward(e32, eng, img, x_in, time_buf, mo)
             torch.cuda.synchronize()
-            gm = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gm):
-                for _ in range(G):
-                    one(eng)
+            gm = None
+            if reps > 0:
+                gm = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gm):
+                    for _ in range(G):
+                        one(eng)
             gt = None
             if K > 0:
                 gt = torch.cuda.CUDAGraph()
@@ -742,17 +752,18 @@ class ResidualDiffusion(nn.Module):
             img.copy_(start)
             t_dev.copy_(t0)
         gm, gt = graphs[key]
-        reps = n_main // G
         lim = getattr(self, "_anc_max_chunks", None)          # bench.py's bounded leg: time a few chunks, not the volume
         if lim:
-            reps = min(reps, int(lim))
+            reps, rem = min(reps, int(lim)), 0
+        for _ in range(rem):
+            one(eng)
         for _ in range(reps):
             gm.replay()
         if gt is not None:
             if lim:
                 t_dev.fill_(K)                                # jump to the tail steps
             gt.replay()
-        self._anc_steps_run = reps * G + K
+        self._anc_steps_run = rem + reps * G + K
 
     @torch.no_grad()
     def ddim_sample(self, x_input, shape, last=True, noise=None):
@@ -909,6 +920,8 @@ class ResidualDiffusion(nn.Module):
             self._slot = k
             try:
                 with torch.cuda.stream(st):
+                    if k and self.stream_offset_us > 0:
+                        L.call("fd_stream_delay", float(k * self.stream_offset_us), C.c_void_p(st.cuda_stream))
                     sl = slice(k * per, (k + 1) * per)
                     if seeds is None:
                         o = self.ddim_sample([x_in[sl].contiguous()], (per,) + tuple(size[1:]), last=True,
@@ -1087,15 +1100,26 @@ class Trainer(object):
         `batch_size` > 1 batches independent slices (the reference uses 1).  `sample=True` keeps the
         reference's branch that returns inputs + outputs without metrics; without `condition` the loop is the
         reference's unconditional `self.sample` rounds (100, or up to 50000 images with FID)."""
-        from .metrics import compute_metrics
-        self.model.init()
         # batch_size 1 is the reference's loop: one slice per sample() call -> the kernel set for a lone slice (DAEngine
         # low_latency: same arithmetic, chunked scans at every level; outputs differ from a batched run by fp32
-        # summation order)
-        for name in ("unet0", "unet1"):
-            u = getattr(getattr(self.model, "model", None), name, None)
-            if u is not None and hasattr(u, "low_latency"):
-                u.low_latency = batch_size == 1
+        # summation order).  The switch is only ever turned ON here (FOUNDDIFF_LOW_LATENCY=1 stays in force for any batch
+        # size) and is restored on the way out, so later sample() calls on the same model are not affected.  Cost: the
+        # low-latency engine is a second DAEngine (its own weight copy, workspaces and graphs) next to the default one.
+        unets = [u for u in (getattr(getattr(self.model, "model", None), n, None) for n in ("unet0", "unet1"))
+                 if u is not None and hasattr(u, "low_latency")]
+        saved = [u.low_latency for u in unets]
+        try:
+            if batch_size == 1:
+                for u in unets:
+                    u.low_latency = True
+            return self._test(sample, last, FID, batch_size)
+        finally:
+            for u, v in zip(unets, saved):
+                u.low_latency = v
+
+    def _test(self, sample, last, FID, batch_size):
+        from .metrics import compute_metrics
+        self.model.init()
         print("test start")
         if not self.condition:
             if FID:

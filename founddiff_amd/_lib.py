@@ -96,6 +96,7 @@ SIGNATURES = {
     "fd_res_ddim_step": (i32, [vp, vp, vp, vp, f32, f32, i32, vp, i64, vp]),
     "fd_res_step_obj": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i64, vp]),
     "fd_res_posterior_step": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i64, vp]),
+    "fd_stream_delay": (i32, [f32, vp]),
     "fd_keyed_normal": (i32, [vp, i32, vp, i32, i64, vp]),
     "fd_ancestral_begin": (i32, [vp, vp, vp, i32, vp]),
     "fd_res_posterior_step_keyed": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i64, vp]),

@@ -649,7 +649,7 @@ extern "C" int fd_conv_kernel_id(const fd_conv_params *pp) {
     if (fd_conv3x3_ok(*pp)) return fd_conv3x3_fp8_ok(*pp) ? 12 : 11;
     const bool wide = pp->Cout > 64, tall = conv_bm((int64_t)pp->OH * pp->OW) == 128;
     static const int force = [] { const char *e = getenv("FD_CONV_KID"); return e ? atoi(e) : -1; }();   // development: tile experiments
-    if (force >= 0 && !pp->stats_partial && pp->KH == 1 && pp->Cout >= 256) return force;
+    if (force >= 0 && force <= 6 && !pp->stats_partial && pp->KH == 1 && pp->Cout >= 256) return force;
     // 8-wave 128x256 tile (id 4) for the dense layers of the 64x64 / 128x128 levels: it halves the operand
     // traffic from beyond L2 (+15..30 % at batch 8) but launches 4x fewer workgroups, so it is chosen only
     // when the batch fills the chip.  This choice may depend on the batch size without breaking batch

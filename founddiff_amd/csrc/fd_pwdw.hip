@@ -258,6 +258,7 @@ __global__ __launch_bounds__(256, CIN == 64 ? 3 : 2) void pwdw_kernel(const PwDw
             wt[t][0] = w0.x; wt[t][1] = w0.y; wt[t][2] = w0.z; wt[t][3] = w0.w;
         }
         load8((const float *)(sW + 5 * p.Cdw + c0), bs);
+        // the bias is the fp16 accumulator's initial value (v_cvt_pkrtz: round toward zero, |b| > 65504 saturates)
 #pragma unroll
         for (int j = 0; j < 4; ++j) b2[j] = pk_h2(bs[2 * j], bs[2 * j + 1]);
         // phase 1: t[hp][64 ch] = W_chunk . xn, 3 m-tiles per wave (fragments re-read per chunk: registers
@@ -696,7 +697,11 @@ __global__ __launch_bounds__(256, 3) void dwconv_gram_kernel(const DwGramParams 
             for (int k = 0; k < NLD; ++k) {
                 const int idx = tl + k * 256, hp = idx >> 3;
                 const u32x4 z4 = {0, 0, 0, 0};
-                // bf16 (HBM) -> fp16 pairs (dw_row_f16): exact for |x| < 65504 with <= 11 significant bits -- every bf16 is
+                // bf16 (HBM) -> fp16 pairs (dw_row_f16): the 8-bit MANTISSA of a bf16 always fits fp16's 11 bits, the
+                // exponent does not -- magnitudes below 6.1e-5 become fp16 subnormals, below ~3e-8 zero, above 65504
+                // saturate.  q and k are L2-normalised per channel afterwards (src/DADiff.py:273-274), so the host packs
+                // their 1x1 rows and depthwise taps with a per-channel power-of-two scale that brings them to O(1)
+                // (engine.py: _qk_prescale; the norm cancels it exactly): in range for any checkpoint.
                 const u32x4 rv = r[k];
                 const uint32_t rw[4] = {rv.x, rv.y, rv.z, rv.w};
                 uint32_t hw4[4];
@@ -861,7 +866,7 @@ extern "C" int fd_dwconv_gram_nblk(int H, int W) {
 
 extern "C" int fd_dwconv_gram(int dtype, const void *qkv, int ld, int C, const uint32_t *w_dw, float *partial, int B, int H,
                               int W, void *stream) {
-    FD_REQUIRE(fd_dwconv_gram_ok(dtype, C, H, W) || getenv("FD_NO_DWGRAM"), "fd_dwconv_gram: unsupported shape (bf16, C %% 64, H %% 8, W %% 16): C=%d H=%d W=%d", C, H, W);
+    FD_REQUIRE(fd_dwconv_gram_ok(dtype, C, H, W), "fd_dwconv_gram: unsupported shape (bf16, C %% 64, H %% 8, W %% 16): C=%d H=%d W=%d", C, H, W);
     FD_REQUIRE(qkv && w_dw && partial && ld % 8 == 0 && ld >= 2 * C && ((uintptr_t)w_dw & 15) == 0, "fd_dwconv_gram: bad args");
     DwGramParams p;
     p.qkv = (const bf16 *)qkv; p.ld = ld; p.C = C; p.w_dw = w_dw; p.part = partial;

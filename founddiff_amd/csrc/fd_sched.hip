@@ -32,9 +32,10 @@ __device__ __forceinline__ u32q philox4x32_10(u32q c, uint32_t k0, uint32_t k1) 
 // four standard normals of (seed, t, group g of four consecutive pixels)
 __device__ __forceinline__ void keyed_normal4(uint64_t seed, uint32_t t, uint32_t g, float z[4]) {
     const u32q r = philox4x32_10(u32q{g, t, 0x46444e5au, 0u}, (uint32_t)seed, (uint32_t)(seed >> 32));
-    // 24-bit uniforms in (0, 1): exactly representable, never 0 or 1
-    const float u0 = ((float)(r.x >> 8) + 0.5f) * (1.f / 16777216.f), u1 = ((float)(r.y >> 8) + 0.5f) * (1.f / 16777216.f);
-    const float u2 = ((float)(r.z >> 8) + 0.5f) * (1.f / 16777216.f), u3 = ((float)(r.w >> 8) + 0.5f) * (1.f / 16777216.f);
+    // 23-bit uniforms (k + 0.5) * 2^-23, k < 2^23: k + 0.5 has 24 significant bits, so every value is exactly
+    // representable, strictly inside (0, 1) and the grid is uniform over the whole range
+    const float u0 = ((float)(r.x >> 9) + 0.5f) * (1.f / 8388608.f), u1 = ((float)(r.y >> 9) + 0.5f) * (1.f / 8388608.f);
+    const float u2 = ((float)(r.z >> 9) + 0.5f) * (1.f / 8388608.f), u3 = ((float)(r.w >> 9) + 0.5f) * (1.f / 8388608.f);
     const float ra = sqrtf(-2.f * logf(u0)), rb = sqrtf(-2.f * logf(u2));
     float s0, c0, s1, c1;
     sincospif(2.f * u1, &s0, &c0);
@@ -59,7 +60,7 @@ __global__ void keyed_normal_kernel(const int64_t *__restrict__ seeds, int t, fl
 
 // start of an ancestral step: t <- t - 1, time[b] <- times[t] (the UNet's time input alphas_cumsum[t] * T)
 __global__ void ancestral_begin_kernel(int *t_dev, const float *__restrict__ times, float *__restrict__ time_buf, int B) {
-    const int t = *t_dev - 1;
+    const int t = max(*t_dev - 1, 0);          // a caller that runs more steps than the table has rows repeats t = 0
     __syncthreads();
     if (threadIdx.x == 0) *t_dev = t;
     for (int b = threadIdx.x; b < B; b += blockDim.x) time_buf[b] = times[t];
@@ -72,7 +73,7 @@ __global__ void res_posterior_keyed_kernel(const float *__restrict__ mo, const f
                                            const int64_t *__restrict__ seeds, float *out, float *__restrict__ xs_out,
                                            int64_t npix) {
     const int b = blockIdx.y;
-    const int t = *t_dev;
+    const int t = max(*t_dev, 0);
     const float c1 = coef_table[t * 4], c2 = coef_table[t * 4 + 1], c3 = coef_table[t * 4 + 2];
     const float sd = t > 0 ? expf(0.5f * coef_table[t * 4 + 3]) : 0.f;       // no noise at t = 0 (src/DADiff.py:1228)
     const uint64_t seed = (uint64_t)seeds[b];
@@ -94,9 +95,22 @@ __global__ void res_posterior_keyed_kernel(const float *__restrict__ mo, const f
     }
 }
 
+__global__ void stream_delay_kernel(long long ticks) {
+    const long long t0 = wall_clock64();                       // constant 100 MHz, independent of the shader clock
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
 inline int g4(int64_t npix) { int64_t b = ((npix + 3) / 4 + 255) / 256; return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b)); }
 
 }  // namespace
+
+extern "C" int fd_stream_delay(float usec, void *stream) {
+    FD_REQUIRE(usec >= 0.f && usec <= 1e6f, "fd_stream_delay: %g us is outside [0, 1 s]", (double)usec);
+    if (usec > 0.f)
+        hipLaunchKernelGGL(stream_delay_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long)(usec * 100.f));
+    FD_LAUNCH_OK("fd_stream_delay");
+    return FD_OK;
+}
 
 extern "C" int fd_keyed_normal(const int64_t *seeds, int t, float *out, int B, int64_t npix, void *stream) {
     FD_REQUIRE(seeds && out && B > 0 && npix > 0 && npix < (1ll << 33), "fd_keyed_normal: bad args");

@@ -144,6 +144,23 @@ class DAEngine:
         h = w9c.to(torch.float16).view(torch.int16).to(torch.int32) & 0xFFFF
         return (h[:, 0::2] | (h[:, 1::2] << 16)).contiguous()
 
+    @staticmethod
+    def _qk_prescale(qkv_w, dw_w, C_):
+        """Per-channel power-of-two scales for the q and k thirds of TransposedAttention's qkv / qkv_dwconv weights
+        (src/DADiff.py:266-276).  q and k are consumed only through F.normalize(dim=-1) (273-274), so any positive
+        per-channel factor cancels; a power of two commutes with every rounding (bf16 weights, fp16 on-chip tiles, fp32
+        sums), so the result is unchanged BIT FOR BIT as long as nothing leaves its range -- and that is the point:
+        the fused kernels keep q / k as fp16 on chip (fd_pwdw.hip), where a channel of ~1e-6 magnitude would be
+        subnormal or zero.  Rows are brought to unit norm (to the nearest power of two): the 1x1 output of a
+        LayerNorm'd pixel then has O(1) rms, the depthwise output likewise.  qkv_w (3C, C) / dw_w (3C, 9) fp32."""
+        qkv_w, dw_w = qkv_w.clone(), dw_w.clone()
+        for w in (qkv_w, dw_w):
+            n = w[:2 * C_].double().norm(dim=1)
+            e = torch.frexp(n)[1].clamp(-100, 100)
+            sc = torch.where((n > 0) & torch.isfinite(n), torch.ldexp(torch.ones_like(n), -e), torch.ones_like(n))
+            w[:2 * C_] *= sc[:, None].to(w.dtype)
+        return qkv_w, dw_w
+
     def _pack_mamba(self, s):
         m = s.sub("mamba.")
         C_ = s["norm1.weight"].shape[0]
@@ -153,6 +170,10 @@ class DAEngine:
         R = dtw.shape[2]
         D = dtw.shape[1]
         a = s.sub("attn_blk.")
+        qkv_w = a["qkv.weight"].detach().float().reshape(3 * C_, C_)
+        qdw = a["qkv_dwconv.weight"].detach().float().reshape(3 * C_, 9)
+        if self.tdt == torch.bfloat16:      # (the fp32 parity modes keep the checkpoint's values untouched)
+            qkv_w, qdw = self._qk_prescale(qkv_w, qdw, C_)
         d = dict(
             C=C_, N=N, R=R, D=D, CD=R + 2 * N, heads=a["temperature"].shape[0],
             n1w=self._f(s["norm1.weight"]), n1b=self._f(s["norm1.bias"]),
@@ -163,8 +184,8 @@ class DAEngine:
             A=self._f(-torch.exp(m["A_logs"].detach().float())), Ds=self._f(m["Ds"]),
             onw=self._f(m["out_norm.weight"]), onb=self._f(m["out_norm.bias"]),
             out_proj=self._convw(m["out_proj.weight"]),
-            qkv=self._convw(a["qkv.weight"]),
-            qdw_w=self._f(a["qkv_dwconv.weight"].reshape(3 * C_, 9).t()),
+            qkv=self._convw(qkv_w),
+            qdw_w=self._f(qdw.t()),
             temp=self._f(a["temperature"].reshape(-1)),
             wproj=self._f(a["project_out.weight"].reshape(C_, C_)),
         )

@@ -178,7 +178,7 @@ int fd_dwconv3x3(int dtype, const void *in, int ld_in, int off_in, const float *
  *          through SiLU to out_z (Cz = 0: none)
  *   w_dw   [9][Cdw/2] 32-bit words of fp16 tap weights, tap = 3*dy + dx, word j = (channel 2j low, 2j+1 high): the
  *          depthwise runs on v_pk_fma_f16 (the 1x1 output is kept in LDS as fp16 channel pairs, the 9-tap sum is
- *          accumulated in fp16; bias and SiLU in fp32).  b_dw [Cdw] fp32 or NULL
+ *          accumulated in fp16 starting from the bias rounded to fp16 (toward zero); SiLU in fp32).  b_dw [Cdw] fp32 or NULL
  *   ln_*   as fd_conv_params' LN_MOD prologue (gamma/beta may be NULL)
  * fd_pw_dw3x3_ok: 1 if the shape is served (callers fall back to fd_conv2d + fd_dwconv3x3).   */
 int fd_pw_dw3x3_ok(int dtype, int Cin, int Cdw, int Cz, int H, int W);
@@ -193,7 +193,9 @@ int fd_pw_dw3x3(int dtype, const void *x, int ld_x, int off_x, int Cin, const fl
  * reach HBM: only v (out_v, [B,H,W,ld_v] channels [off_v, +64)) and one partial per workgroup do --
  * partial [B][2 heads][nblk][1024 + 64] fp32 in fd_chan_attn_gram's layout (Gram rows = q channels; then sum q^2,
  * sum k^2), nblk = fd_pw_dw3x3_gram_nblk(H, W), reduced in fixed order by fd_chan_attn_weff.  bf16, Cin = 64 (two
- * heads), w_pw [192][64] (q | k | v rows), w_dw [9][96] as for fd_pw_dw3x3, no bias; q and k are fp16 on chip (f16 MFMA).                       */
+ * heads), w_pw [192][64] (q | k | v rows), w_dw [9][96] as for fd_pw_dw3x3, no bias; q and k are fp16 on chip (f16 MFMA):
+ * their magnitudes must sit inside fp16's range -- they are L2-normalised per channel afterwards, so a per-channel
+ * power-of-two scale folded into their w_pw rows / w_dw taps is free (founddiff_amd/engine.py does that at pack time). */
 int fd_pw_dw3x3_gram_ok(int dtype, int Cin, int H, int W);
 int fd_pw_dw3x3_gram_nblk(int H, int W);
 int fd_pw_dw3x3_gram(int dtype, const void *x, int ld_x, int off_x, int Cin, const float *ln_gamma,
@@ -373,6 +375,11 @@ int fd_ancestral_begin(int *t_dev, const float *times, float *time_buf, int B, v
 int fd_res_posterior_step_keyed(const float *model_out, const float *x_t, const float *x_in,
                                 const float *coef_table, const int *t_dev, const int64_t *seeds,
                                 float *img_out, float *x_start_out, int B, int64_t npix, void *stream);
+/* fd_stream_delay: one wave that idles for `usec` microseconds (s_sleep on the constant-rate 100 MHz counter) on
+ *   `stream`.  The sampler runs a batch as two concurrent half-batches on two HIP streams; delaying
+ *   one of them by part of a UNet forward makes the MFMA-bound kernels of one half meet the VALU- / HBM-bound kernels
+ *   of the other instead of their twins.  No reference counterpart (the reference is single-stream).              */
+int fd_stream_delay(float usec, void *stream);
 /* ---- vanilla DDPM U-Net extras (src/denoising_diffusion_pytorch.py) -----------------------
  * fd_gn_film_silu_apply: silu(GN(h)*(1+scale[b]) + shift[b])   Block w/ scale_shift, 190-199, 213-221
  * fd_chan_ln:            LN over channels * g (+ res)           LayerNorm/PreNorm/Residual, 95-101,127-146

@@ -1,6 +1,6 @@
 """TEST INFRASTRUCTURE ONLY -- numpy restatement of the per-slice keyed step noise of the ancestral sampler
 (founddiff_amd/csrc/fd_sched.hip: Philox4x32-10 keyed by the slice seed, counter = (pixel // 4, t, tag, 0),
-Box-Muller on 24-bit uniforms).  The reference has no counterpart: it draws torch.randn_like(x) from the device
+Box-Muller on 23-bit uniforms (k + 0.5) / 2^23).  The reference has no counterpart: it draws torch.randn_like(x) from the device
 generator (/root/reference/src/DADiff.py:1228), which ties a slice's noise to its place in the batch; the keyed stream
 is what makes a sharded BASELINE configs[3] volume independent of the world size.  Parity of the noise VALUES with the
 reference is therefore neither possible nor claimed -- parity tests feed explicit noise tensors (`step_noise=`)."""
@@ -30,7 +30,7 @@ def keyed_normal(seed, t, npix):
     g = np.arange(ng, dtype=np.uint64)
     z = np.zeros(ng, dtype=np.uint64)
     r = philox4x32_10(g, z + np.uint64(t & MASK), z + np.uint64(TAG), z, seed & MASK, seed >> 32)
-    u = [((v >> np.uint64(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0) for v in r]
+    u = [((v >> np.uint64(9)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 8388608.0) for v in r]
     ra = np.sqrt(np.float32(-2.0) * np.log(u[0])).astype(np.float32)
     rb = np.sqrt(np.float32(-2.0) * np.log(u[2])).astype(np.float32)
     a0, a1 = np.float32(2.0 * np.pi) * u[1], np.float32(2.0 * np.pi) * u[3]

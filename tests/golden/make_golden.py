@@ -49,13 +49,25 @@ def rnd(*shape, seed=0, scale=1.0):
 
 
 def save(name, spec=None, seed=SEED_W, **arrs):
+    """One .npz per fixture, written so that the FILE is reproducible byte for byte: keys in sorted order, the spec as
+    sorted-key JSON, zip members with a fixed timestamp (np.savez stamps them with the wall clock)."""
+    import io
+    import zipfile
     out = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v))
            for k, v in arrs.items()}
     if spec is not None:
-        out["spec_json"] = np.frombuffer(json.dumps(spec).encode(), dtype=np.uint8)
+        out["spec_json"] = np.frombuffer(json.dumps(spec, sort_keys=True).encode(), dtype=np.uint8)
         out["weight_seed"] = np.asarray(seed)
     path = os.path.join(os.environ.get("FD_GOLDEN_OUT", HERE), name + ".npz")     # tests regenerate into a temp dir
-    np.savez_compressed(path, **out)
+    with zipfile.ZipFile(path, "w", compression=zipfile.ZIP_DEFLATED, compresslevel=6) as zf:
+        for k in sorted(out):
+            buf = io.BytesIO()
+            a = out[k]
+            np.lib.format.write_array(buf, np.ascontiguousarray(a) if a.ndim else a, allow_pickle=False)
+            zi = zipfile.ZipInfo(k + ".npy", date_time=(1980, 1, 1, 0, 0, 0))
+            zi.compress_type = zipfile.ZIP_DEFLATED
+            zi.external_attr = 0o644 << 16
+            zf.writestr(zi, buf.getvalue(), compresslevel=6)
     print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
 
 

@@ -89,6 +89,44 @@ def test_mamba_block(golden, mode, tol, tag):
     assert rel_err(nchw(out), g[p + "out"]) < tol
 
 
+@pytest.mark.parametrize("C_,H,W", [(64, 32, 32), (128, 32, 32)])
+def test_tiny_qk_channels_stay_in_fp16_range(C_, H, W):
+    """the fused Gram kernels keep q / k as fp16 on chip; a q / k channel whose weights are ~1e-6 would be
+    subnormal or zero there and get a garbage direction where the reference's F.normalize (src/DADiff.py:273-274) gives
+    a unit vector.  The engine packs q / k rows with per-channel power-of-two scales (DAEngine._qk_prescale), which the
+    L2 norm cancels exactly: a block whose q / k weights are scaled by 2^-22 / 2^-9 on some channels must give the
+    SAME BITS as the unscaled block (C = 64: pwdw_gram_kernel, C = 128: row-GEMM + dwconv_gram_kernel)."""
+    from founddiff_amd import _lib as L, arch, synth
+    from founddiff_amd.engine import _Sub
+    spec = {}
+    arch._mamba(spec, "b.", C_, 4, 256)
+    w = synth.synth_state_dict(spec, seed=11)
+    w2 = {k: v.clone() for k, v in w.items()}
+    for c in (3, C_ - 1, C_ + 5, 2 * C_ - 2):            # two q and two k channels
+        w2["b.attn_blk.qkv.weight"][c] *= 2.0 ** -22
+        w2["b.attn_blk.qkv_dwconv.weight"][c] *= 2.0 ** -9
+    B = 2
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, C_, H, W, generator=g)
+    t, c = torch.randn(B, 256, generator=g), torch.randn(B, 256, generator=g)
+    outs = []
+    for wd in (w, w2):
+        e = bare_engine("bf16")
+        m = e._pack_mamba(_Sub(wd, "b."))
+        m["mod_off"], m["loc_off"] = 0, 0
+        e.mod_total, e.loc_total = 6 * C_, m["D"]
+        e.mod_all = torch.empty(B, 6 * C_, device="cuda")
+        e.linear(t.cuda(), m.pop("adaln_w").cuda(), m.pop("adaln_b").cuda(), e.mod_all, pre_silu=True)
+        e.local_all = torch.empty(B, m["D"], device="cuda")
+        e.linear(c.cuda(), m.pop("local_w").cuda(), None, e.local_all, L.ACT_SILU)
+        assert L.lib().fd_pw_dw3x3_gram_ok(e.dt, C_, H, W) == (C_ == 64)
+        assert C_ == 64 or L.lib().fd_dwconv_gram_ok(e.dt, C_, H, W)
+        outs.append(e.mamba_block(m, nhwc(x, e.tdt), B, H, W, "t").clone())
+    torch.cuda.synchronize()
+    assert torch.isfinite(outs[0].float()).all()
+    assert torch.equal(outs[0], outs[1])
+
+
 def _tiny_model(golden, precision, S=10):
     from founddiff_amd.DADiff import ResidualDiffusion, UnetRes, load_weights
     g = golden("e2e_da_tiny")

@@ -46,11 +46,18 @@ def diff_state(sd, spec, unet_prefixes=("model.unet0.",), extra_dead=()):
                 ok=not missing and not mism and not unexpected)
 
 
-def inspect_checkpoint(path, dim=64, dim_mults=(1, 2, 4, 8), num_unet=1, input_condition=False, clip=None):
+def inspect_checkpoint(path, dim=64, dim_mults=(1, 2, 4, 8), num_unet=1, input_condition=False, clip=None,
+                       unsafe=False):
+    """`unsafe=False`: the file is read with torch.load(weights_only=True) -- tensors and plain containers only, no
+    arbitrary unpickling of an untrusted file.  A checkpoint that carries other pickled objects (the reference saves its
+    GradScaler state and version string, src/DADiff.py:1630-1636) needs `unsafe=True` (--unsafe): full unpickling, only
+    for files whose origin is trusted."""
     from founddiff_amd import arch
     from founddiff_amd.DADiff import residual_schedule
     clip = clip or arch.RN50
-    data = torch.load(path, map_location="cpu", weights_only=False)
+    data, err = _load(path, unsafe)
+    if err:
+        return {"file": path, "ok": False, "top_level_keys": None, "error": err}
     rep = {"file": path, "top_level_keys": sorted(data) if isinstance(data, dict) else None}
     if not isinstance(data, dict) or "model" not in data:
         rep["error"] = "not the reference's checkpoint dict: no 'model' entry (src/DADiff.py:1630-1636)"
@@ -89,12 +96,25 @@ def inspect_checkpoint(path, dim=64, dim_mults=(1, 2, 4, 8), num_unet=1, input_c
     return rep
 
 
-def inspect_dose_clip(path, clip=None):
+def _load(path, unsafe):
+    """torch.load with the safe unpickler first; full unpickling only behind `unsafe` (see inspect_checkpoint)."""
+    try:
+        return torch.load(path, map_location="cpu", weights_only=True), None
+    except Exception as e:                                   # noqa: BLE001 -- report, do not fall back silently
+        if not unsafe:
+            return None, (f"torch.load(weights_only=True) refused the file ({type(e).__name__}: {e}); "
+                          "re-run with --unsafe if the file's origin is trusted")
+        return torch.load(path, map_location="cpu", weights_only=False), None
+
+
+def inspect_dose_clip(path, clip=None, unsafe=False):
     """Dose-CLIP.pth = CLIPIQA(model_type='clipiqa+').state_dict() (src/DADiff.py:595-596): the live part is
     clip_model.visual.*, head1.*, head2.*; prompt_learner.* and the CLIP text side are dead on the sampling path."""
     from founddiff_amd import arch
     clip = clip or arch.RN50
-    sd = torch.load(path, map_location="cpu", weights_only=False)
+    sd, err = _load(path, unsafe)
+    if err:
+        return {"file": path, "ok": False, "error": err}
     if isinstance(sd, dict) and "state_dict" in sd and not any(k.startswith("head1") for k in sd):
         sd = sd["state_dict"]
     full = arch.da_unet_spec(64, (1, 2, 4, 8), prefix="", clip=clip)
@@ -126,15 +146,17 @@ def main():
     ap.add_argument("--dim-mults", default="1,2,4,8")
     ap.add_argument("--num-unet", type=int, default=1)
     ap.add_argument("--input-condition", action="store_true")
+    ap.add_argument("--unsafe", action="store_true", help="allow full unpickling (torch.load weights_only=False) when the "
+                    "safe loader refuses the file: trusted files only")
     ap.add_argument("--json", action="store_true", help="full report as JSON (default: shortened lists)")
     a = ap.parse_args()
     ok = True
     if a.checkpoint:
-        rep = inspect_checkpoint(a.checkpoint, a.dim, tuple(int(m) for m in a.dim_mults.split(",")), a.num_unet, a.input_condition)
+        rep = inspect_checkpoint(a.checkpoint, a.dim, tuple(int(m) for m in a.dim_mults.split(",")), a.num_unet, a.input_condition, unsafe=a.unsafe)
         print(json.dumps(rep if a.json else _short(rep), indent=1, default=str))
         ok &= rep["ok"]
     if a.dose_clip:
-        rep = inspect_dose_clip(a.dose_clip)
+        rep = inspect_dose_clip(a.dose_clip, unsafe=a.unsafe)
         print(json.dumps(rep if a.json else _short(rep), indent=1, default=str))
         ok &= rep["ok"]
     if not a.checkpoint and not a.dose_clip:
