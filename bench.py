@@ -332,12 +332,67 @@ def latency_leg(dev, x, noise, reps=3):
             "kernel_set": "low_latency (Trainer.test(batch_size=1))", "higher_is_better": False}
 
 
+def _smi_read():
+    """(sclk MHz, mclk MHz, socket power W) from one rocm-smi call, None where not available"""
+    import re
+    import subprocess
+    r = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=30)
+    d = json.loads(r.stdout)
+    card = d.get("card0") or next(iter(d.values()))
+    out = {}
+    for k, v in card.items():
+        kl = k.lower()
+        m = re.search(r"([0-9.]+)", str(v))
+        if not m:
+            continue
+        if kl.startswith("sclk") and "level" not in kl:
+            out["sclk_mhz"] = float(m.group(1))
+        elif kl.startswith("mclk") and "level" not in kl:
+            out["mclk_mhz"] = float(m.group(1))
+        elif "power" in kl and "(w)" in kl:
+            out["socket_power_w"] = float(m.group(1))
+    return out
+
+
+class SmiSampler:
+    """Polls rocm-smi from a host thread while the timed region runs: mean / min shader clock and mean socket power of
+    the region.  The headline workload holds the socket at its power cap (~1.4 kW) with the shader clock near 2.0 GHz
+    instead of the 2.4 GHz the peaks are quoted at: the reading says how much of a box-to-box difference is clock."""
+
+    def __init__(self, period=0.4):
+        import threading
+        self.period, self.samples, self._stop = period, [], threading.Event()
+        self._thr = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        while not self._stop.is_set():
+            try:
+                self.samples.append(_smi_read())
+            except Exception:                               # noqa: BLE001 -- a reading, not a requirement
+                pass
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        self._thr.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        self._thr.join(timeout=40)
+
+    def summary(self):
+        sc = [q["sclk_mhz"] for q in self.samples if "sclk_mhz" in q]
+        pw = [q["socket_power_w"] for q in self.samples if "socket_power_w" in q]
+        if not sc:
+            return None
+        return {"samples": len(sc), "sclk_mhz_mean": round(sum(sc) / len(sc), 1), "sclk_mhz_min": min(sc),
+                "socket_power_w_mean": round(sum(pw) / len(pw), 1) if pw else None}
+
+
 def clocks_under_load(lib, launches, seconds=1.5):
     """Shader clock and socket power WHILE the halo-conv launches replay (rocm-smi next to ~1.5 s of queued kernels), so a
     bench line can be attributed to its box: the pool's boxes differ by up to 1.5x on the MFMA-bound kernels
     (profiles/README.md).  None where rocm-smi is not usable."""
-    import re
-    import subprocess
     if not launches:
         return None
     one = _time_launches(lib, launches, reps=1)
@@ -347,21 +402,7 @@ def clocks_under_load(lib, launches, seconds=1.5):
             getattr(lib, name)(*args)
     out = None
     try:
-        r = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=30)
-        d = json.loads(r.stdout)
-        card = d.get("card0") or next(iter(d.values()))
-        out = {}
-        for k, v in card.items():
-            kl = k.lower()
-            m = re.search(r"([0-9.]+)", str(v))
-            if not m:
-                continue
-            if kl.startswith("sclk") and "level" not in kl:
-                out["sclk_mhz"] = float(m.group(1))
-            elif kl.startswith("mclk") and "level" not in kl:
-                out["mclk_mhz"] = float(m.group(1))
-            elif "power" in kl and "(w)" in kl:
-                out["socket_power_w"] = float(m.group(1))
+        out = _smi_read()
         out["queued_ms"] = round(one * n, 1)
     except Exception as e:                               # noqa: BLE001 -- a reading, not a requirement
         out = {"error": f"{type(e).__name__}: {e}"[:200]}
@@ -441,6 +482,9 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    smi = SmiSampler() if rank == 0 else None
+    if smi:
+        smi.__enter__()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         vol = step()
@@ -448,6 +492,8 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    if smi:
+        smi.__exit__()
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -474,6 +520,7 @@ def main():
                        "collective; 1 all-gather of the output volume"},
             "ms_per_unet_forward_per_slice": round(dt / a.steps / a.ddim_steps / B * 1e3, 3),
             "alg_tflops_sustained": round(ALG_GFLOP_PER_FORWARD * a.ddim_steps * slices / dt / 1e3, 1),
+            "box_during_timed_region": smi.summary(),
         }
         if a.sampler == "ancestral":
             res["metric"] = "denoised CT slices/sec (512x512, 1000-step ancestral p_sample_loop)"

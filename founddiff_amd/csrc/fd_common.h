@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include "../../include/founddiff_hip.h"
 
 typedef __bf16 bf16;
@@ -45,6 +47,34 @@ template <> struct TT<bf16> { static constexpr int CH = 8; };
 // (v_div_scale/fmas/fixup: ~10 instructions and 4 live registers per element).
 __device__ __forceinline__ float fd_silu(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+// the same on a PAIR (v_pk_mul / v_pk_add around the four transcendentals): 11 instead of 14 issue slots per two
+// elements, bit-identical to fd_silu per element (packed fp32 ops round like the scalar ones)
+__device__ __forceinline__ f32x2 fd_silu2(f32x2 x) {
+    const f32x2 t = x * -1.4426950408889634f;
+    const f32x2 e = f32x2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + 1.0f;
+    return x * f32x2{__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y)};
+}
+__device__ __forceinline__ void fd_silu8(float (&v)[8]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x2 r = fd_silu2(f32x2{v[2 * j], v[2 * j + 1]});
+        v[2 * j] = r.x;
+        v[2 * j + 1] = r.y;
+    }
+}
+// val += silu((h - mean) * rstd * gamma + beta) on 8 channels: the GroupNorm + SiLU + residual tail of a ResnetBlock
+// (src/DADiff.py:213-229, 397-430) in packed fp32
+__device__ __forceinline__ void fd_gn_silu_add8(float (&val)[8], const float (&h)[8], float mean, float rstd,
+                                                const float (&gamma)[8], const float (&beta)[8]) {
+    const float nm = -mean * rstd;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x2 t = f32x2{h[2 * j], h[2 * j + 1]} * rstd + nm;
+        const f32x2 r = fd_silu2(t * f32x2{gamma[2 * j], gamma[2 * j + 1]} + f32x2{beta[2 * j], beta[2 * j + 1]});
+        val[2 * j] += r.x;
+        val[2 * j + 1] += r.y;
+    }
 }
 __device__ __forceinline__ float fd_softplus(float x) { return x > 20.0f ? x : log1pf(__expf(x)); }
 // softplus without libm: for x < -4 the series e - e^2/2 + e^3/3 of log1p(e), e = exp(x) < 0.0184
@@ -94,6 +124,69 @@ __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
+}
+
+// v + (v of the lane the DPP control selects): one v_add_f32_dpp.  0xB1 / 0x4E = lane ^ 1 / lane ^ 2 inside a quad,
+// 0x141 = row_half_mirror (lane 7 - i of each 8), 0x140 = row_mirror (lane 15 - i of each 16): after the two quad steps
+// every lane of a quad holds the quad's sum, so the mirrors pair whole quads -- sums over 8 / 16 neighbouring lanes
+// without ds_bpermute (an LDS round trip per step) and with the same bits in every lane of the group.
+template <int CTRL>
+__device__ __forceinline__ float fd_dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int LANES>
+__device__ __forceinline__ float fd_group_sum(float v) {
+    static_assert(LANES == 4 || LANES == 8 || LANES == 16, "fd_group_sum: 4, 8 or 16 neighbouring lanes");
+    v = fd_dpp_add<0xB1>(v);
+    v = fd_dpp_add<0x4E>(v);
+    if (LANES >= 8) v = fd_dpp_add<0x141>(v);
+    if (LANES >= 16) v = fd_dpp_add<0x140>(v);
+    return v;
+}
+
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+__device__ __forceinline__ uint32_t fd_pack_bf16(f32x2 v) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2)); }
+__device__ __forceinline__ f32x2 fd_unpack_bf16(uint32_t w) {
+    return f32x2{__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xffff0000u)};
+}
+
+// LayerNorm + modulate of one 16-byte chunk (8 bf16 channels) of a pixel whose C = 8 * LANES channels sit in LANES
+// neighbouring lanes (src/DADiff.py:450-451, 477-488: x_n = LN(x) * g + b with g = gamma (1 + scale), b = beta (1 + scale)
+// + shift folded by the caller).  One pass (sum and sum of squares, fp32), packed fp32 arithmetic, DPP group sums:
+// ~40 issue slots per chunk (the two-pass scalar form with ds_bpermute shuffles took ~120 and six LDS round trips).
+template <int LANES>
+__device__ __forceinline__ u32x4 fd_ln_mod_chunk(u32x4 raw, const f32x2 (&g)[4], const f32x2 (&b)[4], float eps) {
+    const uint32_t rw[4] = {raw.x, raw.y, raw.z, raw.w};
+    f32x2 x[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] = fd_unpack_bf16(rw[j]);
+    const f32x2 s = (x[0] + x[1]) + (x[2] + x[3]);
+    f32x2 q = x[0] * x[0];
+    q = x[1] * x[1] + q;
+    q = x[2] * x[2] + q;
+    q = x[3] * x[3] + q;
+    const float s1 = fd_group_sum<LANES>(s.x + s.y), s2 = fd_group_sum<LANES>(q.x + q.y);
+    constexpr float inv = 1.f / (8 * LANES);
+    const float mean = s1 * inv;
+    const float var = fmaxf(s2 * inv - mean * mean, 0.f);
+    const float rstd = __builtin_amdgcn_rsqf(var + eps), nm = -mean * rstd;
+    uint32_t o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x2 t = x[j] * rstd + nm;
+        o[j] = fd_pack_bf16(t * g[j] + b[j]);
+    }
+    return u32x4{o[0], o[1], o[2], o[3]};
+}
+
+// Development switch FD_PAD_<NAME>=<KiB>: extra dynamic LDS requested per workgroup of kernel family NAME, i.e. a cap on
+// its workgroups per CU -- used to study how kernels of the two concurrent sub-batch streams share a CU
+// (tools/probes/corun.py).  0 (unset) in production.
+static inline size_t fd_occ_pad(const char *name) {
+    char key[64];
+    snprintf(key, sizeof key, "FD_PAD_%s", name);
+    const char *e = getenv(key);
+    return e ? (size_t)atoi(e) * 1024 : 0;
 }
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

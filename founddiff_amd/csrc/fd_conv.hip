@@ -383,10 +383,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const fd_conv_
                     val[4 + e] = acc[i][2 * jp + 1][e] + bias8[4 + e];
                 }
                 if (p.epilogue == FD_EPI_SILU_SPLIT) {
-                    if (n0 >= p.epi_split) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) val[e] = fd_silu(val[e]);
-                    }
+                    if (n0 >= p.epi_split) fd_silu8(val);
                 } else if (p.epilogue == FD_EPI_RELU) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) val[e] = fmaxf(val[e], 0.f);
@@ -403,8 +400,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const fd_conv_
                 } else if (p.epilogue == FD_EPI_GNSILU_ADD) {
                     float hv[8];
                     load8((const T *)p.h + pix * p.Cout + n0, hv);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) val[e] += fd_silu((hv[e] - gm) * gr * ev0[e] + ev1[e]);
+                    fd_gn_silu_add8(val, hv, gm, gr, ev0, ev1);
                 }
                 if (p.out_f32) store8((float *)p.out + pix * p.ldo + p.offo + n0, val);
                 else store8((T *)p.out + pix * p.ldo + p.offo + n0, val);
@@ -622,9 +618,11 @@ __global__ void gn_silu_apply_kernel(const T *__restrict__ h, const float *__res
         load8(h + off, hv);
         if (res) load8(res + off, rv);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float y = fd_silu(hv[e] * sc[e] + sh[e]);
-            o[e] = res ? y + rv[e] : y;
+        for (int j = 0; j < 4; ++j) {
+            f32x2 y = fd_silu2(f32x2{hv[2 * j], hv[2 * j + 1]} * f32x2{sc[2 * j], sc[2 * j + 1]} + f32x2{sh[2 * j], sh[2 * j + 1]});
+            if (res) y = y + f32x2{rv[2 * j], rv[2 * j + 1]};
+            o[2 * j] = y.x;
+            o[2 * j + 1] = y.y;
         }
         store8(out + off, o);
     }

@@ -10,9 +10,10 @@
 // im2col copy exists anywhere.  Global->LDS traffic for A drops 9x -> 1.4x, the only per-tap
 // traffic is the 8/16 KiB weight tile (L2-resident, register-prefetched one tap ahead), and the
 // next slab's halo is in flight during the current slab's 9 taps.
-// Epilogue = the generic kernel's (LDS-staged accumulators, row-contiguous 16-byte stores,
-// deterministic per-tile GroupNorm partial sums).
+// Epilogue straight from the accumulators (the weights are the MFMA's A operand: a lane holds 8 consecutive channels
+// of a pixel, 16-byte stores, no LDS staging); deterministic per-tile GroupNorm partial sums.
 #include "fd_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -46,8 +47,35 @@ __device__ __forceinline__ int swz(int row, int chunk) {
 // the LDS fragment bytes, half the weight DMA and a quarter of the MFMA instructions of the bf16 form.
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 
+// The weights are the MFMA's A operand (D = W . X^T: a lane's 4 accumulator values of a 16x16 tile are 4 ROWS = 4
+// output channels of ONE pixel), and row R of a weight tile in LDS holds output channel
+//   R = 32 a + 16 p + 4 b + e   ->   32 a + 8 b + 4 p + e
+// so that the two tiles (p = 0, 1) of a 32-row group give lane group b = lane / 16 the 8 CONSECUTIVE channels
+// 32 a + 8 b .. + 7 of its pixel: the epilogue stores 16 bytes per lane straight from the accumulators -- no LDS
+// staging of the C tile, no barrier between the last MFMA and the stores.
+__device__ __forceinline__ int tile_row_channel(int R) {
+    return (R & ~31) | (((R >> 2) & 3) << 3) | (((R >> 4) & 1) << 2) | (R & 3);
+}
+
+// x summed over the 16 lanes of a DPP row, the total in every lane: xor 1, xor 2 (quad permutes), then the mirrored
+// other quad of the 8-lane half and the mirrored other half of the row -- 4 v_add_f32_dpp, no LDS, a fixed order.
+__device__ __forceinline__ float row16_sum(float x) {
+    const auto dpp = [](float v, int ctrl) -> float {
+        const int r = ctrl == 0xB1   ? __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)
+                      : ctrl == 0x4E ? __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)
+                      : ctrl == 0x141 ? __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)
+                                      : __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true);
+        return __builtin_bit_cast(float, r);
+    };
+    x += dpp(x, 0xB1);        // quad_perm [1,0,3,2]
+    x += dpp(x, 0x4E);        // quad_perm [2,3,0,1]
+    x += dpp(x, 0x141);       // row_half_mirror
+    x += dpp(x, 0x140);       // row_mirror
+    return x;
+}
+
 template <int BN, int TH, bool F8>
-__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_params p) {
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_params p, const int tpw, const int tiles_xy) {
     constexpr int BM = TH * TW, HY = TH + 2, HP = HY * HX;
     constexpr int HL = (HP * 8 + 255) / 256;          // halo 16-byte LDS chunks per thread
     constexpr int SLABC = F8 ? 128 : 64;              // channels per K slab
@@ -55,17 +83,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
     constexpr int ESZ = F8 ? 1 : 2;                   // bytes per weight element
     constexpr int WMW = TH / 4, WNW = 4 / WMW;        // wave grid
     constexpr int NB = BN / 32, NT = BN / WNW / 16, MT = 4;
-    constexpr int HALO_B = HP * ROWB;                 // 23040
+    constexpr int HALO_B = HP * ROWB;                 // 23040 (TH = 8) / 41472 (TH = 16)
     constexpr int WT_B = BN * ROWB;
     constexpr int NWB = 3;                         // weight-tile ring (LDS-DMA, two taps ahead)
-    constexpr int LOOP_B = HALO_B + NWB * WT_B;    // ONE halo buffer (the next slab waits in registers)
-    constexpr int C_B = BM * BN * 4;
-    constexpr int SM_B = LOOP_B > C_B ? LOOP_B : C_B;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[SM_B];
+    constexpr int LOOP_B = HALO_B + NWB * WT_B;    // ONE halo buffer (the next slab / tile waits in registers)
+    constexpr int NPASS = BN / 64;                 // epilogue passes: the C tile is staged 64 channels at a time
+    constexpr int RB = BM * 8 / 256;               // 16-byte chunks of a staged pass per thread
+    static_assert(BM * 128 <= HALO_B, "the C staging of one pass lives in the (dead) halo buffer");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LOOP_B];
     __shared__ float s_stat[4][BN][2];
+    __shared__ __attribute__((aligned(16))) float s_bias[BN], s_wsc[BN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_x = p.OW / TW;
-    const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
+    // a workgroup owns tpw consecutive tiles (row-major: neighbours share halo columns through L2) of image b,
+    // channel tile nt
+    const int t_begin = blockIdx.x * tpw, t_end = min(t_begin + tpw, tiles_xy);
     const int nt = blockIdx.y, b = blockIdx.z;
     const int Cin = p.c0 + p.c1, K = 9 * Cin, nslab = Cin / SLABC;
     const int Hs = p.OH, Ws = p.OW;                   // conv input grid == output grid (stride 1, pad 1)
@@ -76,31 +108,76 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
     // ---- halo loader: chunk ids hid = tid + 256*i -> (halo pixel, 16-byte channel chunk)
     // Every load is issued (from a clamped in-image address, zeroed on the LDS store where it was
     // padding): the s_waitcnt bookkeeping of the weight ring below counts wave-level VMEM instructions.
-    int hoff[HL];          // element offset of the (clamped) source pixel inside the image
-    uint32_t hvalid = 0;
-#pragma unroll
-    for (int i = 0; i < HL; ++i) {
-        const int hid = tid + 256 * i;
-        const int hp = min(hid >> 3, HP - 1);
-        const int hy = hp / HX, hx = hp - hy * HX;
-        int y = ty0 + hy - 1, x = tx0 + hx - 1;
-        if (y >= 0 && y < Hs && x >= 0 && x < Ws) hvalid |= 1u << i;
-        y = min(max(y, 0), Hs - 1);
-        x = min(max(x, 0), Ws - 1);
+    // The geometry is recomputed per load / store from an OPAQUE copy of tid (~10 VALU per chunk against a slab's
+    // 288 MFMAs): as loop invariants the HL source offsets and HL LDS addresses were kept in -- spilled -- registers,
+    // and a scratch reload is a VMEM operation whose s_waitcnt vmcnt(0) also waits for the weight DMA just issued.
+    // chunk i of a thread is halo pixel hp0 + 32 i: (row, column) advance by (1, 14) with a carry at 18 -- a division
+    // only for chunk 0
+    struct HaloPos { int hy, hx; };
+    auto halo_first = [&](int tl) -> HaloPos {
+        const int hp = tl >> 3;
+        const int hy = hp / HX;
+        return {hy, hp - hy * HX};
+    };
+    auto halo_next = [&](HaloPos &q) {
+        q.hx += 32 - HX;
+        q.hy += 1;
+        if (q.hx >= HX) { q.hx -= HX; q.hy += 1; }
+    };
+    auto halo_geom = [&](int tl, int i, HaloPos q, int ty0, int tx0, bool interior, bool &valid) -> int {    // element offset of the (clamped) source pixel
+        if (i == HL - 1 && (HL * 256) / 8 > HP) {        // chunks past the halo (never stored): any in-image address
+            const bool over = (tl >> 3) + 32 * i > HP - 1;
+            q.hy = over ? HY - 1 : q.hy;
+            q.hx = over ? HX - 1 : q.hx;
+        }
+        int y = ty0 + q.hy - 1, x = tx0 + q.hx - 1;
+        if (interior) {                                  // (wave-uniform) no halo pixel of this tile is padding
+            valid = true;
+        } else {
+            valid = (unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws;
+            y = min(max(y, 0), Hs - 1);
+            x = min(max(x, 0), Ws - 1);
+        }
         if (p.upsample) { y >>= 1; x >>= 1; }
-        hoff[i] = y * p.W + x;
-    }
+        return y * p.W + x;
+    };
     u32x4 rh[HL][HG];
-    auto halo_gload = [&](int slab) {
-        const int c = slab * SLABC + (tid & 7) * (SLABC / 8);     // a thread's 8 (16) channels come from ONE source
-        const bf16 *src;
-        int ld, cc;
-        if (c < p.c0) { src = in0; ld = p.ld0; cc = c; }
-        else { src = in1; ld = p.ld1; cc = c - p.c0; }
+    uint32_t hvalid = 0;                               // validity bits of the halo waiting in rh
+    auto halo_gload = [&](int slab, int ty0, int tx0) {
+        int tl = tid;
+        asm volatile("" : "+v"(tl));
+        const int c = slab * SLABC + (tl & 7) * (SLABC / 8);      // a thread's 8 (16) channels come from ONE source
+        const bool interior = !F8 && ty0 >= 1 && ty0 + TH < Hs && tx0 >= 1 && tx0 + TW < Ws;
+        hvalid = 0;
+        if constexpr (F8) {
+            const bf16 *src;
+            int ld, cc;
+            if (c < p.c0) { src = in0; ld = p.ld0; cc = c; }
+            else { src = in1; ld = p.ld1; cc = c - p.c0; }
+            HaloPos hq = halo_first(tl);
 #pragma unroll
-        for (int i = 0; i < HL; ++i)
+            for (int i = 0; i < HL; ++i, halo_next(hq)) {
+                bool v;
+                const int ho = halo_geom(tl, i, hq, ty0, tx0, interior, v);
+                if (v) hvalid |= 1u << i;
 #pragma unroll
-            for (int h = 0; h < HG; ++h) rh[i][h] = *(const u32x4 *)(src + (int64_t)hoff[i] * ld + cc + 8 * h);
+                for (int h = 0; h < HG; ++h) rh[i][h] = *(const u32x4 *)(src + (int64_t)ho * ld + cc + 8 * h);
+            }
+        } else {
+            // a 64-channel slab lies in ONE source (c0 % 64 == 0): wave-uniform base + a 32-bit byte offset per load
+            const bool first = slab * SLABC < p.c0;
+            const char *src = (const char *)(first ? in0 : in1);
+            const unsigned ld2 = 2u * (unsigned)(first ? p.ld0 : p.ld1);
+            const unsigned cc2 = 2u * (unsigned)(first ? c : c - p.c0);
+            HaloPos hq = halo_first(tl);
+#pragma unroll
+            for (int i = 0; i < HL; ++i, halo_next(hq)) {
+                bool v;
+                const unsigned h = (unsigned)halo_geom(tl, i, hq, ty0, tx0, interior, v);
+                if (v) hvalid |= 1u << i;
+                rh[i][0] = *(const u32x4 *)(src + (h * ld2 + cc2));
+            }
+        }
     };
     // two bf16 (one dword) -> two e4m3 bytes in the low / high half of `acc`
     auto cvt2 = [&](uint32_t w, uint32_t acc, bool hi) -> uint32_t {
@@ -112,9 +189,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
     };
     auto halo_lstore = [&]() {
         unsigned char *sH = smem;
+        int tl = tid;
+        asm volatile("" : "+v"(tl));
 #pragma unroll
         for (int i = 0; i < HL; ++i) {
-            const int hid = tid + 256 * i, hp = hid >> 3;
+            const int hid = tl + 256 * i, hp = hid >> 3;
             const u32x4 z4 = {0, 0, 0, 0};
             u32x4 v;
             if constexpr (F8) {
@@ -125,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
                     v[2 * h + 1] = cvt2(s4[3], cvt2(s4[2], 0u, false), true);
                 }
             } else v = rh[i][0];
-            if (hp < HP) *(u32x4 *)(sH + hp * ROWB + swz<F8>(hp, tid & 7)) = ((hvalid >> i) & 1) ? v : z4;
+            if (hp < HP) *(u32x4 *)(sH + hp * ROWB + swz<F8>(hp, tl & 7)) = ((hvalid >> i) & 1) ? v : z4;
         }
     };
     // ---- weight tiles ([BN rows][64 k] of tap t, slab s) by LDS-DMA (global_load_lds_dwordx4): no VGPR
@@ -141,17 +220,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
     for (int i = 0; i < NB; ++i) {
         const int r = 8 * (wave * NB + i) + (lane >> 3);
         const int c = swz<F8>(r, lane & 7) >> 4;          // the logical chunk that belongs in this lane's physical slot
-        const int n = min(nt * BN + r, p.Cout - 1);
+        const int n = min(nt * BN + tile_row_channel(r), p.Cout - 1);
         goff[i] = (unsigned)(n * K * ESZ + c * 16);
     }
     // Issued through inline asm on purpose: for __builtin_amdgcn_global_load_lds on a plain LDS array the
     // compiler's waitcnt pass (no alias scopes to tell the ring slots apart) inserts s_waitcnt vmcnt(0)
     // before the next ds_read of ANY LDS address, i.e. right after the request -- the opposite of a
     // prefetch.  The counted waits below are therefore manual.  (The compiler's own vmcnt accounting for the
-    // register halo loads stays safe: operations it does not know about only make its waits stricter.)
-    // M0 (the DMA's LDS base) is written inside the asm -- hipcc rejects "m0" in clobber lists as a reserved
-    // register, so each request saves and restores it.  The counted waits (FD_WAIT_VM below) assume exactly NB
-    // DMA instructions per wave and tap and HL register halo loads per wave and slab.
+    // register halo loads and the epilogue's stores stays safe: operations it does not know about only make its waits
+    // stricter.)  M0 (the DMA's LDS base) is written inside the asm -- hipcc rejects "m0" in clobber lists as a
+    // reserved register, so each request saves and restores it.  The counted waits assume exactly NB DMA
+    // instructions per wave and tap and HL * HG register halo loads per wave and slab; loads retire in order, so a
+    // store (or any other VMEM operation) still in flight only makes a counted wait longer, never shorter.
     const unsigned lds_w = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)smem + HALO_B +
                            __builtin_amdgcn_readfirstlane(wave) * NB * 1024;
     auto w_dma = [&](int slab, int tap, int buf) {
@@ -159,8 +239,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const unsigned dst = lds_w + buf * WT_B + i * 1024;       // wave-uniform: M0
-            // M0 is saved and restored around the request, so the compiler may keep its own value live in it
-            // (a future dynamic-indexing / readlane use) -- hipcc does not accept "m0" as a clobber
             unsigned m0_saved;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\t"
                          "s_mov_b32 m0, %0"
@@ -169,14 +247,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
     };
     // s_waitcnt vmcnt(n) alone (expcnt / lgkmcnt left at their maxima); gfx9 encoding
 #define FD_WAIT_VM(n) __builtin_amdgcn_s_waitcnt(((n) & 0xF) | (((n) >> 4) << 14) | (0x7 << 4) | (0xF << 8))
+    // ... and lgkmcnt(l): LDS operations return in order (no scalar loads are in flight inside the tap loop)
+#define FD_WAIT_VM_LGKM(n, l) __builtin_amdgcn_s_waitcnt(((n) & 0xF) | (((n) >> 4) << 14) | (0x7 << 4) | ((l) << 8))
 
     const int wm = wave / WNW, wn = wave % WNW;
     const int fr = lane & 15, fg = lane >> 4;
     f32x4 acc[MT][NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // LDS byte offsets of the A / B fragments, computed ONCE: with the 9 taps unrolled a tap is the
     // compile-time pick aoff[i + kh][kw] (6 halo rows x 3 column shifts cover all 36 (tap, m-tile) pairs)
@@ -197,158 +273,300 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
         boff[j] = r * ROWB + swz<F8>(r, F8 ? 2 * fg : fg);
     }
 
+    // bf16 register sets: weight fragments double-buffered, pixel fragments rolling (fa[i] is reloaded for the next
+    // half-step as soon as the NT MFMAs that read it are issued).  The second K32 step of a slab flips bit 6 of the
+    // swizzled offsets: one v_xor per read, kept opaque so that the compiler does not keep a second copy of the
+    // 18 + NT offsets in registers.
+    bf16x8 fa[MT], fb[2][NT];
+    auto koff = [&](int off, int ks) -> int {
+        if (ks == 0) return off;
+        int o;
+        asm volatile("v_xor_b32 %0, 64, %1" : "=v"(o) : "v"(off));
+        return o;
+    };
+    auto load_a = [&](int tap, int ks, int i) {
+        const int kh = tap / 3, kw = tap - kh * 3;
+        fa[i] = *(const bf16x8 *)(smem + koff(aoff[i + kh][kw], ks));              // pixel tile i = tile row 4 wm + i
+    };
+    auto load_b = [&](int tap, int ks, bf16x8 (&bq)[NT]) {
+        const unsigned char *sB = smem + HALO_B + (tap % NWB) * WT_B;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bq[j] = *(const bf16x8 *)(sB + koff(boff[j], ks));
+    };
+    // the MFMAs of one half-step; `next`: request the pixel fragments of half-step (ntap, nks) behind their last readers
+    auto half_step = [&](const bf16x8 (&bq)[NT], bool next, int ntap, int nks) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[j], fa[i], acc[i][j], 0, 0, 0);
+            if (next) load_a(ntap, nks, i);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // bias / fp8 weight scales of the channel tile: read from LDS by every tile's epilogue (a global load there would
+    // sit behind the weight DMA and halo loads in flight: vmcnt retires in order)
+    if (tid < BN) {
+        const int n = blockIdx.y * BN + tid;
+        s_bias[tid] = (p.bias && n < p.Cout) ? p.bias[n] : 0.f;
+        s_wsc[tid] = (F8 && n < p.Cout) ? p.w_scale[n] / p.act_scale : 1.f;
+    }
+    int ty0 = (t_begin / tiles_x) * TH, tx0 = (t_begin % tiles_x) * TW;
     w_dma(0, 0, 0);
     w_dma(0, 1, 1);
-    halo_gload(0);
+    if constexpr (!F8) w_dma(0, 2, 2);
+    halo_gload(0, ty0, tx0);
     halo_lstore();                                   // consumes the youngest loads: everything above has landed
     FD_WAIT_VM(0);
     __syncthreads();
-    for (int slab = 0; slab < nslab; ++slab) {
-        const bool has_next = slab + 1 < nslab;
-        const unsigned char *sH = smem;
+    if constexpr (!F8) {
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const bool last_tap = tap == 8;
-            // request tile q+2 into the buffer tile q-1 was read from (all waves are past that barrier)
-            const bool dma = tap + 2 < 9 || has_next;
-            if (tap == 0 && has_next) halo_gload(slab + 1);       // in flight during this slab's 9 taps
-            if (dma) w_dma(tap + 2 < 9 ? slab : slab + 1, (tap + 2) % 9, (tap + 2) % NWB);
-            const unsigned char *sB = smem + HALO_B + (tap % NWB) * WT_B;
-            const int kh = tap / 3, kw = tap - kh * 3;
+        for (int i = 0; i < MT; ++i) load_a(0, 0, i);
+        load_b(0, 0, fb[0]);
+    }
+
+    for (int t = t_begin; t < t_end; ++t) {
+        const bool more_tiles = t + 1 < t_end;
+        const int tn = more_tiles ? t + 1 : t;
+        const int nty0 = (tn / tiles_x) * TH, ntx0 = (tn % tiles_x) * TW;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        for (int slab = 0; slab < nslab; ++slab) {
+            // the (tile, slab) unit that follows this one: the next slab, or slab 0 of the workgroup's next tile -- its
+            // halo is loaded into registers during this unit's taps, its first weight tiles ride the ring
+            const bool last_slab = slab + 1 == nslab;
+            const bool has_next = !last_slab || more_tiles;
+            const int nslab_i = last_slab ? 0 : slab + 1;
             if constexpr (F8) {
-                // operands are 8 VGPRs each: the A fragments of the wave's 4 m-tiles stay live (32 VGPRs), the B
-                // fragments are read one n-tile at a time (a compiler fence keeps hipcc from hoisting all of them
-                // above the MFMAs, which spilled ~600 registers); 4 MFMAs x 32 cycles cover the next read
-                i32x8 af[MT];
+                const unsigned char *sH = smem;
 #pragma unroll
-                for (int i = 0; i < MT; ++i) {
-                    const u32x4 lo = *(const u32x4 *)(sH + aoff[i + kh][kw]), hi = *(const u32x4 *)(sH + (aoff[i + kh][kw] ^ 16));
-                    af[i] = (i32x8){(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
-                }
+                for (int tap = 0; tap < 9; ++tap) {
+                    // request tile q+2 into the buffer tile q-1 was read from (all waves are past that barrier)
+                    const bool dma = tap + 2 < 9 || has_next;
+                    if (tap == 0 && has_next) {                   // in flight during this slab's 9 taps
+                        if (last_slab) halo_gload(0, nty0, ntx0); else halo_gload(slab + 1, ty0, tx0);
+                    }
+                    if (dma) w_dma(tap + 2 < 9 ? slab : nslab_i, (tap + 2) % 9, (tap + 2) % NWB);
+                    const unsigned char *sB = smem + HALO_B + (tap % NWB) * WT_B;
+                    const int kh = tap / 3, kw = tap - kh * 3;
+                    // operands are 8 VGPRs each: the pixel fragments of the wave's 4 m-tiles stay live (32 VGPRs), the
+                    // weight fragments are read one n-tile at a time (a compiler fence keeps hipcc from hoisting all of
+                    // them above the MFMAs, which spilled ~600 registers); 4 MFMAs x 32 cycles cover the next read
+                    i32x8 af[MT];
 #pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    const u32x4 lo = *(const u32x4 *)(sB + boff[j]), hi = *(const u32x4 *)(sB + (boff[j] ^ 16));
-                    const i32x8 bj = (i32x8){(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+                    for (int i = 0; i < MT; ++i) {
+                        const u32x4 lo = *(const u32x4 *)(sH + aoff[i + kh][kw]), hi = *(const u32x4 *)(sH + (aoff[i + kh][kw] ^ 16));
+                        af[i] = (i32x8){(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+                    }
 #pragma unroll
-                    for (int i = 0; i < MT; ++i)
-                        // inline asm with the accumulator TIED (dst = src C): through the builtin hipcc 7.2 leaves the
-                        // two untied and the register allocator spills ~600 VGPRs.  Hazards by hand: A / B come from
-                        // ds_read (the compiler's s_waitcnt covers asm operands), the same accumulator recurs only
-                        // 4 MFMAs (>= 128 cycles) later, s_nop 1 covers the v_mov of the scale register, and the
-                        // epilogue's first read of the accumulators sits behind the s_nop block after the loop.
-                        asm("s_nop 1\n\tv_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]"
-                            : "+v"(acc[i][j]) : "v"(af[i]), "v"(bj), "v"(0x7f7f7f7f));
+                    for (int j = 0; j < NT; ++j) {
+                        const u32x4 lo = *(const u32x4 *)(sB + boff[j]), hi = *(const u32x4 *)(sB + (boff[j] ^ 16));
+                        const i32x8 bj = (i32x8){(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+#pragma unroll
+                        for (int i = 0; i < MT; ++i)
+                            // inline asm with the accumulator TIED (dst = src C): through the builtin hipcc 7.2 leaves the
+                            // two untied and the register allocator spills ~600 VGPRs.  Hazards by hand: A / B come from
+                            // ds_read (the compiler's s_waitcnt covers asm operands), the same accumulator recurs only
+                            // 4 MFMAs (>= 128 cycles) later, s_nop 1 covers the v_mov of the scale register, and the
+                            // epilogue's first read of the accumulators sits behind the s_nop block after the loop.
+                            asm("s_nop 1\n\tv_mfma_scale_f32_16x16x128_f8f6f4 %0, %2, %1, %0, %3, %3 op_sel_hi:[0,0,0]"
+                                : "+v"(acc[i][j]) : "v"(af[i]), "v"(bj), "v"(0x7f7f7f7f));
+                    }
+                    // tile q+1 (requested one tap ago) must have landed before the barrier publishes it.  vmcnt retires
+                    // in order: allow exactly the operations issued AFTER that request -- this tap's DMA (NB
+                    // instructions) and, during the first tap of a slab, the halo loads of the next unit.
+                    const bool halo_young = tap < 1 && has_next;
+                    if (dma) { if (halo_young) FD_WAIT_VM(NB + HL * HG); else FD_WAIT_VM(NB); }
+                    else FD_WAIT_VM(0);
+                    __syncthreads();
+                    if (tap == 8 && !last_slab) {           // every wave is done with this slab's halo
+                        halo_lstore();
+                        __syncthreads();
+                    }
                 }
             } else {
+                // bf16: a tap is two K32 half-steps; the fragments of half-step h + 1 are requested from LDS before /
+                // between the 16 MFMAs of half-step h, so an LDS round trip is behind matrix work instead of in front of
+                // it.  The per-tap barrier sits BETWEEN a tap's two half-steps: by then every wave has read both halves
+                // of weight tile t (the (t, 1) reads were issued before the (t, 0) MFMAs), so B_t both publishes tile
+                // t + 1 -- whose first fragments are requested right behind it -- and frees slot t % 3 for the request of
+                // tile t + 3: three slots give a two-tap lead.
+                //   per tap t:  B reads(t, 1) | MFMA(t, 0) + A reads(t, 1) | wait tile t+1, B_t | DMA tile t+3 |
+                //               B reads(t+1, 0) | MFMA(t, 1) + A reads(t+1, 0)
+                // vmcnt order of a unit: ... DMA(2) | B_0 | DMA(3), next unit's halo loads | B_1 | DMA(4) | B_2 | DMA(5) ...
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 af[MT], bfr[NT];
-#pragma unroll
-                for (int i = 0; i < MT; ++i)                         // m tile i = tile row 4*wm + i
-                    af[i] = *(const bf16x8 *)(sH + (aoff[i + kh][kw] ^ (ks << 6)));
-#pragma unroll
-                for (int j = 0; j < NT; ++j) bfr[j] = *(const bf16x8 *)(sB + (boff[j] ^ (ks << 6)));
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                for (int tap = 0; tap < 9; ++tap) {
+                    const bool next_tile = tap + 1 < 9 || has_next;
+                    load_b(tap, 1, fb[1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    half_step(fb[0], true, tap, 1);
+                    if (next_tile) {
+                        // tile t+1 landed: younger than its request are DMA(t+2) and, at B_1 / B_2, the next unit's halo
+                        // loads; and this wave's reads of tile t have returned: all but the MT youngest LDS reads (the
+                        // pixel fragments of (t, 1), from the halo).  A bare s_barrier: __syncthreads() would drain those
+                        // as well, an LDS round trip in front of every barrier.
+                        const bool t2 = tap + 2 < 9 || has_next;
+                        const bool halo_young = has_next && (tap == 1 || tap == 2);
+                        asm volatile("" ::: "memory");
+                        // (B_8 drains them too: behind it the halo buffer is overwritten -- next slab / C staging)
+                        if (tap == 8) { if (t2) FD_WAIT_VM_LGKM(NB, 0); else FD_WAIT_VM_LGKM(0, 0); }
+                        else if (t2) { if (halo_young) FD_WAIT_VM_LGKM(NB + HL * HG, MT); else FD_WAIT_VM_LGKM(NB, MT); }
+                        else FD_WAIT_VM_LGKM(0, MT);
+                        __builtin_amdgcn_s_barrier();
+                        asm volatile("" ::: "memory");
+                        if (tap + 3 < 9 || has_next) w_dma(tap + 3 < 9 ? slab : nslab_i, (tap + 3) % 9, tap % NWB);
+                        if (tap == 0 && has_next) {               // in flight during this unit's taps
+                            if (last_slab) halo_gload(0, nty0, ntx0); else halo_gload(slab + 1, ty0, tx0);
+                        }
+                    }
+                    if (tap < 8) {
+                        load_b(tap + 1, 0, fb[0]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        half_step(fb[1], true, tap + 1, 0);
+                    } else if (!last_slab) {                      // every wave is done with this slab's halo
+                        halo_lstore();
+                        __syncthreads();
+                        load_b(0, 0, fb[0]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        half_step(fb[1], true, 0, 0);
+                    } else half_step(fb[1], false, 0, 0);         // the tile's last MFMAs; the epilogue follows
+                }
             }
+        }
+        // F8: the last inline-asm MFMAs must have written their accumulators before the epilogue reads them (the
+        // compiler's hazard recognizer does not see into asm); volatile + memory clobber keeps the LDS stores below it
+        if constexpr (F8) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+
+        // ---- epilogue.  acc[i][2 q + h][e] of lane (fr, fg) = pixel (tile row 4 wm + i, column fr), output channel
+        // cb + 32 q + 4 h + e with cb = the wave's channel base + 8 fg (tile_row_channel above).  Every wave is past its
+        // last halo read (B_8), so the halo buffer stages the bf16 C tile 64 channels at a time -- 16-byte LDS
+        // stores, then every store instruction of a wave writes 8 whole 128-byte rows -- while the next tile's halo
+        // waits in rh and its first weight tiles land in the ring (storing 64-byte pieces straight from the
+        // accumulators measured 8 % slower than this round trip).
+        // (lane geometry from an opaque copy of tid: as tile-loop invariants the bias values, staging addresses and
+        // output offsets of the epilogue would stay live -- spilled -- across the tap loop)
+        constexpr int NQ = NT / 2;
+        if (!more_tiles) __syncthreads();        // no B_8 behind the workgroup's last unit: halo reads of other waves
+        int te = tid;
+        asm volatile("" : "+v"(te));
+        const int fr = te & 15, fg = (te >> 4) & 3, wv = te >> 6;
+        const int wm = wv / WNW, wn = wv % WNW;
+        const int cb = (BN / WNW) * wn + 8 * fg;
+        __attribute__((aligned(8))) float ssum[4 * NT], ssq[4 * NT];
+#pragma unroll
+        for (int k = 0; k < 4 * NT; ++k) ssum[k] = ssq[k] = 0.f;
+        const bool relu = p.epilogue == FD_EPI_RELU;
+        bf16 *outp = (bf16 *)p.out + (int64_t)b * p.OH * p.OW * p.ldo + p.offo;
+        const int v8 = te & 7, r0 = te >> 3;
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            // (two copies, ReLU or not: as a per-value select it was 128 of the epilogue's ~450 VALU instructions)
+            auto stage = [&](auto relu_c) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    float bias[8], wsc[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        bias[e] = s_bias[cb + 32 * q + e];
+                        wsc[e] = F8 ? s_wsc[cb + 32 * q + e] : 1.f;
+                    }
+                    // 16-byte chunk of the staged 128-byte row: the wave's channels of this pass, octet by octet
+                    const int ch = (NPASS == 1 ? (BN / WNW) * wn / 8 : 0) + fg + 4 * q;
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+                        float val[8];
+#pragma unroll
+                        for (int e = 0; e < 8; e += 2) {         // channel pairs: v_pk_add / v_pk_fma
+                            const f32x4 a4 = acc[i][2 * q + (e >> 2)];
+                            const f32x2 a = (e & 2) ? f32x2{a4[2], a4[3]} : f32x2{a4[0], a4[1]};
+                            const f32x2 bi = {bias[e], bias[e + 1]};
+                            f32x2 v2 = F8 ? a * f32x2{wsc[e], wsc[e + 1]} + bi : a + bi;
+                            if (decltype(relu_c)::value == 1 || (decltype(relu_c)::value == 2 && relu))
+                                v2 = f32x2{fmaxf(v2.x, 0.f), fmaxf(v2.y, 0.f)};
+                            f32x2 &su = *(f32x2 *)&ssum[8 * q + e], &sq2 = *(f32x2 *)&ssq[8 * q + e];
+                            su += v2;
+                            sq2 = v2 * v2 + sq2;
+                            val[e] = v2.x;
+                            val[e + 1] = v2.y;
+                        }
+                        const int r = 16 * (4 * wm + i) + fr;
+                        store8((bf16 *)(smem + r * 128 + ((ch ^ (r & 7)) << 4)), val);
+                    }
+                }
+            };
+            if (NPASS == 1 || wn == ps) {
+                if constexpr (F8) stage(std::integral_constant<int, 2>{});      // one copy (register budget), per-value select
+                else if (relu) stage(std::integral_constant<int, 1>{});
+                else stage(std::integral_constant<int, 0>{});
             }
-            // tile q+1 (requested one tap ago) must have landed before the barrier publishes it.  vmcnt retires
-            // in order: allow exactly the operations issued AFTER that request -- this tap's DMA (NB
-            // instructions) and, during the first two taps of a slab, the HL halo loads of the next slab.
-            const bool halo_young = tap < 1 && has_next;
-            if (dma) { if (halo_young) FD_WAIT_VM(NB + HL * HG); else FD_WAIT_VM(NB); }
-            else FD_WAIT_VM(0);
+            if (ps == NPASS - 1 && p.stats_partial) {
+                // per-channel sums over the wave's 64 pixels: slot k = 8 q + e of lane (fr, fg) is channel cb + 32 q + e;
+                // lane fr = 0 of each row writes its group's 4 NT channels
+#pragma unroll
+                for (int k = 0; k < 4 * NT; ++k) {
+                    ssum[k] = row16_sum(ssum[k]);
+                    ssq[k] = row16_sum(ssq[k]);
+                }
+                if (fr == 0) {
+#pragma unroll
+                    for (int k = 0; k < 4 * NT; ++k)
+                        *(f32x2 *)&s_stat[wm][cb + 32 * (k >> 3) + (k & 7)][0] = f32x2{ssum[k], ssq[k]};
+                }
+            }
             __syncthreads();
-            if (last_tap && has_next) {             // every wave is done with this slab's halo
-                halo_lstore();
-                __syncthreads();
+            u32x4 cv[RB];
+#pragma unroll
+            for (int k = 0; k < RB; ++k) {
+                const int r = r0 + 32 * k;
+                cv[k] = *(const u32x4 *)(smem + r * 128 + ((v8 ^ (r & 7)) << 4));
+            }
+            if (ps == NPASS - 1 && p.stats_partial && te < BN) {
+                const int n = nt * BN + te;
+                if (n < p.Cout) {
+                    float sm = 0.f, sq = 0.f;
+#pragma unroll
+                    for (int w = 0; w < WMW; ++w) { sm += s_stat[w][te][0]; sq += s_stat[w][te][1]; }
+                    // the workspace holds one entry per 64 output pixels (fd_conv_mtiles): this BM-pixel
+                    // tile fills its first entry and zeroes the other BM/64 - 1
+                    constexpr int EPT = BM / 64;
+                    float *sp = p.stats_partial + (((int64_t)b * EPT * tiles_xy + EPT * t) * p.Cout + n) * 2;
+                    sp[0] = sm;
+                    sp[1] = sq;
+#pragma unroll
+                    for (int e = 1; e < EPT; ++e) {
+                        sp[2 * e * p.Cout] = 0.f;
+                        sp[2 * e * p.Cout + 1] = 0.f;
+                    }
+                }
+            }
+            __syncthreads();                             // the staging area is free again
+            if (ps == NPASS - 1 && more_tiles) halo_lstore();      // the next tile's halo, before the stores below
+            const int n0 = nt * BN + 64 * ps + 8 * v8;
+            if (n0 < p.Cout) {
+                // row r0 + 32 k is pixel (ty0 + r0 / 16 + 2 k, tx0 + r0 % 16): one 32-bit byte offset + a uniform step
+                // from the image's (wave-uniform) base
+                const unsigned step = 4u * (unsigned)p.OW * (unsigned)p.ldo;
+                unsigned ob = 2u * ((unsigned)((ty0 + (r0 >> 4)) * p.OW + tx0 + (r0 & 15)) * (unsigned)p.ldo + (unsigned)n0);
+#pragma unroll
+                for (int k = 0; k < RB; ++k, ob += step) *(u32x4 *)((char *)outp + ob) = cv[k];
+            }
+        }
+        if (more_tiles) {
+            __syncthreads();                             // the next tile's halo is published
+            ty0 = nty0;
+            tx0 = ntx0;
+            if constexpr (!F8) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) load_a(0, 0, i);
+                load_b(0, 0, fb[0]);
             }
         }
     }
 #undef FD_WAIT_VM
-    // F8: the last inline-asm MFMAs must have written their accumulators before the epilogue reads them (the
-    // compiler's hazard recognizer does not see into asm); volatile + memory clobber keeps the LDS stores below it
-    if constexpr (F8) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-
-    // ---- stage accumulators, row r = tile pixel (ty = r >> 4, tx = r & 15)
-    float *sC = (float *)smem;
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int r = 64 * wm + 16 * i + fg * 4 + e;
-                const int cc = (BN / WNW) * wn + 16 * j + fr;
-                sC[r * BN + cc] = acc[i][j][e];
-            }
-    __syncthreads();
-    constexpr int VPR = BN / 8, RPP = 256 / VPR;
-    const int v = tid % VPR, r0 = tid / VPR;
-    const int n0 = nt * BN + v * 8;
-    float bias[8], ssum[8], ssq[8], wsc[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        bias[e] = (p.bias && n0 + e < p.Cout) ? p.bias[n0 + e] : 0.f;
-        wsc[e] = (F8 && n0 + e < p.Cout) ? p.w_scale[n0 + e] / p.act_scale : 1.f;
-        ssum[e] = ssq[e] = 0.f;
-    }
-    bf16 *outp = (bf16 *)p.out + (int64_t)b * p.OH * p.OW * p.ldo + p.offo;
-    if (n0 < p.Cout) {
-        for (int r = r0; r < BM; r += RPP) {
-            const int y = ty0 + (r >> 4), x = tx0 + (r & 15);
-            float val[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) val[e] = F8 ? sC[r * BN + v * 8 + e] * wsc[e] + bias[e] : sC[r * BN + v * 8 + e] + bias[e];
-            if (p.epilogue == FD_EPI_RELU) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) val[e] = fmaxf(val[e], 0.f);
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { ssum[e] += val[e]; ssq[e] += val[e] * val[e]; }
-            store8(outp + ((int64_t)y * p.OW + x) * p.ldo + n0, val);
-        }
-    }
-    if (p.stats_partial) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-#pragma unroll
-            for (int o = VPR; o < 64; o <<= 1) {
-                ssum[e] += __shfl_xor(ssum[e], o, 64);
-                ssq[e] += __shfl_xor(ssq[e], o, 64);
-            }
-        }
-        if (lane < VPR) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                s_stat[wave][lane * 8 + e][0] = ssum[e];
-                s_stat[wave][lane * 8 + e][1] = ssq[e];
-            }
-        }
-        __syncthreads();
-        if (tid < BN) {
-            const int n = nt * BN + tid;
-            if (n < p.Cout) {
-                float s = 0.f, q = 0.f;
-#pragma unroll
-                for (int w = 0; w < 4; ++w) { s += s_stat[w][tid][0]; q += s_stat[w][tid][1]; }
-                // the workspace holds one entry per 64 output pixels (fd_conv_mtiles): this BM-pixel
-                // tile fills its first entry and zeroes the other BM/64 - 1
-                constexpr int EPT = BM / 64;
-                float *sp = p.stats_partial + (((int64_t)b * EPT * gridDim.x + EPT * blockIdx.x) * p.Cout + n) * 2;
-                sp[0] = s;
-                sp[1] = q;
-#pragma unroll
-                for (int e = 1; e < EPT; ++e) {
-                    sp[2 * e * p.Cout] = 0.f;
-                    sp[2 * e * p.Cout + 1] = 0.f;
-                }
-            }
-        }
-    }
+#undef FD_WAIT_VM_LGKM
 }
 
 }  // namespace
@@ -368,6 +586,7 @@ int fd_conv3x3_ok(const fd_conv_params &p) {
     if ((int64_t)p.OH * p.OW < 4096) return 0;
     if ((int64_t)p.H * p.W * (p.ld0 > p.ld1 ? p.ld0 : p.ld1) >= (1ll << 30)) return 0;   // 32-bit byte offsets
     if ((int64_t)p.Cout * 9 * Cin >= (1ll << 30)) return 0;
+    if ((int64_t)p.OH * p.OW * p.ldo >= (1ll << 30)) return 0;
     return 1;
 }
 
@@ -382,15 +601,24 @@ int fd_conv3x3_fp8_ok(const fd_conv_params &p) {
 int fd_conv3x3_launch(const fd_conv_params &p, hipStream_t s) {
     const bool wide = p.Cout > 64;
     const int th = (!wide && p.OH % 16 == 0) ? 16 : 8;
-    dim3 grid((p.OH / th) * (p.OW / TW), cdiv(p.Cout, wide ? 128 : 64), p.B), block(256);
+    const int tiles_xy = (p.OH / th) * (p.OW / TW), gy = cdiv(p.Cout, wide ? 128 : 64);
+    // consecutive tiles per workgroup: the next tile's halo is in flight during the current tile's MFMAs (a workgroup
+    // per tile has nothing in flight while it computes: the 64 -> 64 convolutions of level 0 ran at 2.1 TB/s of a
+    // latency-bound load -> compute -> store sequence).  Chosen from the launch size only: any split gives the same
+    // bits (a tile's result does not depend on which workgroup computes it).
+    static const int tpw_env = [] { const char *e = getenv("FD_CONV_TPW"); return e ? atoi(e) : 0; }();
+    int tpw = tpw_env > 0 ? tpw_env : (int)((int64_t)tiles_xy * gy * p.B / 2048);
+    tpw = tpw < 1 ? 1 : (tpw > 8 ? 8 : tpw);
+    dim3 grid(cdiv(tiles_xy, tpw), gy, p.B), block(256);
+    static const size_t pad = fd_occ_pad("CONV3");
     if (fd_conv3x3_fp8_ok(p)) {
-        if (wide) hipLaunchKernelGGL((conv3x3_halo_kernel<128, 8, true>), grid, block, 0, s, p);
-        else if (th == 16) hipLaunchKernelGGL((conv3x3_halo_kernel<64, 16, true>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((conv3x3_halo_kernel<64, 8, true>), grid, block, 0, s, p);
+        if (wide) hipLaunchKernelGGL((conv3x3_halo_kernel<128, 8, true>), grid, block, 0, s, p, tpw, tiles_xy);
+        else if (th == 16) hipLaunchKernelGGL((conv3x3_halo_kernel<64, 16, true>), grid, block, 0, s, p, tpw, tiles_xy);
+        else hipLaunchKernelGGL((conv3x3_halo_kernel<64, 8, true>), grid, block, 0, s, p, tpw, tiles_xy);
         return 0;
     }
-    if (wide) hipLaunchKernelGGL((conv3x3_halo_kernel<128, 8, false>), grid, block, 0, s, p);
-    else if (th == 16) hipLaunchKernelGGL((conv3x3_halo_kernel<64, 16, false>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((conv3x3_halo_kernel<64, 8, false>), grid, block, 0, s, p);
+    if (wide) hipLaunchKernelGGL((conv3x3_halo_kernel<128, 8, false>), grid, block, pad, s, p, tpw, tiles_xy);
+    else if (th == 16) hipLaunchKernelGGL((conv3x3_halo_kernel<64, 16, false>), grid, block, pad, s, p, tpw, tiles_xy);
+    else hipLaunchKernelGGL((conv3x3_halo_kernel<64, 8, false>), grid, block, pad, s, p, tpw, tiles_xy);
     return 0;
 }

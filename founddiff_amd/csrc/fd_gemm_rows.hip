@@ -221,10 +221,7 @@ __global__ __launch_bounds__(NT) void gemm_rows_kernel(const fd_conv_params p, i
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { val[e] = acc[0][s][e] + bias[e]; val[4 + e] = acc[1][s][e] + bias[4 + e]; }
                 if (EPI == FD_EPI_SILU_SPLIT) {
-                    if (n0 >= p.epi_split) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) val[e] = fd_silu(val[e]);
-                    }
+                    if (n0 >= p.epi_split) fd_silu8(val);
                 } else if (EPI == FD_EPI_RELU) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) val[e] = fmaxf(val[e], 0.f);
@@ -241,8 +238,7 @@ __global__ __launch_bounds__(NT) void gemm_rows_kernel(const fd_conv_params p, i
                 } else if (EPI == FD_EPI_GNSILU_ADD || EPI == FD_EPI_GNSILU_ADD_FINAL) {
                     float hv[8];
                     load8(hp + m * N + n0, hv);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) val[e] += fd_silu((hv[e] - ev2[e]) * ev3[e] * ev0[e] + ev1[e]);
+                    fd_gn_silu_add8(val, hv, ev2[0], ev3[0], ev0, ev1);
                 }
                 if (EPI == FD_EPI_GNSILU_ADD_FINAL) {
                     // the block output is rounded to the storage type before final_conv reads it in the unfused
@@ -344,7 +340,8 @@ int fd_gemm_rows_launch(const fd_conv_params &p, hipStream_t s) {
     if (per_cu < 1) per_cu = 1;
     int nt = per_cu >= 3 ? 256 : ((per_cu == 2 || !fits_768(KS, p.prologue)) ? 512 : 768);
     if (nt == 512 && !fits_512(KS, p.prologue)) nt = 256;
-    int gx = (256 * per_cu + p.B - 1) / p.B;
+    static const int cap = [] { const char *e = getenv("FD_ROWS_PER_CU"); return e ? atoi(e) : 0; }();   // development: see fd_occ_pad
+    int gx = (256 * ((cap > 0 && per_cu > cap) ? cap : per_cu) + p.B - 1) / p.B;
     const int need = (wtiles + nt / 64 - 1) / (nt / 64);
     if (gx > need) gx = need;
     dim3 grid(gx, p.B);

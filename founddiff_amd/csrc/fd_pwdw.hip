@@ -159,36 +159,16 @@ __global__ __launch_bounds__(256, CIN == 64 ? 3 : 2) void pwdw_kernel(const PwDw
         // cost 3 v_mad_u64_u32 + 4 v_mul_lo_u32 (quarter rate) per load
         raw[k] = *(const u32x4 *)(xin + (__umul24(__umul24(yc, p.W) + xc, p.ld_x) + v * 8));
     }
-    float g8[8], b8[8];
-    load8(&sV[0][v * 8], g8);
-    load8(&sV[1][v * 8], b8);
+    f32x2 g2[4], b2m[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        g2[j] = *(const f32x2 *)&sV[0][v * 8 + 2 * j];
+        b2m[j] = *(const f32x2 *)&sV[1][v * 8 + 2 * j];
+    }
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
         const int hp = (tl + k * 256) >> LCH;
-        float f[8];
-        const bf16x8 xv = __builtin_bit_cast(bf16x8, raw[k]);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = (float)xv[e];
-        float s = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s += f[e];
-        s += __shfl_xor(s, 1, 64);
-        s += __shfl_xor(s, 2, 64);
-        s += __shfl_xor(s, 4, 64);
-        if (CH == 16) s += __shfl_xor(s, 8, 64);
-        const float mean = s * (1.f / CIN);
-        float q = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { const float d = f[e] - mean; q += d * d; }
-        q += __shfl_xor(q, 1, 64);
-        q += __shfl_xor(q, 2, 64);
-        q += __shfl_xor(q, 4, 64);
-        if (CH == 16) q += __shfl_xor(q, 8, 64);
-        const float rstd = rsqrtf(q * (1.f / CIN) + p.ln_eps);
-        bf16x8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (bf16)((f[e] - mean) * rstd * g8[e] + b8[e]);
-        *(bf16x8 *)(xs + xs_off(hp, v)) = o;
+        *(u32x4 *)(xs + xs_off(hp, v)) = fd_ln_mod_chunk<CH>(raw[k], g2, b2m, p.ln_eps);
     }
     // which of this lane's halo pixels (m-tile mt, row fr) lie inside the image: the depthwise conv
     // zero-pads ITS input, i.e. the 1x1 output -- not LN(0)
@@ -226,9 +206,8 @@ __global__ __launch_bounds__(256, CIN == 64 ? 3 : 2) void pwdw_kernel(const PwDw
                     a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ks], xb[i][ks], a0, 0, 0, 0);
                     a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[ks], xb[i][ks], a1, 0, 0, 0);
                 }
-                float val[8];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { val[e] = fd_silu(a0[e]); val[4 + e] = fd_silu(a1[e]); }
+                float val[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                fd_silu8(val);
                 const int y = ty0 + 2 * wave + i, x = tx0 + fr;
                 store8(zout + (__umul24(__umul24(y, p.W) + x, p.ld_z) + 32 * ng + 8 * fg), val);
             }
@@ -314,10 +293,7 @@ __global__ __launch_bounds__(256, CIN == 64 ? 3 : 2) void pwdw_kernel(const PwDw
             dw_row_f16(win, rr, wt, b2, o2);
             float acc[8];
             unpack_h8(o2, acc);
-            if (p.dw_silu) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] = fd_silu(acc[e]);
-            }
+            if (p.dw_silu) fd_silu8(acc);
             const int y = ty0 + 4 * rh + rr, x = tx0 + px;
             store8(dwout + (__umul24(__umul24(y, p.W) + x, p.ld_dw) + c0), acc);
         }
@@ -429,34 +405,16 @@ __global__ __launch_bounds__(256, 3) void pwdw_gram_kernel(const PwGramParams p)
             const int yc = min(max(ty0 + hy - 1, 0), p.H - 1), xc = min(max(tx0 + hx - 1, 0), p.W - 1);
             raw[k] = *(const u32x4 *)(xin + (__umul24(__umul24(yc, p.W) + xc, p.ld_x) + v * 8));
         }
-        float g8[8], b8[8];
-        load8(&sV[0][v * 8], g8);
-        load8(&sV[1][v * 8], b8);
+        f32x2 g2[4], b2m[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            g2[j] = *(const f32x2 *)&sV[0][v * 8 + 2 * j];
+            b2m[j] = *(const f32x2 *)&sV[1][v * 8 + 2 * j];
+        }
 #pragma unroll
         for (int k = 0; k < NLD; ++k) {
             const int hp = (tl + k * 256) >> 3;
-            float f[8];
-            const bf16x8 xv = __builtin_bit_cast(bf16x8, raw[k]);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] = (float)xv[e];
-            float s = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s += f[e];
-            s += __shfl_xor(s, 1, 64);
-            s += __shfl_xor(s, 2, 64);
-            s += __shfl_xor(s, 4, 64);
-            const float mean = s * (1.f / 64);
-            float q = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { const float d = f[e] - mean; q += d * d; }
-            q += __shfl_xor(q, 1, 64);
-            q += __shfl_xor(q, 2, 64);
-            q += __shfl_xor(q, 4, 64);
-            const float rstd = rsqrtf(q * (1.f / 64) + p.ln_eps);
-            bf16x8 o;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (bf16)((f[e] - mean) * rstd * g8[e] + b8[e]);
-            *(bf16x8 *)(xs + xs_off(hp, v)) = o;
+            *(u32x4 *)(xs + xs_off(hp, v)) = fd_ln_mod_chunk<8>(raw[k], g2, b2m, p.ln_eps);
         }
         uint32_t inside = 0;
 #pragma unroll
@@ -804,8 +762,9 @@ extern "C" int fd_pw_dw3x3(int dtype, const void *x, int ld_x, int off_x, int Ci
     static const int tpw_env = [] { const char *e = getenv("FD_PWDW_TPW"); return e ? atoi(e) : 0; }();
     p.tpw = tpw_env > 0 ? tpw_env : 4;
     dim3 grid((p.ntiles + p.tpw - 1) / p.tpw, B), block(256);
-    if (Cin == 64) hipLaunchKernelGGL(pwdw_kernel<64>, grid, block, 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(pwdw_kernel<128>, grid, block, 0, (hipStream_t)stream, p);
+    static const size_t pad = fd_occ_pad("PWDW");
+    if (Cin == 64) hipLaunchKernelGGL(pwdw_kernel<64>, grid, block, pad, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(pwdw_kernel<128>, grid, block, pad, (hipStream_t)stream, p);
     FD_LAUNCH_OK("fd_pw_dw3x3");
     return FD_OK;
 }
@@ -845,7 +804,8 @@ extern "C" int fd_pw_dw3x3_gram(int dtype, const void *x, int ld_x, int off_x, i
     p.part = partial; p.nblk = fd_pw_dw3x3_gram_nblk(H, W);
     p.H = H; p.W = W; p.tpw = gram_tpw(); p.ntiles = (H / PT_H) * (W / PT_W);
     dim3 grid(p.nblk, B), block(256);
-    hipLaunchKernelGGL(pwdw_gram_kernel, grid, block, 0, (hipStream_t)stream, p);
+    static const size_t pad = fd_occ_pad("PWDW");
+    hipLaunchKernelGGL(pwdw_gram_kernel, grid, block, pad, (hipStream_t)stream, p);
     FD_LAUNCH_OK("fd_pw_dw3x3_gram");
     return FD_OK;
 }

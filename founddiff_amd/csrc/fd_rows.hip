@@ -20,26 +20,40 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(
     const bool active = row < nrows;
     const int64_t rr = active ? row : 0;
     const int b = (int)(rr / hw);
-    float v[VPL][8];
-    float s = 0.f;
+    // packed fp32 throughout (v_pk_add / v_pk_fma: two channels per issue slot) and DPP row sums for the first four
+    // butterfly steps: this kernel lives on row parallelism and ran at 97 % VALU busy (PMC, round 3)
+    auto allsum = [&](float t) -> float {
+        if (lpr >= 2) t = fd_dpp_add<0xB1>(t);
+        if (lpr >= 4) t = fd_dpp_add<0x4E>(t);
+        if (lpr >= 8) t = fd_dpp_add<0x141>(t);
+        if (lpr >= 16) t = fd_dpp_add<0x140>(t);
+        if (lpr >= 32) t += __shfl_xor(t, 16, 64);
+        if (lpr >= 64) t += __shfl_xor(t, 32, 64);
+        return t;
+    };
+    f32x2 v[VPL][4];
+    f32x2 s2 = {0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < VPL; ++j) {
-        load8(x + rr * C + (j * lpr + sub) * 8, v[j]);
+        float t8[8];
+        load8(x + rr * C + (j * lpr + sub) * 8, t8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s += v[j][e];
+        for (int e = 0; e < 4; ++e) {
+            v[j][e] = f32x2{t8[2 * e], t8[2 * e + 1]};
+            s2 += v[j][e];
+        }
     }
-    for (int o = 1; o < lpr; o <<= 1) s += __shfl_xor(s, o, 64);
-    const float mean = s / C;
-    float q = 0.f;
+    const float mean = allsum(s2.x + s2.y) / C;
+    f32x2 q2 = {0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < VPL; ++j)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float d = v[j][e] - mean;
-            q += d * d;
+        for (int e = 0; e < 4; ++e) {
+            const f32x2 d = v[j][e] - mean;
+            q2 = d * d + q2;
         }
-    for (int o = 1; o < lpr; o <<= 1) q += __shfl_xor(q, o, 64);
-    const float rstd = rsqrtf(q / C + eps);
+    const float rstd = rsqrtf(allsum(q2.x + q2.y) / C + eps);
+    const float nm = -mean * rstd;
     if (!active) return;
 #pragma unroll
     for (int j = 0; j < VPL; ++j) {
@@ -59,12 +73,14 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(
             }
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float y = (v[j][e] - mean) * rstd;
-            if (gamma) y = y * gg[e] + bb[e];
-            if (GATE) y = y * zz[e] + sh[e];       // shift == local
-            else y = y * (1.f + sc[e]) + sh[e];
-            o8[e] = y;
+        for (int e = 0; e < 4; ++e) {
+            f32x2 y = v[j][e] * rstd + nm;
+            if (gamma) y = y * f32x2{gg[2 * e], gg[2 * e + 1]} + f32x2{bb[2 * e], bb[2 * e + 1]};
+            const f32x2 sh2 = {sh[2 * e], sh[2 * e + 1]};
+            if (GATE) y = y * f32x2{zz[2 * e], zz[2 * e + 1]} + sh2;       // shift == local
+            else y = y * (f32x2{sc[2 * e], sc[2 * e + 1]} + 1.f) + sh2;
+            o8[2 * e] = y.x;
+            o8[2 * e + 1] = y.y;
         }
         store8(out + rr * C + c0, o8);
     }
@@ -171,10 +187,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const T *__restrict__ in
 #pragma unroll
                 for (int e = 0; e < 8; ++e) acc[e] += v[e] * wt[dy * 3 + dx][e];
             }
-        if (silu) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] = fd_silu(acc[e]);
-        }
+        if (silu) fd_silu8(acc);
         store8(out + ((img * H + y) * W + x) * ld_out + off_out + c0, acc);
     }
 }
@@ -187,7 +200,6 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const T *__restrict__ in
 //    register that holds the tap weight in the wanted half and 0 in the other -- no bf16->f32 unpack.
 //    The tap weights are therefore rounded to bf16 (as every dense conv weight in this mode is);
 //    accumulation stays f32.
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 constexpr int DWB_T = 16;
 __global__ __launch_bounds__(256) void dwconv3x3_bf16_kernel(const bf16 *__restrict__ in, int ld_in, int off_in,
                                                             const float *__restrict__ w,
@@ -289,10 +301,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_bf16_kernel(const bf16 *__restr
                     acc[2 * j + 1] = __builtin_amdgcn_fdot2_f32_bf16(
                         xv, __builtin_bit_cast(bf16x2, whi[dy * 3 + dx][j]), acc[2 * j + 1], false);
                 }
-        if (silu) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] = fd_silu(acc[e]);
-        }
+        if (silu) fd_silu8(acc);
         store8(out_img + (__umul24(__umul24(y, W) + x, ld_out) + c0), acc);
     }
 }

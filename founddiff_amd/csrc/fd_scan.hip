@@ -776,7 +776,8 @@ void launch_scan(const T *xc, const float *xdbl, const float *dtw, const float *
     const int cw = two ? 128 : 64;                     // channels per wave
     const int nw = g.D >= 4 * cw ? 4 : g.D / cw;       // waves per workgroup
     dim3 grid(g.nch * (g.D / (cw * nw)), g.B * 4), block(64 * nw);
-    const size_t lds = (size_t)g.CL * ((g.CD + 3) & ~3) * sizeof(float);
+    static const size_t pad = fd_occ_pad("SCAN");
+    const size_t lds = (size_t)g.CL * ((g.CD + 3) & ~3) * sizeof(float) + pad;
     if (two) hipLaunchKernelGGL((scan_chunk_kernel<T, N, R, false, ODD, CPL>), grid, block, lds, s, xc, xdbl, dtw, dtb, A, Ds, y, wsH, wsP, g);
     else hipLaunchKernelGGL((scan_chunk_kernel<T, N, R, false, ODD>), grid, block, lds, s, xc, xdbl, dtw, dtb, A, Ds, y, wsH, wsP, g);
     if (g.nch > 1)

@@ -89,7 +89,7 @@ def test_mamba_block(golden, mode, tol, tag):
     assert rel_err(nchw(out), g[p + "out"]) < tol
 
 
-@pytest.mark.parametrize("C_,H,W", [(64, 32, 32), (128, 32, 32)])
+@pytest.mark.parametrize("C_,H,W", [(64, 128, 256), (128, 32, 32)])
 def test_tiny_qk_channels_stay_in_fp16_range(C_, H, W):
     """the fused Gram kernels keep q / k as fp16 on chip; a q / k channel whose weights are ~1e-6 would be
     subnormal or zero there and get a garbage direction where the reference's F.normalize (src/DADiff.py:273-274) gives
