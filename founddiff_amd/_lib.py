@@ -74,6 +74,9 @@ SIGNATURES = {
     "fd_selective_scan_fuses_xproj": (i32, [i32, i32, i32, i32]),
     "fd_selective_scan_plan": (i32, [i32, i32, i32, i32, i32, i32]),
     "fd_selective_scan_xproj": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "fd_selective_scan_fused_ok": (i32, [i32, i32, i32, i32, i32, i32]),
+    "fd_scan_fused_ws_floats": (i64, [i32, i32, i32, i32, i32, i32]),
+    "fd_selective_scan_fused": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "fd_selective_scan_fwd_f32": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i64, vp, vp, vp]),
     "fd_chan_attn_nblk": (i32, [i64]),
     "fd_chan_attn_gram": (i32, [i32, vp, i32, i64, i32, vp, vp]),

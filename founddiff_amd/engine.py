@@ -101,6 +101,7 @@ class DAEngine:
         # chosen for throughput at a batch that fills the chip; both are functions of the image size only.
         self.low_latency = bool(low_latency)
         self.scan_dt = self.dt | (L.FD_OPT_LOW_LATENCY if low_latency else 0)
+        self.scan_fused = os.environ.get("FOUNDDIFF_SCAN_FUSED", "0") == "1"      # single-launch scan (opt-in, see mamba_block)
         self.dev = torch.device(device)
         self.f32 = dict(device=self.dev, dtype=torch.float32)
         sd = _Sub(state_dict, prefix)
@@ -443,7 +444,15 @@ class DAEngine:
         nws = L.lib().fd_scan_ws_floats(B, H, W, D, N)
         ws = self._b("scan_ws", (nws,), torch.float32)
         y = self._b("scan_y", (B, H, W, D))
-        if L.lib().fd_selective_scan_plan(getattr(self, 'scan_dt', self.dt), D, N, R, H, W):
+        if getattr(self, 'scan_fused', False) and L.lib().fd_selective_scan_fused_ok(getattr(self, 'scan_dt', self.dt), D, N, R, H, W):
+            # ONE launch: u tile in LDS, x_proj on MFMA, decays cached between the passes, in-launch carry tree
+            # (fd_scan_fused.hip): x_dbl and the chunk states never reach HBM.  OPT-IN (FOUNDDIFF_SCAN_FUSED=1): correct
+            # and deterministic, but measured 2x slower than the 3-phase form at level 0
+            fws = self._b("scan_fws", (L.lib().fd_scan_fused_ws_floats(B, H, W, D, N, R),), torch.float32)
+            L.call("fd_selective_scan_fused", self.dt, _p(xc), _p(m["x_proj"]), _p(m["dtw"]), _p(m["dtb"]), _p(m["A"]),
+                   _p(m["Ds"]), _p(y), _p(fws), B, H, W, D, N, R, s)
+            self._pr(tag + ".xdbl", y)
+        elif L.lib().fd_selective_scan_plan(getattr(self, 'scan_dt', self.dt), D, N, R, H, W):
             # x_proj inside the scan's first phase (one workgroup per chunk at d_inner <= 256): no separate pass over xc
             L.call("fd_selective_scan_xproj", self.dt, _p(xc), _p(m["x_proj"]), _p(xdbl), _p(m["dtw"]), _p(m["dtb"]),
                    _p(m["A"]), _p(m["Ds"]), _p(y), _p(ws), B, H, W, D, N, R, s)
