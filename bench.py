@@ -336,7 +336,7 @@ def _smi_read():
     """(sclk MHz, mclk MHz, socket power W) from one rocm-smi call, None where not available"""
     import re
     import subprocess
-    r = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=30)
+    r = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showmaxpower", "--json"], capture_output=True, text=True, timeout=30)
     d = json.loads(r.stdout)
     card = d.get("card0") or next(iter(d.values()))
     out = {}
@@ -349,6 +349,8 @@ def _smi_read():
             out["sclk_mhz"] = float(m.group(1))
         elif kl.startswith("mclk") and "level" not in kl:
             out["mclk_mhz"] = float(m.group(1))
+        elif "max" in kl and "power" in kl:
+            out["power_cap_w"] = float(m.group(1))
         elif "power" in kl and "(w)" in kl:
             out["socket_power_w"] = float(m.group(1))
     return out
@@ -385,8 +387,9 @@ class SmiSampler:
         pw = [q["socket_power_w"] for q in self.samples if "socket_power_w" in q]
         if not sc:
             return None
+        cap = [q["power_cap_w"] for q in self.samples if "power_cap_w" in q]
         return {"samples": len(sc), "sclk_mhz_mean": round(sum(sc) / len(sc), 1), "sclk_mhz_min": min(sc),
-                "socket_power_w_mean": round(sum(pw) / len(pw), 1) if pw else None}
+                "socket_power_w_mean": round(sum(pw) / len(pw), 1) if pw else None, "power_cap_w": cap[0] if cap else None}
 
 
 def clocks_under_load(lib, launches, seconds=1.5):

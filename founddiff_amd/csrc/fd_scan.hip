@@ -48,7 +48,7 @@ __device__ __forceinline__ void scan_pos(const ScanGeom &g, int k, int l, int &l
 // instructions too, the cross-half add of the y pair disappears, u / y move as one dword per lane and step, and a
 // wave's LDS row broadcasts serve 128 channels: ~26.5 instead of ~31 issue slots per (channel, position).
 template <typename T, int N, int R, bool FINAL, bool ODD, int CPL = 1>
-__global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 8 ? (CPL == 2 ? 4 : 5) : (CPL == 2 && !FINAL ? 4 : 1)))) void scan_chunk_kernel(const T *__restrict__ xc, const float *__restrict__ xdbl,
+__global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 8 ? (CPL == 2 ? 4 : 5) : 1))) void scan_chunk_kernel(const T *__restrict__ xc, const float *__restrict__ xdbl,
                                                         const float *__restrict__ dtw, const float *__restrict__ dtb,
                                                         const float *__restrict__ A, const float *__restrict__ Ds,
                                                         T *__restrict__ y, float *__restrict__ wsH,
@@ -82,15 +82,14 @@ __global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 8 ? (CPL == 2 ? 4 : 5) : 
     // workspace phase C stages from.  The separate x_proj launch read the whole xc tensor once more from HBM
     // (0.17 ms per batch-8 launch at 512x512); here that read is the first touch of the chunk's pixels and the
     // recurrence's own u loads below hit L2.  Transposed issue: rows = outputs e, columns = 16 positions.
-    // INTER (round 4; two channels per lane, i.e. d_inner = 128 and ONE wave per workgroup): the x_proj of a 16-position
-    // block is computed right in front of the recurrence steps that consume its rows (the main loop below) instead of
-    // for the whole chunk up front.  The fragment loads are then the first touch of those pixels and the recurrence's own
-    // u loads of the same 16 pixel rows follow within a few microseconds: they hit L1 / L2.  With the chunk-wide prologue
-    // they came 128 steps later and missed -- phase A fetched u TWICE from beyond L2 (traffic.json, round 3: 1.075 GB per
-    // launch at level 0 against 0.537 GB of u).
-    constexpr bool INTER = CPL == 2 && !FINAL;
+    // (Round 4, measured: they do NOT hit -- FETCH_SIZE of this phase is 2x u.  tools/probes/fetch_calib.hip: a streaming
+    // kernel turns an XCD's 4 MB L2 over in ~3 us (a re-touch 3 us after the first touch goes back to memory 74 % of
+    // the time, an immediate one never), and the recurrence re-touches a chunk's pixels up to 128 steps later.  Two
+    // interleaved forms were built -- x_proj block by block in front of its 16 recurrence steps, fragment and u loads
+    // one group apart (fetch +14 %, time equal) or issued together (the extra live registers spill at 4 waves per
+    // SIMD: 2x slower) -- and dropped; the kernel is VALU-bound and the second read costs bytes, not time.)
     if constexpr (!FINAL && sizeof(T) == 2) {
-        if (g.xw && !INTER) {
+        if (g.xw) {
             const bf16 *Wk = (const bf16 *)g.xw + (int64_t)k * CD * g.D;
             const bf16 *ubx = (const bf16 *)xc + (int64_t)b * g.H * g.W * g.D;
             float *xo = g.xdbl_out + ((int64_t)k * g.B + b) * g.L * g.CD;
@@ -162,7 +161,7 @@ __global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 8 ? (CPL == 2 ? 4 : 5) : 
     }
     // ---- stage the chunk's rows
     if (FINAL || sizeof(T) != 2 || !g.xw)
-    for (int idx = threadIdx.x; idx < (l1 - l0) * CD; idx += blockDim.x) {   // (INTER with g.xw: rows come block by block)
+    for (int idx = threadIdx.x; idx < (l1 - l0) * CD; idx += blockDim.x) {
         const int row = idx / CD, e = idx - row * CD;
         const int l = l0 + row;
         int h2, w2;
@@ -367,78 +366,6 @@ __global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 8 ? (CPL == 2 ? 4 : 5) : 
         }
         l += U;
     };
-    bool blocks_done = false;
-    if constexpr (INTER) {
-        if (g.xw) {
-            // x_proj of block nb = positions [l0 + 16 nb, +16): the rows of recurrence group nb (U = 16)
-            static_assert(U == 16, "one x_proj block per recurrence group");
-            const bf16 *Wk = (const bf16 *)g.xw + (int64_t)k * CD * g.D;
-            const bf16 *ubx = (const bf16 *)xc + (int64_t)b * g.H * g.W * g.D;
-            float *xo = g.xdbl_out + ((int64_t)k * g.B + b) * g.L * g.CD;
-            constexpr int MB = (CD + 15) / 16, KS4 = 4;              // d_inner = 128 (launcher)
-            const int fr = lane & 15, fg = lane >> 4;
-            const int nblk = (l1 - l0 + 15) >> 4;
-            int xl = 0, xlrow = 0, nl = 0, nlrow = 0;
-            bf16x8 bcur[KS4], bnxt[KS4];
-            auto xfetch = [&](int nb, int &ql, int &qlrow, bf16x8 (&bq)[KS4]) {
-                const int l = l0 + nb * 16 + fr;
-                int h2, w2;
-                if (odd) { w2 = l / g.H2; h2 = l - w2 * g.H2; }
-                else { h2 = l / g.W2; w2 = l - h2 * g.W2; }
-                const int hh = 2 * h2 + ph, ww = 2 * w2 + pw;
-                const bool inimg = l < l1 && hh < g.H && ww < g.W;      // odd sizes: padded positions are zero rows
-                const bf16 *px = ubx + ((int64_t)hh * g.W + ww) * g.D + 8 * fg;
-                ql = l;
-                qlrow = h2 * g.W2 + w2;
-#pragma unroll
-                for (int ks = 0; ks < KS4; ++ks) {
-                    bq[ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-                    if (inimg) bq[ks] = *(const bf16x8 *)(px + 32 * ks);
-                }
-            };
-            auto xblock = [&](int nb) {              // rows of block nb from bcur; block nb + 1's pixels requested first
-                const bool more = nb + 1 < nblk;
-                if (more) xfetch(nb + 1, nl, nlrow, bnxt);
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb) {
-                    const int e = mb * 16 + fr;
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int ks = 0; ks < KS4; ++ks) {
-                        bf16x8 af = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-                        if (e < CD) af = *(const bf16x8 *)(Wk + (int64_t)e * g.D + 32 * ks + 8 * fg);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bcur[ks], acc, 0, 0, 0);
-                    }
-                    const int e0 = mb * 16 + 4 * fg;                    // CD % 4 == 0 (launcher): all four or none
-                    if (xl < l1 && e0 < CD) {
-                        *(f32x4 *)&sx[(nb * 16 + fr) * CDP + e0] = acc;
-                        *(f32x4 *)&xo[(int64_t)xlrow * CD + e0] = acc;
-                    }
-                }
-                if (more) {
-                    xl = nl;
-                    xlrow = nlrow;
-#pragma unroll
-                    for (int ks = 0; ks < KS4; ++ks) bcur[ks] = bnxt[ks];
-                }
-            };
-            xfetch(0, xl, xlrow, bcur);
-            xblock(0);
-            if (ngroups > 0) fetch(pixA, uA);
-            for (int gi = 0; gi < ngroups; gi += 2) {
-                if (gi + 1 < nblk) xblock(gi + 1);
-                if (gi + 1 < ngroups) fetch(pixB, uB);
-                run(pixA, uA);
-                if (gi + 1 < ngroups) {
-                    if (gi + 2 < nblk) xblock(gi + 2);
-                    if (gi + 2 < ngroups) fetch(pixA, uA);
-                    run(pixB, uB);
-                }
-            }
-            blocks_done = true;
-        }
-    }
-    if (!blocks_done) {
     if (ngroups > 0) fetch(pixA, uA);
     for (int gi = 0; gi < ngroups; gi += 2) {
         if (gi + 1 < ngroups) fetch(pixB, uB);
@@ -447,7 +374,6 @@ __global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 8 ? (CPL == 2 ? 4 : 5) : 
             if (gi + 2 < ngroups) fetch(pixA, uA);
             run(pixB, uB);
         }
-    }
     }
     for (; l < l1; ++l) {
         int soff;
