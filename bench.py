@@ -118,7 +118,7 @@ def forward_bounds(eng, H, W, traffic, t_measured_ms):
     return out
 
 
-def roofline_leg(dif, x, noise, t_measured_ms=None):
+def roofline_leg(dif, x, noise, t_measured_ms=None, clock_replay=True):
     """Roofline of the dominant kernel symbol of one UNet forward -- the symbol with the largest total time, which is
     also the top symbol of the rocprofv3 --stats summary of this command (profiles/).  Candidates: pwdw_kernel<64|128> and
     pwdw_gram_kernel (fused LayerNorm+modulate -> 1x1 -> depthwise 3x3 [-> Gram] of the 64- / 128-channel Mamba blocks: HBM
@@ -192,7 +192,8 @@ def roofline_leg(dif, x, noise, t_measured_ms=None):
     if dws:
         dw_bytes = sum(2.0 * a[10] * a[11] * a[12] * a[13] * esz for _, a in dws)
         cands.append(hbm_entry("dwconv3x3_bf16_kernel", dws, dw_bytes, "dwconv3x3_bf16_hbm_bytes_per_launch"))
-    box = clocks_under_load(lib, halo)
+    # (~1.5 s of halo-conv launches next to a rocm-smi call; skipped under rocprofv3, whose --stats would count them)
+    box = clocks_under_load(lib, halo) if clock_replay else None
     cands.sort(key=lambda c: -c["kernel_ms_per_forward"])
     res = cands[0]
     res["box_under_halo_replay"] = box
@@ -437,6 +438,8 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="slices per GPU per step (run as two concurrent half-batches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-clock-replay", action="store_true", help="skip the 1.5 s halo-conv replay behind "
+                    "roofline.box_under_halo_replay (for runs under rocprofv3 --stats: the replayed launches would be counted)")
     ap.add_argument("--no-fp32-leg", action="store_true")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp8"],
                     help="fp8: BASELINE configs[4] -- e4m3 weights on the fp8 MFMA for the 3x3 convs; a separate "
@@ -533,7 +536,8 @@ def main():
             res["config"]["workload"] = (f"BASELINE configs[4] geometry: 512x512 slice, {a.ddim_steps}-step DDIM, full FoundDiff "
                                          f"UNet + DA-CLIP RN50 cond, precision {a.precision}")
         if not a.no_roofline and a.precision == "bf16":
-            res["roofline"] = roofline_leg(dif, x, noise, t_measured_ms=res["ms_per_unet_forward_per_slice"])
+            res["roofline"] = roofline_leg(dif, x, noise, t_measured_ms=res["ms_per_unet_forward_per_slice"],
+                                           clock_replay=not a.no_clock_replay)
         if world == 1 and not a.no_extra_legs and a.precision == "bf16" and a.sampler == "ddim":
             res["fp8_25step"] = fp8_leg(dev, x, noise)
             res["ancestral_config3"] = ancestral_leg(dev, x)

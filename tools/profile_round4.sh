@@ -10,10 +10,10 @@ export TMPDIR=/tmp
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 FOUNDDIFF_STREAMS=1 python3 bench.py --batch 8 --no-cpu-baseline --no-fp32-leg --no-extra-legs --no-roofline > $OUT/bench_one_stream_b8.json 2> $OUT/bench_s1.err
 # 2. rocprofv3 kernel stats of the default bench and of the one-stream batch-8 bench (exclusive durations)
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o bench --output-format csv -- python3 bench.py --no-cpu-baseline --no-fp32-leg --no-extra-legs > $OUT/bench_under_rocprof.json 2> $OUT/bench_prof.err
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o bench --output-format csv -- python3 bench.py --no-cpu-baseline --no-fp32-leg --no-extra-legs --no-clock-replay > $OUT/bench_under_rocprof.json 2> $OUT/bench_prof.err
 find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_default_bench.csv \;
 export FOUNDDIFF_STREAMS=1
-rocprofv3 --kernel-trace --stats -d $OUT/stats_s1 -o bench --output-format csv -- python3 bench.py --batch 8 --no-cpu-baseline --no-fp32-leg --no-extra-legs > $OUT/bench_one_stream_b8_under_rocprof.json 2> $OUT/bench_prof_s1.err
+rocprofv3 --kernel-trace --stats -d $OUT/stats_s1 -o bench --output-format csv -- python3 bench.py --batch 8 --no-cpu-baseline --no-fp32-leg --no-extra-legs --no-clock-replay > $OUT/bench_one_stream_b8_under_rocprof.json 2> $OUT/bench_prof_s1.err
 unset FOUNDDIFF_STREAMS
 find $OUT/stats_s1 -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_one_stream_b8.csv \;
 # 3. HBM traffic: FETCH_SIZE / WRITE_SIZE in separate passes
