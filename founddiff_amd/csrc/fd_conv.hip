@@ -637,9 +637,12 @@ int fd_gemm_rows_launch(const fd_conv_params &p, hipStream_t s);
 int fd_conv3x3_ok(const fd_conv_params &p);
 int fd_conv3x3_fp8_ok(const fd_conv_params &p);
 int fd_conv3x3_launch(const fd_conv_params &p, hipStream_t s);
+int fd_pwgemm_ok(const fd_conv_params &p);
+int fd_pwgemm_launch(const fd_conv_params &p, hipStream_t s);
 
 // Which kernel fd_conv2d dispatches `p` to: 10 streaming row-GEMM, 11 halo-tiled 3x3, else the
-// implicit-GEMM tile variant 0 <128,128>, 1 <128,64>, 2 <64,128>, 3 <64,64>, 4 <128,256>, 5 <256,256>, 6 <128,32> (BM, BN).
+// implicit-GEMM tile variant 0 <128,128>, 1 <128,64>, 2 <64,128>, 3 <64,64>, 4 <128,256>, 5 <256,256>, 6 <128,32> (BM, BN);
+// 7: the persistent 256x256 pointwise GEMM with deferred stores (fd_pwgemm.hip) where 5 would run and it applies.
 extern "C" int fd_conv_fp8_ok(const fd_conv_params *pp) { return pp && !fd_conv_prologue_ok(pp) && fd_conv3x3_fp8_ok(*pp); }
 
 extern "C" int fd_conv_kernel_id(const fd_conv_params *pp) {
@@ -662,7 +665,7 @@ extern "C" int fd_conv_kernel_id(const fd_conv_params *pp) {
     // 128x128: 176 -> 140 us and 120 -> 99 us at batch 8 against the 64x128 tile, `FD_CONV_KID` experiments).
     if (!tall && !pp->stats_partial && pp->Cout >= 256 && pp->KH * pp->KW * (pp->c0 + pp->c1) >= 256 &&
         (int64_t)pp->B * pp->ndir * cdiv((int64_t)pp->OH * pp->OW, 256) * cdiv(pp->Cout, 256) >= 192)
-        return 5;
+        return fd_pwgemm_ok(*pp) ? 7 : 5;
     if (!tall && pp->Cout >= 256 && pp->Cout <= 512 && !pp->stats_partial && pp->KH * pp->KW * (pp->c0 + pp->c1) >= 256) {
         const int64_t wgs = (int64_t)pp->B * pp->ndir * cdiv((int64_t)pp->OH * pp->OW, 128) * cdiv(pp->Cout, 256);
         if (wgs >= 192 || getenv("FD_CONV_BIG_TILE")) return 4;
@@ -708,6 +711,11 @@ extern "C" int fd_conv2d(const fd_conv_params *pp, void *stream) {
     FD_REQUIRE((int64_t)p.H * p.W * (p.ld0 > p.ld1 ? p.ld0 : p.ld1) < (1ll << 31),
                "fd_conv2d: one image of a source must hold < 2^31 elements");
     const int kid = fd_conv_kernel_id(pp);
+    if (kid == 7) {
+        fd_pwgemm_launch(p, (hipStream_t)stream);
+        FD_LAUNCH_OK("fd_conv2d(persistent pointwise GEMM)");
+        return FD_OK;
+    }
     const int BMs[7] = {128, 128, 64, 64, 128, 256, 128}, BNs[7] = {128, 64, 128, 64, 256, 256, 32};
     dim3 grid(cdiv((int64_t)p.OH * p.OW, BMs[kid]), cdiv(p.Cout, BNs[kid]), p.B * p.ndir), block(kid == 4 || kid == 5 ? 512 : 256);
     hipStream_t s = (hipStream_t)stream;

@@ -77,14 +77,19 @@ def test_conv(eng_factory, mode, tol, cfg):
 
 
 @pytest.mark.parametrize("cfg", [
-    dict(c0=512, c1=0, cout=2048, hw=(64, 64), epi="silu_split"),       # in_proj of the 512-channel blocks
-    dict(c0=1024, c1=0, cout=512, hw=(64, 64), epi="gate_res"),         # out_proj: gated residual
-    dict(c0=256, c1=192, cout=328, hw=(60, 52), epi="none"),            # two sources, ragged M and N tiles
+    dict(c0=512, c1=0, cout=2048, hw=(64, 64), epi="silu_split", kid=7),       # in_proj of the 512-channel blocks
+    dict(c0=1024, c1=0, cout=512, hw=(64, 64), epi="gate_res", kid=7),         # out_proj: gated residual
+    dict(c0=256, c1=0, cout=768, hw=(64, 64), epi="none", kid=7),              # qkv of the 256-channel block: 3 column tiles
+    dict(c0=256, c1=0, cout=768, hw=(128, 128), epi="none", kid=7),            # qkv at 128x128: 6 tiles per workgroup, 3 column tiles
+    dict(c0=512, c1=0, cout=256, hw=(128, 128), epi="gate_res", kid=7),        # out_proj at 128x128: one column tile
+    dict(c0=256, c1=192, cout=328, hw=(60, 52), epi="none", kid=5),            # two sources, ragged M and N tiles
 ])
 def test_pointwise_gemm_256_tile(eng_factory, cfg):
-    """1x1 convolutions that run on the 256x256 tile of the generic kernel (fd_conv_kernel_id == 5: the dense layers of
-    the 64x64 / 128x128 levels at batch 8) against the fp32 composition, with the pointwise epilogues they use, two
-    sources, ragged M and N tiles; repeated launches reproduce the first one bit for bit."""
+    """1x1 convolutions of the 64x64 / 128x128 levels at batch 8: the persistent 256x256 pointwise GEMM with deferred
+    stores (fd_conv_kernel_id == 7, fd_pwgemm.hip) and the 256x256 tile of the generic kernel (== 5) against the fp32
+    composition, with the pointwise epilogues they use; repeated launches reproduce the first one bit for bit, and the
+    persistent kernel gives the SAME BITS as the generic tile (same K order per output element: the same problem posed
+    with its K axis split over two sources is not eligible for the persistent kernel and runs on the generic one)."""
     from founddiff_amd import _lib as L
     from founddiff_amd.engine import ConvW
     e = eng_factory("bf16")
@@ -112,7 +117,7 @@ def test_pointwise_gemm_256_tile(eng_factory, cfg):
         kw.update(epi=L.EPI_GATE_RES, res=res.cuda().to(torch.bfloat16), gate=gate.cuda(), gate_ld=cout)
         ref = res + gate[:, None, None, :] * ref
     ad = a.cuda().to(torch.bfloat16)
-    assert e.conv(cw, ad, B, H, W, out, probe="kid", **kw) == 5
+    assert e.conv(cw, ad, B, H, W, out, probe="kid", **kw) == cfg["kid"]
     e.conv(cw, ad, B, H, W, out, **kw)
     torch.cuda.synchronize()
     assert rel_err(out.float().cpu(), ref) < 6e-3
@@ -120,6 +125,15 @@ def test_pointwise_gemm_256_tile(eng_factory, cfg):
     for _ in range(8):
         out.zero_()
         e.conv(cw, ad, B, H, W, out, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(out, first)
+    if cfg["kid"] == 7:
+        h0 = c0 // 2
+        kw2 = dict(kw, c0=h0, in1=ad[..., h0:].contiguous(), c1=c0 - h0)
+        a0 = ad[..., :h0].contiguous()
+        assert e.conv(cw, a0, B, H, W, out, probe="kid", **kw2) == 5
+        out.zero_()
+        e.conv(cw, a0, B, H, W, out, **kw2)
         torch.cuda.synchronize()
         assert torch.equal(out, first)
 
