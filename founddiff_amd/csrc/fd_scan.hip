@@ -829,26 +829,32 @@ int dispatch_n(const T *xc, const float *xdbl, const float *dtw, const float *dt
     return -1;
 }
 
-int chunk_len(int L, int D) {
-    // aim for >= ~4096 waves per image (4 per SIMD), chunk length a power of two in [32, 256].
-    // Deliberately independent of the batch size: a slice's result must not depend on what
+int chunk_len(int L, int D, bool low_latency) {
+    // aim for >= ~4096 waves per image (4 per SIMD), chunk length a power of two in [32, 256] -- [64, 256] in the
+    // throughput kernel set.  Deliberately independent of the batch size: a slice's result must not depend on what
     // else is in the batch (bitwise batch invariance -> sharding over GPUs changes nothing).
+    // Round 4: 32-step chunks only pay for ONE slice (low_latency); from batch 8 up the chip is full anyway and a chunk
+    // start costs its constants, its x_dbl staging and a carry entry: 64-step chunks measured 316 -> 270 us (d_inner 128,
+    // N = 8 at 256x256) and 472 -> 429 us (d_inner 512, N = 16 at 128x128) at batch 8, level 0 (128 steps) unchanged.
+    static const int force = [] { const char *e = getenv("FD_SCAN_CL"); return e ? atoi(e) : 0; }();     // development: chunk-length experiments
+    if (force >= 32 && force <= 256 && (force & (force - 1)) == 0) return force;
     int64_t units = (int64_t)4 * (D / 64) * L;
     int cl = 256;
+    const int cmin = low_latency ? 32 : 64;
     // (measured: 2048 / 1024 waves per image gain < 2 % at batch 8 and cost 8-30 % at batch 1)
-    while (cl > 32 && units / cl < 4096) cl >>= 1;
+    while (cl > cmin && units / cl < 4096) cl >>= 1;
     return cl;
 }
 
-ScanGeom make_geom(int B, int H, int W, int D, int N, int R) {
+ScanGeom make_geom(int B, int H, int W, int D, int N, int R, bool low_latency = false) {
     ScanGeom g;
     g.B = B; g.H = H; g.W = W; g.D = D; g.N = N; g.R = R; g.CD = R + 2 * N;
     g.H2 = (H + 1) / 2; g.W2 = (W + 1) / 2; g.L = g.H2 * g.W2;     // odd sizes: padded sub-grids (src/emamba2.py:191-199)
-    g.CL = chunk_len(g.L, D);
+    g.CL = chunk_len(g.L, D, low_latency);
     g.nch = (g.L + g.CL - 1) / g.CL;
     g.xw = nullptr;
     g.xdbl_out = nullptr;
-    g.low_latency = false;
+    g.low_latency = low_latency;
     return g;
 }
 
@@ -857,7 +863,7 @@ ScanGeom make_geom(int B, int H, int W, int D, int N, int R) {
 extern "C" int fd_selective_scan_fuses_xproj(int dtype, int D, int N, int R);
 
 extern "C" int64_t fd_scan_ws_floats(int B, int H, int W, int D, int N) {
-    ScanGeom g = make_geom(B, H, W, D, N, 1);
+    ScanGeom g = make_geom(B, H, W, D, N, 1, true);        // the kernel set with the shorter chunks: an upper bound for both
     return 2 * (int64_t)B * 4 * g.nch * N * D;
 }
 
@@ -869,8 +875,7 @@ static int scan_entry(int dtype_opts, const void *xc, const void *x_proj_w, floa
     FD_REQUIRE(H > 0 && W > 0, "fd_selective_scan: bad image size %d x %d", H, W);
     FD_REQUIRE(D % 64 == 0, "fd_selective_scan: d_inner=%d must be a multiple of 64", D);
     FD_REQUIRE((int64_t)H * W * D * 4 < (1ll << 31), "fd_selective_scan: one image must stay below 2^31 bytes");
-    ScanGeom g = make_geom(B, H, W, D, N, R);
-    g.low_latency = (dtype_opts & FD_OPT_LOW_LATENCY) != 0;
+    ScanGeom g = make_geom(B, H, W, D, N, R, (dtype_opts & FD_OPT_LOW_LATENCY) != 0);
     if (x_proj_w) {
         FD_REQUIRE(fd_selective_scan_fuses_xproj(dtype, D, N, R), "fd_selective_scan_xproj: not available for this shape "
                    "(bf16, d_inner <= 256, (R + 2N) %% 4 == 0): D=%d N=%d R=%d", D, N, R);
