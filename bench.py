@@ -168,7 +168,7 @@ def roofline_leg(dif, x, noise, t_measured_ms=None, clock_replay=True):
     #      off_v, partial, B, H, W, stream): reads 64 channels, writes v (64 channels) + one Gram partial per workgroup
     pg = [(n, a) for n, a in trace if n == "fd_pw_dw3x3_gram"]
     if pg:
-        pg_bytes = sum(1.0 * a[17] * a[18] * a[19] * (64 + 64) * esz + 1.0 * a[17] * 2 * lib.fd_pw_dw3x3_gram_nblk(a[18], a[19]) * 1088 * 4
+        pg_bytes = sum(1.0 * a[17] * a[18] * a[19] * (64 + 64) * esz + 1.0 * a[17] * 2 * lib.fd_pw_dw3x3_gram_nblk_opts(a[0], a[18], a[19]) * 1088 * 4
                        for _, a in pg)
         cands.append(hbm_entry("pwdw_gram_kernel", pg, pg_bytes, "pwdw_gram_hbm_bytes_per_launch"))
     # the two instantiations of the halo 3x3 kernel separately (separate symbols in the rocprof summary: <128,8> serves

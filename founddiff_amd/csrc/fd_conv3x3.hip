@@ -607,7 +607,10 @@ int fd_conv3x3_launch(const fd_conv_params &p, hipStream_t s) {
     // latency-bound load -> compute -> store sequence).  Chosen from the launch size only: any split gives the same
     // bits (a tile's result does not depend on which workgroup computes it).
     static const int tpw_env = [] { const char *e = getenv("FD_CONV_TPW"); return e ? atoi(e) : 0; }();
-    int tpw = tpw_env > 0 ? tpw_env : (int)((int64_t)tiles_xy * gy * p.B / 2048);
+    // Round 4: ONE tile per workgroup by default.  Alone on the chip several tiles per workgroup win (64 -> 64 at 512x512:
+    // 265 -> 238 us at 4 tiles), inside the forward they lose: FD_CONV_TPW=1 / 2 / 4 for every layer gave 13.09 / 13.11 /
+    // 13.37 ms per batch-8 forward against 13.13 with the launch-size rule (interleaved runs, one box).
+    int tpw = tpw_env > 0 ? tpw_env : 1;
     tpw = tpw < 1 ? 1 : (tpw > 8 ? 8 : tpw);
     dim3 grid(cdiv(tiles_xy, tpw), gy, p.B), block(256);
     static const size_t pad = fd_occ_pad("CONV3");

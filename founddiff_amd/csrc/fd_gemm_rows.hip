@@ -336,7 +336,12 @@ int fd_gemm_rows_launch(const fd_conv_params &p, hipStream_t s) {
     const int wtiles = (int)((hw + px - 1) / px);
     const size_t lds = (size_t)p.Cout * RS + 3 * (size_t)K * sizeof(float);
     int per_cu = (int)(150 * 1024 / lds);
-    if (per_cu > 4) per_cu = 4;
+    // (round 4: 3 persistent workgroups per CU instead of 4 once the batch fills the chip: -0.1..-0.3 % per batch-8 forward,
+    //  2: +0.8 %; 4 for small batches: +0.7 ms per 50-step slice at batch 1 otherwise.  The grid size does not touch the
+    //  results: every pixel row is computed by itself)
+    static const int pcmax = [] { const char *e = getenv("FD_ROWS_PER_CU_MAX"); return e ? atoi(e) : 0; }();    // development
+    const int pclim = pcmax > 0 ? pcmax : (p.B >= 4 ? 3 : 4);
+    if (per_cu > pclim) per_cu = pclim;
     if (per_cu < 1) per_cu = 1;
     int nt = per_cu >= 3 ? 256 : ((per_cu == 2 || !fits_768(KS, p.prologue)) ? 512 : 768);
     if (nt == 512 && !fits_512(KS, p.prologue)) nt = 256;

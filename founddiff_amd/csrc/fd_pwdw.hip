@@ -769,11 +769,13 @@ extern "C" int fd_pw_dw3x3(int dtype, const void *x, int ld_x, int off_x, int Ci
     return FD_OK;
 }
 
-// tiles per workgroup of the Gram-fused qkv kernel: a constant of the build (the order of the partial sums, hence
-// the result, must not depend on the batch); FD_GRAM_TPW overrides it for experiments
-static int gram_tpw() {
-    static const int t = [] { const char *e = getenv("FD_GRAM_TPW"); const int v = e ? atoi(e) : 4; return v >= 1 && v <= 64 ? v : 4; }();
-    return t;
+// tiles per workgroup of the Gram-fused qkv kernel: a constant of the kernel set (the order of the partial sums, hence
+// the result, must not depend on the batch): 8 in the throughput set (round 4: -0.3 % per batch-8 forward against 4;
+// 16: +0.6 %), 4 under FD_OPT_LOW_LATENCY (one slice: 8 leaves 256 workgroups for 256 CUs, +2.5 ms per 50-step slice);
+// FD_GRAM_TPW overrides both for experiments
+static int gram_tpw(int dtype_opts) {
+    static const int forced = [] { const char *e = getenv("FD_GRAM_TPW"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 64 ? v : 0; }();
+    return forced ? forced : ((dtype_opts & FD_OPT_LOW_LATENCY) ? 4 : 8);
 }
 
 extern "C" int fd_pw_dw3x3_gram_ok(int dtype, int Cin, int H, int W) {
@@ -781,15 +783,19 @@ extern "C" int fd_pw_dw3x3_gram_ok(int dtype, int Cin, int H, int W) {
     return !off && Cin == 64 && fd_pw_dw3x3_ok(dtype, Cin, 192, 0, H, W);      // pwdw_gram_kernel is the 64-channel form
 }
 
-extern "C" int fd_pw_dw3x3_gram_nblk(int H, int W) {
-    const int ntiles = (H / PT_H) * (W / PT_W);
-    return (ntiles + gram_tpw() - 1) / gram_tpw();
+extern "C" int fd_pw_dw3x3_gram_nblk_opts(int dtype_opts, int H, int W) {
+    const int ntiles = (H / PT_H) * (W / PT_W), tpw = gram_tpw(dtype_opts);
+    return (ntiles + tpw - 1) / tpw;
 }
+
+extern "C" int fd_pw_dw3x3_gram_nblk(int H, int W) { return fd_pw_dw3x3_gram_nblk_opts(0, H, W); }
 
 extern "C" int fd_pw_dw3x3_gram(int dtype, const void *x, int ld_x, int off_x, int Cin, const float *ln_gamma,
                                 const float *ln_beta, float ln_eps, const float *ln_shift, const float *ln_scale,
                                 int ln_ld, const void *w_pw, const uint32_t *w_dw, void *out_v, int ld_v, int off_v,
                                 float *partial, int B, int H, int W, void *stream) {
+    const int dtype_opts = dtype;
+    dtype &= 0xff;
     FD_REQUIRE(fd_pw_dw3x3_ok(dtype, Cin, 192, 0, H, W),
                "fd_pw_dw3x3_gram: unsupported shape (bf16, Cin=64, H%%8, W%%16, >= 32768 px): Cin=%d H=%d W=%d", Cin, H, W);
     FD_REQUIRE(x && ln_shift && ln_scale && w_pw && w_dw && out_v && partial, "fd_pw_dw3x3_gram: null pointer");
@@ -801,8 +807,8 @@ extern "C" int fd_pw_dw3x3_gram(int dtype, const void *x, int ld_x, int off_x, i
     p.ln_gamma = ln_gamma; p.ln_beta = ln_beta; p.ln_shift = ln_shift; p.ln_scale = ln_scale; p.ln_ld = ln_ld; p.ln_eps = ln_eps;
     p.w_pw = (const bf16 *)w_pw; p.w_dw = w_dw;
     p.out_v = (bf16 *)out_v; p.ld_v = ld_v; p.off_v = off_v;
-    p.part = partial; p.nblk = fd_pw_dw3x3_gram_nblk(H, W);
-    p.H = H; p.W = W; p.tpw = gram_tpw(); p.ntiles = (H / PT_H) * (W / PT_W);
+    p.part = partial; p.nblk = fd_pw_dw3x3_gram_nblk_opts(dtype_opts, H, W);
+    p.H = H; p.W = W; p.tpw = gram_tpw(dtype_opts); p.ntiles = (H / PT_H) * (W / PT_W);
     dim3 grid(p.nblk, B), block(256);
     static const size_t pad = fd_occ_pad("PWDW");
     hipLaunchKernelGGL(pwdw_gram_kernel, grid, block, pad, (hipStream_t)stream, p);

@@ -483,10 +483,11 @@ class DAEngine:
         if L.lib().fd_pw_dw3x3_gram_ok(self.dt, Cc, H, W):
             # qkv -> qkv_dwconv -> L2 norms + q k^T in one pass: q and k never reach HBM, only v and one Gram
             # partial per workgroup do (fd_pwdw.hip: pwdw_gram_kernel)
-            nblk = L.lib().fd_pw_dw3x3_gram_nblk(H, W)
+            gdt = getattr(self, 'scan_dt', self.dt)          # carries FD_OPT_LOW_LATENCY: tiles per workgroup of the Gram kernel
+            nblk = L.lib().fd_pw_dw3x3_gram_nblk_opts(gdt, H, W)
             vbuf = self._b("attn_v", (B, H, W, Cc))
             part = self._b("gram", (B, m["heads"], nblk, 1024 + 64), torch.float32)
-            L.call("fd_pw_dw3x3_gram", self.dt, _p(x1), Cc, 0, Cc, None, None, 1e-6, mp(3), mp(4), ml,
+            L.call("fd_pw_dw3x3_gram", gdt, _p(x1), Cc, 0, Cc, None, None, 1e-6, mp(3), mp(4), ml,
                    _p(m["qkv"].w), _p(m["qdw_wm"]), _p(vbuf), Cc, 0, _p(part), B, H, W, s)
             self._pr(tag + ".qkv2", vbuf)
             weff = self._b("weff", (B, Cc, Cc))

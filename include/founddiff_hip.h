@@ -198,6 +198,9 @@ int fd_pw_dw3x3(int dtype, const void *x, int ld_x, int off_x, int Cin, const fl
  * power-of-two scale folded into their w_pw rows / w_dw taps is free (founddiff_amd/engine.py does that at pack time). */
 int fd_pw_dw3x3_gram_ok(int dtype, int Cin, int H, int W);
 int fd_pw_dw3x3_gram_nblk(int H, int W);
+/* ... with `dtype | FD_OPT_LOW_LATENCY` passed to fd_pw_dw3x3_gram (4 instead of 8 tiles per workgroup: the kernel set for ONE
+ * slice, as for the scan) the partial count is fd_pw_dw3x3_gram_nblk_opts(dtype_opts, H, W).                         */
+int fd_pw_dw3x3_gram_nblk_opts(int dtype_opts, int H, int W);
 int fd_pw_dw3x3_gram(int dtype, const void *x, int ld_x, int off_x, int Cin, const float *ln_gamma,
                      const float *ln_beta, float ln_eps, const float *ln_shift, const float *ln_scale,
                      int ln_ld, const void *w_pw, const uint32_t *w_dw, void *out_v, int ld_v, int off_v,
