@@ -600,7 +600,8 @@ int fd_conv3x3_fp8_ok(const fd_conv_params &p) {
 
 int fd_conv3x3_launch(const fd_conv_params &p, hipStream_t s) {
     const bool wide = p.Cout > 64;
-    const int th = (!wide && p.OH % 16 == 0) ? 16 : 8;
+    static const bool th8 = getenv("FD_CONV3_TH8") != nullptr;        // development: 8-row tiles for Cout <= 64 too
+    const int th = (!wide && p.OH % 16 == 0 && !th8) ? 16 : 8;
     const int tiles_xy = (p.OH / th) * (p.OW / TW), gy = cdiv(p.Cout, wide ? 128 : 64);
     // consecutive tiles per workgroup: the next tile's halo is in flight during the current tile's MFMAs (a workgroup
     // per tile has nothing in flight while it computes: the 64 -> 64 convolutions of level 0 ran at 2.1 TB/s of a

@@ -731,11 +731,15 @@ __global__ __launch_bounds__(256, 3) void dwconv_gram_kernel(const DwGramParams 
 
 }  // namespace
 
-extern "C" int fd_pw_dw3x3_ok(int dtype, int Cin, int Cdw, int Cz, int H, int W) {
+extern "C" int fd_pw_dw3x3_ok(int dtype_opts, int Cin, int Cdw, int Cz, int H, int W) {
+    // `dtype | FD_OPT_LOW_LATENCY`: the kernel set for ONE slice keeps the C = 128 block on row-GEMM + depthwise (the fused
+    // 128-channel form has two workgroups per CU and too few tiles for a lone slice: 155 -> 153 ms per 50-step slice)
+    const int dtype = dtype_opts & 0xff;
     static const bool no128 = getenv("FD_NO_PWDW128") != nullptr;        // development switch
-    const bool c64 = Cin == 64 && Cdw <= 192, c128 = Cin == 128 && Cdw <= 256 && Cz <= 256 && !no128;
+    static const int minpix = [] { const char *e = getenv("FD_PWDW_MINPIX"); return e ? atoi(e) : 32768; }();    // development
+    const bool c64 = Cin == 64 && Cdw <= 192, c128 = Cin == 128 && Cdw <= 256 && Cz <= 256 && !no128 && !(dtype_opts & FD_OPT_LOW_LATENCY);
     return dtype == FD_BF16 && (c64 || c128) && Cdw > 0 && Cdw % 64 == 0 && Cz >= 0 && Cz % 32 == 0 && H % PT_H == 0 &&
-           W % PT_W == 0 && (int64_t)H * W >= 32768 && (int64_t)H * W * 256 < (1ll << 31);   // 32-bit element offsets
+           W % PT_W == 0 && (int64_t)H * W >= minpix && (int64_t)H * W * 256 < (1ll << 31);   // 32-bit element offsets
 }
 
 extern "C" int fd_pw_dw3x3(int dtype, const void *x, int ld_x, int off_x, int Cin, const float *ln_gamma,
@@ -743,6 +747,7 @@ extern "C" int fd_pw_dw3x3(int dtype, const void *x, int ld_x, int off_x, int Ci
                            int ln_ld, const void *w_pw, int Cdw, const uint32_t *w_dw, const float *b_dw,
                            int dw_silu, void *out_dw, int ld_dw, int off_dw, int Cz, void *out_z, int ld_z,
                            int off_z, int B, int H, int W, void *stream) {
+    dtype &= 0xff;
     FD_REQUIRE(fd_pw_dw3x3_ok(dtype, Cin, Cdw, Cz, H, W),
                "fd_pw_dw3x3: unsupported shape (bf16, Cin=64|128, Cdw%%64, Cz%%32, H%%8, W%%16, >= 32768 px): "
                "Cin=%d Cdw=%d Cz=%d H=%d W=%d", Cin, Cdw, Cz, H, W);
@@ -760,7 +765,9 @@ extern "C" int fd_pw_dw3x3(int dtype, const void *x, int ld_x, int off_x, int Ci
     p.H = H; p.W = W;
     p.ntiles = (H / PT_H) * (W / PT_W);
     static const int tpw_env = [] { const char *e = getenv("FD_PWDW_TPW"); return e ? atoi(e) : 0; }();
-    p.tpw = tpw_env > 0 ? tpw_env : 4;
+    // (4 consecutive tiles per workgroup once the batch fills the chip; ONE for a lone slice: 154.6 -> 152.8 ms per 50-step
+    //  slice at batch 1.  Tiles are independent: the split does not touch the results)
+    p.tpw = tpw_env > 0 ? tpw_env : (B >= 4 ? 4 : 1);
     dim3 grid((p.ntiles + p.tpw - 1) / p.tpw, B), block(256);
     static const size_t pad = fd_occ_pad("PWDW");
     if (Cin == 64) hipLaunchKernelGGL(pwdw_kernel<64>, grid, block, pad, (hipStream_t)stream, p);

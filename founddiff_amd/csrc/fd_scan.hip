@@ -778,7 +778,9 @@ void launch_scan(const T *xc, const float *xdbl, const float *dtw, const float *
     // shape only
     constexpr int CPL = (sizeof(T) == 2 && N <= 4) ? 2 : 1;     // N = 8: measured slower (305 vs 293 us at 256x256, batch 8)
     // (with the x_proj einsum inside phase A the two-channel form holds d_inner / 32 <= 4 pixel fragments per block)
-    const bool two = CPL == 2 && g.D % 128 == 0 && (!g.xw || g.D == 128) && scan_cpl2_on();
+    // (not for ONE slice: a lone image has 2048 two-channel waves at level 0 for 1024 SIMDs; one channel per lane doubles
+    //  them: 155.7 -> 154.3 ms per 50-step slice at batch 1)
+    const bool two = CPL == 2 && g.D % 128 == 0 && (!g.xw || g.D == 128) && scan_cpl2_on() && !g.low_latency;
     const int cw = two ? 128 : 64;                     // channels per wave
     const int nw = g.D >= 4 * cw ? 4 : g.D / cw;       // waves per workgroup
     dim3 grid(g.nch * (g.D / (cw * nw)), g.B * 4), block(64 * nw);

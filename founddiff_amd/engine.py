@@ -417,7 +417,7 @@ class DAEngine:
         ln1 = dict(prologue=L.PRO_LN_MOD, ln_gamma=m["n1w"], ln_beta=m["n1b"], ln_eps=1e-5, ln_shift=mp(0),
                    ln_scale=mp(1), ln_ld=ml)
         xc = self._b("xc", (B, H, W, D))
-        fused = bool(L.lib().fd_pw_dw3x3_ok(self.dt, Cc, D, D, H, W))
+        fused = bool(L.lib().fd_pw_dw3x3_ok(getattr(self, 'scan_dt', self.dt), Cc, D, D, H, W))      # (low latency: C = 128 unfused)
         if fused:
             # LN+modulate -> in_proj -> conv2d+SiLU (x half) / SiLU (z half) in one pass: the x half of
             # in_proj's output never exists in HBM (xz[..., :D] stays unwritten, z lands in xz[..., D:])

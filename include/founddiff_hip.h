@@ -180,7 +180,8 @@ int fd_dwconv3x3(int dtype, const void *in, int ld_in, int off_in, const float *
  *          depthwise runs on v_pk_fma_f16 (the 1x1 output is kept in LDS as fp16 channel pairs, the 9-tap sum is
  *          accumulated in fp16 starting from the bias rounded to fp16 (toward zero); SiLU in fp32).  b_dw [Cdw] fp32 or NULL
  *   ln_*   as fd_conv_params' LN_MOD prologue (gamma/beta may be NULL)
- * fd_pw_dw3x3_ok: 1 if the shape is served (callers fall back to fd_conv2d + fd_dwconv3x3).   */
+ * fd_pw_dw3x3_ok: 1 if the shape is served (callers fall back to fd_conv2d + fd_dwconv3x3); `dtype | FD_OPT_LOW_LATENCY`
+ *   answers for the one-slice kernel set (Cin = 128 stays unfused there).   */
 int fd_pw_dw3x3_ok(int dtype, int Cin, int Cdw, int Cz, int H, int W);
 int fd_pw_dw3x3(int dtype, const void *x, int ld_x, int off_x, int Cin, const float *ln_gamma,
                 const float *ln_beta, float ln_eps, const float *ln_shift, const float *ln_scale,
