@@ -347,6 +347,8 @@ class ResidualDiffusion(nn.Module):
         # 4.6e-3 / 57.5 dB at 10.2; levels 0-1 of the last step in fp32 (default 2) 7.0e-3 / 53.8 dB at 10.5;
         # level 0 alone 1.01e-2 (the error of the inner levels passes through the outer up path undamped).
         self.final_outer_levels = int(os.environ.get("FOUNDDIFF_FINAL_OUTER_LEVELS", "2"))
+        # how many of those levels also run their DOWN stage on the tail engine (default: all of them)
+        self.final_down_levels = int(os.environ.get("FOUNDDIFF_FINAL_DOWN_LEVELS", "-1"))
         for k, v in residual_schedule(timesteps, after_init=False).items():
             self.register_buffer(k, v)
         self._host_sched = None
@@ -576,7 +578,8 @@ class ResidualDiffusion(nn.Module):
         """The forward of a tail step: hybrid (outer levels on e32, the rest on eng) or all of it on e32."""
         k = self.final_outer_levels
         if k > 0 and k < len(e32.downs):
-            e32.forward_hybrid(eng, img, x_in, time_buf, out=mo, outer_levels=k, sched=sched)
+            e32.forward_hybrid(eng, img, x_in, time_buf, out=mo, outer_levels=k, sched=sched,
+                               down_levels=None if self.final_down_levels < 0 else self.final_down_levels)
         else:
             e32.forward(img, x_in, time_buf, out=mo, sched=sched)
 
@@ -584,7 +587,7 @@ class ResidualDiffusion(nn.Module):
         eng = eng or self._eng()
         run = (lambda: self._tail_forward(eng, tail_of, img, x_in, time_buf, mo)) if tail_of is not None else \
             (lambda: eng.forward(img, x_in, time_buf, out=mo))
-        key = (tuple(img.shape), eng.mode, eng.gen, tail_of.gen if tail_of is not None else 0, self.final_outer_levels)
+        key = (tuple(img.shape), eng.mode, eng.gen, tail_of.gen if tail_of is not None else 0, self.final_outer_levels, self.final_down_levels)
         if not self.use_graph:
             run()
             return
@@ -727,7 +730,7 @@ class ResidualDiffusion(nn.Module):
         # small) a fixed 40 with the n_main % 40 leftover steps run eagerly in front of the replays
         G = max([g for g in range(8, 65) if n_main > 0 and n_main % g == 0] or [40])
         graphs = eng.__dict__.setdefault("anc_graphs", {})
-        key = (tuple(img.shape), eng.mode, eng.gen, G, K, e32.gen if e32 else 0, self.final_outer_levels, T)
+        key = (tuple(img.shape), eng.mode, eng.gen, G, K, e32.gen if e32 else 0, self.final_outer_levels, self.final_down_levels, T)
         reps, rem = n_main // G, n_main % G
         if key not in graphs:
             start, t0 = img.clone(), t_dev.clone()
@@ -810,7 +813,7 @@ class ResidualDiffusion(nn.Module):
         if self.use_graph and last and os.environ.get("FOUNDDIFF_LOOP_GRAPH", "1") != "0":
             # the whole S-step loop as ONE HIP graph (S x (time fill + 141 kernels + DDIM update), every
             # scheduler constant baked into its node): replayed per sample() on the persistent loop buffers
-            key = ("ddim", tuple(shape), eng.mode, eng.gen, S, T, K, e32.gen if e32 else 0, self.final_outer_levels)
+            key = ("ddim", tuple(shape), eng.mode, eng.gen, S, T, K, e32.gen if e32 else 0, self.final_outer_levels, self.final_down_levels)
 
             def fwd(e, sched=None):
                 if e is eng:

@@ -668,31 +668,37 @@ class DAEngine:
             x, h, w = self._up(i, x, B, h, w)
         return self._tail(x, r, B, H, W, out, sched, x_t, x_in)
 
-    def forward_hybrid(self, inner, x_t, x_in, time, out=None, outer_levels=1, sched=None):
-        """One forward with THIS engine on the outermost `outer_levels` resolution levels (init_conv, the first
-        down stages, the last up stages, final block) and `inner` -- another engine of the same weights, normally
-        one precision class down -- on the levels in between; the activation crosses the boundary through a
-        dtype cast (`fd_cast`).  The last step of a sampling loop runs this way (ResidualDiffusion: fp32 at the
-        full-resolution level, where 53 % of the bf16 drift of a forward originates, bf16 below)."""
+    def forward_hybrid(self, inner, x_t, x_in, time, out=None, outer_levels=1, sched=None, down_levels=None):
+        """One forward with THIS engine on the outermost resolution levels (init_conv, the first `down_levels` down
+        stages, the last `outer_levels` up stages, final block) and `inner` -- another engine of the same weights, normally
+        one precision class down -- on the levels in between; the activation crosses the boundary through a dtype cast
+        (`fd_cast`).  The last step of a sampling loop runs this way (ResidualDiffusion: the split-bf16 fp32 engine at
+        the outer levels, where most of the bf16 drift of the returned image originates, bf16 below).  `down_levels`
+        (default = outer_levels) < outer_levels keeps part of the encoder on `inner`; its skips are cast on their way
+        into this engine's up stages."""
         B, _, H, W = x_t.shape
         nd, nu = len(self.downs), len(self.ups)
-        k = outer_levels
-        assert 0 < k < nd and nu == nd
+        ku = outer_levels
+        kd = ku if down_levels is None else max(0, min(int(down_levels), ku))
+        assert 0 < ku < nd and nu == nd
         self.time_cond(time)
         inner.time_cond(time)
         r = self._head(x_t, x_in, None)
         x, h, w = r, H, W
         self._skips, inner._skips = [], []
-        for i in range(k):
+        for i in range(kd):
             x, h, w = self._down(i, x, B, h, w)
         x = inner._cast_from(x, self, "hyb_in")
-        for i in range(k, nd):
+        for i in range(kd, nd):
             x, h, w = inner._down(i, x, B, h, w)
         x = inner._mid(x, B, h, w)
-        for i in range(nu - k):
+        for i in range(nu - ku):
             x, h, w = inner._up(i, x, B, h, w)
         x = self._cast_from(x, inner, "hyb_out")
-        for i in range(nu - k, nu):
+        for lvl, (sk, hs, ws_) in enumerate(inner._skips):       # skips of levels kd .. ku - 1, shallowest first
+            self._skips.append((self._cast_from(sk, inner, f"hyb_skip{kd + lvl}"), hs, ws_))
+        inner._skips = []
+        for i in range(nu - ku, nu):
             x, h, w = self._up(i, x, B, h, w)
         return self._tail(x, r, B, H, W, out, sched, x_t, x_in)
 
