@@ -47,7 +47,10 @@ def conv_flops(p):
     cin = p.c0 + p.c1
     if p.KH == 7 and cin == 8:
         cin = 2       # init_conv: channels 2..7 are zero padding, not algorithmic work
-    return 2.0 * p.B * p.OH * p.OW * p.Cout * p.KH * p.KW * cin * p.ndir
+    fl = 2.0 * p.B * p.OH * p.OW * p.Cout * p.KH * p.KW * cin * p.ndir
+    if p.prologue == 3:      # PRO_LN_GATE_ZRE: the z half of in_proj (Cout -> Cin) runs inside out_proj
+        fl += 2.0 * p.B * p.OH * p.OW * p.Cout * cin
+    return fl
 
 
 def _time_launches(lib, launches, reps=5):

@@ -12,7 +12,7 @@ FD_F32, FD_BF16 = 0, 1
 FD_OPT_LOW_LATENCY = 0x100
 EPI_NONE, EPI_SILU_SPLIT, EPI_RELU, EPI_GATE_RES, EPI_RES_RELU, EPI_GNSILU_ADD, EPI_GNSILU_ADD_FINAL = range(7)
 ACT_NONE, ACT_SILU, ACT_GELU, ACT_RELU = range(4)
-PRO_NONE, PRO_LN_MOD, PRO_LN_GATE = range(3)
+PRO_NONE, PRO_LN_MOD, PRO_LN_GATE, PRO_LN_GATE_ZRE = range(4)
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -43,6 +43,8 @@ class ConvParams(C.Structure):
         ("weight_f8", vp), ("w_scale", vp), ("act_scale", f32), ("f32_split", i32),
         ("fin_w", vp), ("fin_b", f32), ("fin_out", vp), ("fin_mode", i32), ("fin_last", i32), ("fin_img", vp),
         ("fin_xin", vp), ("fin_alpha", f32),
+        ("zre_w", vp), ("zre_gamma", vp), ("zre_beta", vp), ("zre_shift", vp), ("zre_scale", vp), ("zre_ld", i32),
+        ("zre_eps", f32),
     ]
 
 

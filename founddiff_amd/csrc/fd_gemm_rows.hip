@@ -276,6 +276,201 @@ __global__ __launch_bounds__(NT) void gemm_rows_kernel(const fd_conv_params p, i
 
 int row_stride(int K) { return K <= 64 ? 128 : (K <= 128 ? 256 : 512); }
 
+// ---------------------------------------------------------------------------------------------------------------
+// out_proj with the z gate RECOMPUTED (FD_PRO_LN_GATE_ZRE, round 4).  The fused in_proj kernel (fd_pwdw.hip) used to
+// write z = SiLU(W_z . LNmod(x)) -- d_inner channels per pixel, twice the block's own width -- only for this kernel to
+// read it back as the gate of out_norm(y): 1.07 GB of the 6.2 GB a level-0 Mamba block moves at batch 8.  out_proj
+// reads the block input x anyway (the residual of its GATE_RES epilogue), the z rows of in_proj are 16 KB, and the
+// transposed MFMA issue of this file hands a lane EXACTLY the 8 consecutive z channels of its pixel that the LN_GATE
+// prologue multiplies into its 8 y channels (K32 step ks of y <-> 32-row group ks of W_z).  So per 16-pixel tile:
+//   x row (CX = K/2 channels) -> LayerNorm + adaLN modulate (one pass, packed; the arithmetic of fd_ln_mod_chunk)
+//   -> bf16 -> K/32 x (K/64) x 2 MFMAs against W_z in LDS -> SiLU -> bf16 (the rounding point of the stored z)
+//   -> LN_GATE prologue on y with z from registers -> out_proj MFMAs -> x + gate . (acc + bias) with x from the
+//   registers the prologue loaded.  The matrix pipe of this HBM-bound kernel was 4 % busy; bytes per pixel fall from
+//   (K + K + CX + CX) x 2 to (K + CX + CX) x 2.
+template <int KS, int NT>
+__global__ __launch_bounds__(NT) void gemm_rows_zre_kernel(const fd_conv_params p, int wtiles) {
+    constexpr int NW = NT / 64, K = 32 * KS, KX = KS / 2, CX = 16 * KS;
+    constexpr int RS = K <= 128 ? 256 : 512, RX = CX <= 64 ? 128 : 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *sW = smem;                                  // out_proj  [CX rows][RS]
+    unsigned char *sZ = smem + CX * RS;                        // W_z       [K rows][RX]
+    float *sV = (float *)(sZ + K * RX);                        // out_norm gamma, beta, local: [3][K]
+    float *sX = sV + 3 * K;                                    // norm1 G = gamma (1 + scale), Bc = beta (1 + scale) + shift: [2][CX]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int b = blockIdx.y;
+    const int64_t hw = (int64_t)p.H * p.W;
+    {
+        const bf16 *wg = (const bf16 *)p.weight, *wz = (const bf16 *)p.zre_w;
+        for (int idx = tid; idx < CX * (K / 8); idx += NT) {
+            const int row = idx / (K / 8), ch = idx - row * (K / 8);
+            *(u32x4 *)(sW + w_off(row, ch, RS)) = *(const u32x4 *)(wg + (int64_t)row * K + ch * 8);
+        }
+        for (int idx = tid; idx < K * (CX / 8); idx += NT) {
+            const int row = idx / (CX / 8), ch = idx - row * (CX / 8);
+            *(u32x4 *)(sZ + w_off(row, ch, RX)) = *(const u32x4 *)(wz + (int64_t)row * CX + ch * 8);
+        }
+        for (int c = tid; c < K; c += NT) {
+            sV[c] = p.ln_gamma[c];
+            sV[K + c] = p.ln_beta[c];
+            sV[2 * K + c] = p.ln_shift[(int64_t)b * p.ln_ld + c];
+        }
+        for (int c = tid; c < CX; c += NT) {
+            const float g = p.zre_gamma ? p.zre_gamma[c] : 1.f, be = p.zre_beta ? p.zre_beta[c] : 0.f;
+            const float sc = 1.f + p.zre_scale[(int64_t)b * p.zre_ld + c], sh = p.zre_shift[(int64_t)b * p.zre_ld + c];
+            sX[c] = g * sc;
+            sX[CX + c] = be * sc + sh;
+        }
+    }
+    __syncthreads();
+    const bf16 *yin = (const bf16 *)p.in0 + (int64_t)b * hw * p.ld0 + p.off0;
+    const bf16 *xin = (const bf16 *)p.res + (int64_t)b * hw * p.ld_res + p.off_res;
+    bf16 *outp = (bf16 *)p.out + (int64_t)b * hw * p.ldo + p.offo;
+    const int rperm = 8 * (fr >> 2) + (fr & 3);       // weight rows permuted so that a lane ends up with 8 consecutive channels
+    const int wstride = gridDim.x * NW;
+    for (int wt = blockIdx.x * NW + wave; wt < wtiles; wt += wstride) {
+        const int64_t m = min((int64_t)wt * 16 + fr, hw - 1);     // ragged last tile: rows beyond the image read the last row
+        u32x4 yr[KS], xr[KX];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) yr[ks] = *(const u32x4 *)(yin + m * p.ld0 + ks * 32 + fg * 8);
+#pragma unroll
+        for (int kx = 0; kx < KX; ++kx) xr[kx] = *(const u32x4 *)(xin + m * p.ld_res + kx * 32 + fg * 8);
+        // the per-channel vectors of a lane do not depend on the tile; an opaque copy of fg keeps their (cheap) LDS reads
+        // inside the loop instead of 5 x K/4 permanently live registers (see gemm_rows_kernel)
+        int fgo = fg;
+        asm volatile("" : "+v"(fgo));
+        // ---- z = SiLU(W_z . LNmod(x)): a pixel's CX channels sit in the 4 lanes fr, fr + 16, fr + 32, fr + 48
+        u32x4 zb[KS];
+        {
+            f32x2 s = {0.f, 0.f}, q = {0.f, 0.f};
+#pragma unroll
+            for (int kx = 0; kx < KX; ++kx) {
+                const uint32_t rw[4] = {xr[kx].x, xr[kx].y, xr[kx].z, xr[kx].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x2 v = fd_unpack_bf16(rw[j]);
+                    s += v;
+                    q = v * v + q;
+                }
+            }
+            float s1 = s.x + s.y, s2 = q.x + q.y;
+            s1 += __shfl_xor(s1, 16, 64);
+            s2 += __shfl_xor(s2, 16, 64);
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            const float mean = s1 * (1.f / CX);
+            const float var = fmaxf(s2 * (1.f / CX) - mean * mean, 0.f);
+            const float rstd = __builtin_amdgcn_rsqf(var + p.zre_eps), nm = -mean * rstd;
+            bf16x8 xn[KX];
+#pragma unroll
+            for (int kx = 0; kx < KX; ++kx) {
+                const int c = kx * 32 + fgo * 8;
+                const uint32_t rw[4] = {xr[kx].x, xr[kx].y, xr[kx].z, xr[kx].w};
+                uint32_t o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x2 t = fd_unpack_bf16(rw[j]) * rstd + nm;
+                    o[j] = fd_pack_bf16(t * *(const f32x2 *)&sX[c + 2 * j] + *(const f32x2 *)&sX[CX + c + 2 * j]);
+                }
+                xn[kx] = __builtin_bit_cast(bf16x8, (u32x4){o[0], o[1], o[2], o[3]});
+            }
+#pragma unroll
+            for (int ng = 0; ng < KS; ++ng) {
+                f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kx = 0; kx < KX; ++kx) {
+                    const bf16x8 wa = *(const bf16x8 *)(sZ + w_off(32 * ng + rperm, kx * 4 + fgo, RX));
+                    const bf16x8 wb = *(const bf16x8 *)(sZ + w_off(32 * ng + rperm + 4, kx * 4 + fgo, RX));
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xn[kx], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, xn[kx], a1, 0, 0, 0);
+                }
+                float val[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                fd_silu8(val);
+                zb[ng] = (u32x4){fd_pack_bf16(f32x2{val[0], val[1]}), fd_pack_bf16(f32x2{val[2], val[3]}),
+                                 fd_pack_bf16(f32x2{val[4], val[5]}), fd_pack_bf16(f32x2{val[6], val[7]})};
+            }
+        }
+        // ---- out_norm(y) * z + local (two-pass statistics: the arithmetic of the LN_GATE prologue)
+        bf16x8 xb[KS];
+        {
+            f32x2 s = {0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const uint32_t rw[4] = {yr[ks].x, yr[ks].y, yr[ks].z, yr[ks].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s += fd_unpack_bf16(rw[j]);
+            }
+            float s1 = s.x + s.y;
+            s1 += __shfl_xor(s1, 16, 64);
+            s1 += __shfl_xor(s1, 32, 64);
+            const float mean = s1 * (1.f / K);
+            f32x2 q = {0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const uint32_t rw[4] = {yr[ks].x, yr[ks].y, yr[ks].z, yr[ks].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x2 d = fd_unpack_bf16(rw[j]) - mean;
+                    q = d * d + q;
+                }
+            }
+            float s2 = q.x + q.y;
+            s2 += __shfl_xor(s2, 16, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            const float rstd = rsqrtf(s2 * (1.f / K) + p.ln_eps);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int c = ks * 32 + fgo * 8;
+                const uint32_t rw[4] = {yr[ks].x, yr[ks].y, yr[ks].z, yr[ks].w};
+                const uint32_t zw[4] = {zb[ks].x, zb[ks].y, zb[ks].z, zb[ks].w};
+                uint32_t o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x2 t = (fd_unpack_bf16(rw[j]) - mean) * rstd;
+                    const f32x2 u = t * *(const f32x2 *)&sV[c + 2 * j] + *(const f32x2 *)&sV[K + c + 2 * j];
+                    o[j] = fd_pack_bf16(u * fd_unpack_bf16(zw[j]) + *(const f32x2 *)&sV[2 * K + c + 2 * j]);
+                }
+                u32x4 pin = {o[0], o[1], o[2], o[3]};
+                asm volatile("" : "+v"(pin));            // one K32 step at a time (register diet, see gemm_rows_kernel)
+                xb[ks] = __builtin_bit_cast(bf16x8, pin);
+            }
+        }
+        // ---- out_proj + gate . () + x
+        const bool live = (int64_t)wt * 16 + fr < hw;
+#pragma unroll
+        for (int ng = 0; ng < KX; ++ng) {
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 wa = *(const bf16x8 *)(sW + w_off(32 * ng + rperm, ks * 4 + fgo, RS));
+                const bf16x8 wb = *(const bf16x8 *)(sW + w_off(32 * ng + rperm + 4, ks * 4 + fgo, RS));
+                a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb[ks], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, xb[ks], a1, 0, 0, 0);
+            }
+            const int n0 = 32 * ng + 8 * fg;
+            float bias[8], gt[8];
+            if (p.bias) load8(p.bias + n0, bias);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bias[e] = 0.f;
+            }
+            load8(p.gate + (int64_t)b * p.gate_ld + n0, gt);
+            const uint32_t rw[4] = {xr[ng].x, xr[ng].y, xr[ng].z, xr[ng].w};
+            float val[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { val[e] = a0[e] + bias[e]; val[4 + e] = a1[e] + bias[4 + e]; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x2 r = fd_unpack_bf16(rw[j]);
+                val[2 * j] = r.x + gt[2 * j] * val[2 * j];
+                val[2 * j + 1] = r.y + gt[2 * j + 1] * val[2 * j + 1];
+            }
+            if (live) store8(outp + m * p.ldo + n0, val);
+        }
+    }
+}
+
 // 12 waves per workgroup leave 170 VGPRs per lane: enough for every variant without a prologue, for
 // LN+modulate up to K=128 and for LN*z+local up to K=96; the wider ones stay at 8 waves (256 VGPRs).
 constexpr bool fits_768(int KS, int PRO) { return PRO == 0 || (PRO == 1 && KS <= 4) || KS <= 3; }
@@ -318,23 +513,33 @@ extern "C" int fd_conv_prologue_ok(const fd_conv_params *pp) {
     if ((p.epilogue == FD_EPI_GNSILU_ADD || p.epilogue == FD_EPI_GNSILU_ADD_FINAL) && (p.gn_groups <= 0 || (p.Cout / p.gn_groups) % 8)) return 0;
     if (p.epilogue == FD_EPI_GNSILU_ADD_FINAL && (!p.fin_w || !p.fin_out || ((uintptr_t)p.fin_w & 15) ||
                                                   (p.fin_mode == 1 && (!p.fin_img || !p.fin_xin)))) return 0;
+    if (p.prologue < FD_PRO_NONE || p.prologue > FD_PRO_LN_GATE_ZRE) return 0;
     if (p.prologue == FD_PRO_LN_MOD && p.epilogue != FD_EPI_NONE && p.epilogue != FD_EPI_SILU_SPLIT) return 0;
-    if (p.prologue == FD_PRO_LN_GATE && p.epilogue != FD_EPI_GATE_RES) return 0;
+    if ((p.prologue == FD_PRO_LN_GATE || p.prologue == FD_PRO_LN_GATE_ZRE) && p.epilogue != FD_EPI_GATE_RES) return 0;
     if (p.prologue != FD_PRO_NONE) {
         if (p.c1 != 0) return 0;
         if (p.prologue == FD_PRO_LN_GATE && (!p.ln_z || p.ln_ldz % 8 || p.ln_offz % 8 || !p.ln_gamma || !p.ln_beta)) return 0;
         if (!p.ln_shift || (p.prologue == FD_PRO_LN_MOD && !p.ln_scale)) return 0;
+        if (p.prologue == FD_PRO_LN_GATE_ZRE) {
+            // z recomputed from the residual operand: d_inner = 2 dim, shared (not per-batch) weights, the K = 128 instance
+            if ((K != 128 && K != 256) || 2 * p.Cout != K || p.w_batch_stride != 0 || !p.res || !p.ln_gamma || !p.ln_beta) return 0;
+            if (!p.zre_w || ((uintptr_t)p.zre_w & 15) || !p.zre_shift || !p.zre_scale) return 0;
+        }
     }
     if ((int64_t)p.H * p.W < 16384) return 0;     // few pixels: the tiled kernel parallelises better
     return 1;
 }
 
+constexpr int ZRE8_NT = 512;
+
 int fd_gemm_rows_launch(const fd_conv_params &p, hipStream_t s) {
     const int K = p.c0 + p.c1, KS = K / 32, RS = row_stride(K);
     const int64_t hw = (int64_t)p.H * p.W;
     const int px = KS <= 2 ? 32 : 16;      // pixels per wave iteration (see template parameter S)
-    const int wtiles = (int)((hw + px - 1) / px);
-    const size_t lds = (size_t)p.Cout * RS + 3 * (size_t)K * sizeof(float);
+    const bool zre = p.prologue == FD_PRO_LN_GATE_ZRE;
+    const int wtiles = (int)((hw + (zre ? 16 : px) - 1) / (zre ? 16 : px));
+    const size_t lds = (size_t)p.Cout * RS + 3 * (size_t)K * sizeof(float) +
+                       (zre ? (size_t)K * row_stride(K / 2) + (size_t)K * sizeof(float) : 0);
     int per_cu = (int)(150 * 1024 / lds);
     // (round 4: 3 persistent workgroups per CU instead of 4 once the batch fills the chip: -0.1..-0.3 % per batch-8 forward,
     //  2: +0.8 %; 4 for small batches: +0.7 ms per 50-step slice at batch 1 otherwise.  The grid size does not touch the
@@ -345,11 +550,21 @@ int fd_gemm_rows_launch(const fd_conv_params &p, hipStream_t s) {
     if (per_cu < 1) per_cu = 1;
     int nt = per_cu >= 3 ? 256 : ((per_cu == 2 || !fits_768(KS, p.prologue)) ? 512 : 768);
     if (nt == 512 && !fits_512(KS, p.prologue)) nt = 256;
+    if (zre && K == 256) nt = ZRE8_NT;
     static const int cap = [] { const char *e = getenv("FD_ROWS_PER_CU"); return e ? atoi(e) : 0; }();   // development: see fd_occ_pad
     int gx = (256 * ((cap > 0 && per_cu > cap) ? cap : per_cu) + p.B - 1) / p.B;
     const int need = (wtiles + nt / 64 - 1) / (nt / 64);
     if (gx > need) gx = need;
     dim3 grid(gx, p.B);
+    if (zre) {
+        if (K == 128) hipLaunchKernelGGL((gemm_rows_zre_kernel<4, 256>), grid, dim3(256), lds, s, p, wtiles);
+        else {
+            // K = 256: 64 KB of out_proj + 64 KB of W_z rows -- one workgroup per CU, so its waves are the CU's waves
+            (void)hipFuncSetAttribute((const void *)gemm_rows_zre_kernel<8, ZRE8_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((gemm_rows_zre_kernel<8, ZRE8_NT>), grid, dim3(ZRE8_NT), lds, s, p, wtiles);
+        }
+        return 0;
+    }
 #define FD_GR(KS_, PRO_, EPI_) launch_rows<KS_, PRO_, EPI_>(p, nt, grid, lds, wtiles, RS, s)
 #define FD_GR_K(PRO_, EPI_)                            \
     switch (KS) {                                      \

@@ -102,6 +102,9 @@ class DAEngine:
         self.low_latency = bool(low_latency)
         self.scan_dt = self.dt | (L.FD_OPT_LOW_LATENCY if low_latency else 0)
         self.scan_fused = os.environ.get("FOUNDDIFF_SCAN_FUSED", "0") == "1"      # single-launch scan (opt-in, see mamba_block)
+        # z gate of SS2D recomputed inside out_proj instead of written by in_proj and read back (mamba_block); 0 = round-3 dataflow
+        # (development: 64 = only in the 64-channel blocks)
+        self.z_recompute = int(os.environ.get("FOUNDDIFF_Z_RECOMPUTE", "1"))
         self.dev = torch.device(device)
         self.f32 = dict(device=self.dev, dtype=torch.float32)
         sd = _Sub(state_dict, prefix)
@@ -308,7 +311,7 @@ class DAEngine:
              epi=L.EPI_NONE, split=0, res=None, ld_res=0, off_res=0, gate=None, gate_ld=0, h=None,
              gn=None, gamma=None, beta=None, groups=8, stats=None, OH=None, OW=None,
              prologue=L.PRO_NONE, ln_gamma=None, ln_beta=None, ln_eps=1e-5, ln_shift=None, ln_scale=None,
-             ln_ld=0, ln_z=None, ln_ldz=0, ln_offz=0, probe=False, fin=None):
+             ln_ld=0, ln_z=None, ln_ldz=0, ln_offz=0, probe=False, fin=None, zre=None):
         """One fd_conv2d launch.  `probe=True` only asks the library whether this conv can take the
         fused LayerNorm prologue (bf16 streaming row-GEMM path) and launches nothing; `probe="kid"`
         returns fd_conv_kernel_id (tests pin which kernel a shape exercises)."""
@@ -355,6 +358,9 @@ class DAEngine:
         p.ln_shift, p.ln_scale, p.ln_ld = ptr(ln_shift), ptr(ln_scale), ln_ld
         p.ln_z, p.ln_ldz, p.ln_offz = ptr(ln_z), ln_ldz, ln_offz
         p.f32_split = getattr(self, "f32_split", 0)
+        if zre is not None:      # PRO_LN_GATE_ZRE: z = SiLU(w . LNmod(res)) recomputed in the operand load
+            p.zre_w, p.zre_gamma, p.zre_beta = ptr(zre["w"]), ptr(zre.get("gamma")), ptr(zre.get("beta"))
+            p.zre_shift, p.zre_scale, p.zre_ld, p.zre_eps = ptr(zre["shift"]), ptr(zre["scale"]), zre["ld"], zre["eps"]
         if fin is not None:      # EPI_GNSILU_ADD_FINAL: final_conv (+ DDIM update) in the epilogue
             p.fin_w, p.fin_b, p.fin_out = fin["w"].data_ptr(), float(fin["b"]), fin["out"].data_ptr()
             p.fin_mode, p.fin_last = int(fin.get("mode", 0)), int(fin.get("last", 0))
@@ -418,12 +424,31 @@ class DAEngine:
                    ln_scale=mp(1), ln_ld=ml)
         xc = self._b("xc", (B, H, W, D))
         fused = bool(L.lib().fd_pw_dw3x3_ok(getattr(self, 'scan_dt', self.dt), Cc, D, D, H, W))      # (low latency: C = 128 unfused)
+        # out_proj's operands (decided here: whether in_proj has to write z at all depends on them)
+        y = self._b("scan_y", (B, H, W, D))
+        x1 = self._b(tag + ".x1", (B, H, W, Cc))
+        loc = C.c_void_p(self.local_all.data_ptr() + m["loc_off"] * f4)
+        ep1 = dict(epi=L.EPI_GATE_RES, res=x, gate=mp(2), gate_ld=ml)
+        lng = dict(prologue=L.PRO_LN_GATE, ln_gamma=m["onw"], ln_beta=m["onb"], ln_eps=1e-5, ln_shift=loc,
+                   ln_ld=self.loc_total, ln_z=xz, ln_ldz=2 * D, ln_offz=D)
+        # z recomputed inside out_proj from the block input it reads anyway as its residual (fd_gemm_rows.hip:
+        # gemm_rows_zre_kernel): the fused in_proj then writes the depthwise half only and z never exists in HBM
+        lngz = dict(prologue=L.PRO_LN_GATE_ZRE, ln_gamma=m["onw"], ln_beta=m["onb"], ln_eps=1e-5, ln_shift=loc,
+                    ln_ld=self.loc_total,
+                    zre=dict(w=C.c_void_p(m["in_proj"].w.data_ptr() + D * Cc * m["in_proj"].w.element_size()),
+                             gamma=m["n1w"], beta=m["n1b"], shift=mp(0), scale=mp(1), ld=ml, eps=1e-5))
+        xonly = dict(Cout=D, ldo=2 * D)                  # in_proj restricted to its x half (rows 0 .. D-1), z columns of xz untouched
+        zre = (getattr(self, "z_recompute", 0) in (1, Cc) and self.conv(m["out_proj"], y, B, H, W, x1, probe=True, **ep1, **lngz)
+               and (bool(L.lib().fd_pw_dw3x3_ok(getattr(self, 'scan_dt', self.dt), Cc, D, 0, H, W)) if fused else
+                    self.conv(m["in_proj"], x, B, H, W, xz, epi=L.EPI_SILU_SPLIT, split=D, probe=True, **ln1, **xonly)))
         if fused:
             # LN+modulate -> in_proj -> conv2d+SiLU (x half) / SiLU (z half) in one pass: the x half of
             # in_proj's output never exists in HBM (xz[..., :D] stays unwritten, z lands in xz[..., D:])
             L.call("fd_pw_dw3x3", self.dt, _p(x), Cc, 0, Cc, _p(m["n1w"]), _p(m["n1b"]), 1e-5, mp(0), mp(1), ml,
                    _p(m["in_proj"].w), D, _p(m["dw_wm"]), _p(m["dw_b"]), 1, _p(xc), D, 0,
-                   D, _p(xz), 2 * D, D, B, H, W, s)
+                   0 if zre else D, None if zre else _p(xz), 2 * D, D, B, H, W, s)
+        elif zre:
+            self.conv(m["in_proj"], x, B, H, W, xz, epi=L.EPI_SILU_SPLIT, split=D, **ln1, **xonly)
         elif self.conv(m["in_proj"], x, B, H, W, xz, epi=L.EPI_SILU_SPLIT, split=D, probe=True, **ln1):
             self.conv(m["in_proj"], x, B, H, W, xz, epi=L.EPI_SILU_SPLIT, split=D, **ln1)
         else:
@@ -435,7 +460,8 @@ class DAEngine:
             L.call("fd_dwconv3x3", self.dt, _p(xz), 2 * D, 0, _p(m["dw_w"]), _p(m["dw_b"]), 1, _p(xc), D, 0,
                    B, H, W, D, s)
         self._pr(tag + ".xc", xc)
-        self._pr(tag + ".z", xz[..., D:])
+        if not zre:
+            self._pr(tag + ".z", xz[..., D:])
         # odd H / W: the four sub-grids are those of the image zero-padded to even sizes (src/emamba2.py:191-199);
         # the x_proj gather zero-fills the positions outside the image, the scan treats them as padding
         H2, W2 = (H + 1) // 2, (W + 1) // 2
@@ -443,7 +469,6 @@ class DAEngine:
         xdbl = self._b("xdbl", (4, B, Lq, CD), torch.float32)
         nws = L.lib().fd_scan_ws_floats(B, H, W, D, N)
         ws = self._b("scan_ws", (nws,), torch.float32)
-        y = self._b("scan_y", (B, H, W, D))
         if getattr(self, 'scan_fused', False) and L.lib().fd_selective_scan_fused_ok(getattr(self, 'scan_dt', self.dt), D, N, R, H, W):
             # ONE launch: u tile in LDS, x_proj on MFMA, decays cached between the passes, in-launch carry tree
             # (fd_scan_fused.hip): x_dbl and the chunk states never reach HBM.  OPT-IN (FOUNDDIFF_SCAN_FUSED=1): correct
@@ -465,12 +490,9 @@ class DAEngine:
             L.call("fd_selective_scan", getattr(self, "scan_dt", self.dt), _p(xc), _p(xdbl), _p(m["dtw"]), _p(m["dtb"]), _p(m["A"]),
                    _p(m["Ds"]), _p(y), _p(ws), B, H, W, D, N, R, s)
         self._pr(tag + ".y", y)
-        loc = C.c_void_p(self.local_all.data_ptr() + m["loc_off"] * f4)
-        x1 = self._b(tag + ".x1", (B, H, W, Cc))
-        lng = dict(prologue=L.PRO_LN_GATE, ln_gamma=m["onw"], ln_beta=m["onb"], ln_eps=1e-5, ln_shift=loc,
-                   ln_ld=self.loc_total, ln_z=xz, ln_ldz=2 * D, ln_offz=D)
-        ep1 = dict(epi=L.EPI_GATE_RES, res=x, gate=mp(2), gate_ld=ml)
-        if self.conv(m["out_proj"], y, B, H, W, x1, probe=True, **ep1, **lng):
+        if zre:
+            self.conv(m["out_proj"], y, B, H, W, x1, **ep1, **lngz)
+        elif self.conv(m["out_proj"], y, B, H, W, x1, probe=True, **ep1, **lng):
             self.conv(m["out_proj"], y, B, H, W, x1, **ep1, **lng)
         else:
             yz = self._b("yz", (B, H, W, D))

@@ -122,6 +122,16 @@ typedef struct fd_conv_params {
     float *fin_img;                    /* [B][H*W] fp32 x_t, updated in place                 */
     const float *fin_xin;              /* [B][H*W] fp32 x_input                               */
     float fin_alpha;
+    /* FD_PRO_LN_GATE_ZRE (round 4): LN_GATE whose z operand is RECOMPUTED from the block input instead of read:
+     *   z[m] = SiLU(zre_w . (LN(res[m]) * gamma (1 + scale[b]) + beta (1 + scale[b]) + shift[b]))
+     * i.e. the z half of SS2D's in_proj (src/emamba2.py:716-719) applied to the adaLN-modulated norm1 of the Mamba
+     * block's input (src/DADiff.py:450-451, 477-481), which out_proj reads anyway as its residual (`res`, GATE_RES).
+     * z then never exists in HBM.  Needs Cin == 2 * Cout (d_inner = 2 * dim); ask fd_conv_prologue_ok().          */
+    const void *zre_w;                 /* [Cin][Cout] (dtype): rows d_inner .. 2 d_inner - 1 of in_proj.weight    */
+    const float *zre_gamma, *zre_beta; /* [Cout] norm1 affine or NULL                                             */
+    const float *zre_shift, *zre_scale;/* entries [b*zre_ld + c]                                                  */
+    int32_t zre_ld;
+    float zre_eps;
 } fd_conv_params;
 
 /* 1 if fd_conv2d would run `p` (weight_f8 / w_scale set) on the fp8 MFMA path.                        */
@@ -130,6 +140,7 @@ int fd_conv_fp8_ok(const fd_conv_params *p);
 #define FD_PRO_NONE 0
 #define FD_PRO_LN_MOD 1
 #define FD_PRO_LN_GATE 2
+#define FD_PRO_LN_GATE_ZRE 3
 /* 1 if this conv runs on the streaming row-GEMM kernel (1x1, bf16, Cin <= 256, >= 16384 pixels
  * per image, weights fit LDS) and may therefore carry a fused LN prologue.                    */
 int fd_conv_prologue_ok(const fd_conv_params *p);

@@ -571,6 +571,56 @@ def test_row_gemm_fused_prologues(eng_factory):
               gate=C.c_void_p(md.data_ptr() + 128 * 4), gate_ld=6 * 64, prologue=L.PRO_LN_GATE, ln_gamma=g2d,
               ln_beta=b2d, ln_eps=1e-5, ln_shift=locd, ln_ld=128, ln_z=xzd, ln_ldz=256, ln_offz=128)
     assert rel_err(got.reshape(B, hw, 64), ref) < 1.5e-2
+    # (2b) the same out_proj with the z gate RECOMPUTED from the residual operand (PRO_LN_GATE_ZRE): z = SiLU(W_z .
+    # LNmod(res)) rounded to bf16 as the fused in_proj stores it; against torch and against (2)'s kernel fed that z
+    wz = bf(torch.randn(128, 64) / 8)
+    xm2 = F.layer_norm(res, (64,), g, b_, 1e-5) * (1 + mod[:, None, 64:128]) + mod[:, None, 0:64]
+    zt = bf(F.silu(F.linear(bf(xm2), wz)))
+    ref = res + mod[:, None, 128:192] * F.linear(bf((F.layer_norm(y, (128,), g2, b2, 1e-5) * zt + loc[:, None])), w2)
+    wzd = wz.cuda().to(torch.bfloat16)
+    kwz = dict(epi=L.EPI_GATE_RES, res=resd, gate=C.c_void_p(md.data_ptr() + 128 * 4), gate_ld=6 * 64, ln_gamma=g2d,
+               ln_beta=b2d, ln_eps=1e-5, ln_shift=locd, ln_ld=128)
+    out = torch.empty(B, H, W, 64, device="cuda", dtype=torch.bfloat16)
+    got = run(ConvW(w2, None, e.dev, e.tdt), yd, out, prologue=L.PRO_LN_GATE_ZRE,
+              zre=dict(w=wzd, gamma=gd, beta=bd, shift=C.c_void_p(md.data_ptr()), scale=C.c_void_p(md.data_ptr() + 64 * 4),
+                       ld=6 * 64, eps=1e-5), **kwz)
+    assert rel_err(got.reshape(B, hw, 64), ref) < 1.5e-2
+    ztd = torch.zeros(B, hw, 256, dtype=torch.bfloat16, device="cuda")
+    ztd[..., 128:] = zt.cuda().to(torch.bfloat16)
+    out2 = torch.empty(B, H, W, 64, device="cuda", dtype=torch.bfloat16)
+    stored = run(ConvW(w2, None, e.dev, e.tdt), yd, out2, prologue=L.PRO_LN_GATE, ln_z=ztd, ln_ldz=256, ln_offz=128, **kwz)
+    assert rel_err(got, stored) < 4e-3            # same operands up to bf16 flips of LNmod(res) / z at rounding ties
+    # a ragged pixel count (H * W not a multiple of 16) and unaffine norm1
+    Hr, Wr = 127, 255
+    hwr = Hr * Wr
+    outr = torch.empty(B, Hr, Wr, 64, device="cuda", dtype=torch.bfloat16)
+    yr_, rr_ = yd.reshape(B, hw, 128)[:, :hwr].contiguous(), resd.reshape(B, hw, 64)[:, :hwr].contiguous()
+    kwr = dict(kwz, res=rr_)
+    assert e.conv(ConvW(w2, None, e.dev, e.tdt), yr_, B, Hr, Wr, outr, probe=True, prologue=L.PRO_LN_GATE_ZRE,
+                  zre=dict(w=wzd, shift=C.c_void_p(md.data_ptr()), scale=C.c_void_p(md.data_ptr() + 64 * 4), ld=6 * 64, eps=1e-5), **kwr)
+    e.conv(ConvW(w2, None, e.dev, e.tdt), yr_, B, Hr, Wr, outr, prologue=L.PRO_LN_GATE_ZRE,
+           zre=dict(w=wzd, shift=C.c_void_p(md.data_ptr()), scale=C.c_void_p(md.data_ptr() + 64 * 4), ld=6 * 64, eps=1e-5), **kwr)
+    torch.cuda.synchronize()
+    xm3 = F.layer_norm(res[:, :hwr], (64,), None, None, 1e-5) * (1 + mod[:, None, 64:128]) + mod[:, None, 0:64]
+    zt3 = bf(F.silu(F.linear(bf(xm3), wz)))
+    ref3 = res[:, :hwr] + mod[:, None, 128:192] * F.linear(bf((F.layer_norm(y[:, :hwr], (128,), g2, b2, 1e-5) * zt3 + loc[:, None])), w2)
+    assert rel_err(outr.float().cpu().reshape(B, hwr, 64), ref3) < 1.5e-2
+    # the K = 256 instance (the C = 128 blocks: d_inner 256)
+    y8, res8 = bf(torch.randn(B, hw, 256) * 2), bf(torch.randn(B, hw, 128))
+    w8, wz8 = bf(torch.randn(128, 256) / 16), bf(torch.randn(256, 128) / 11)
+    g8, b8, go8, bo8, loc8 = torch.randn(128), torch.randn(128), torch.randn(256), torch.randn(256), torch.randn(B, 256)
+    mod8 = torch.randn(B, 6 * 128) * 0.5
+    xm8 = F.layer_norm(res8, (128,), g8, b8, 1e-5) * (1 + mod8[:, None, 128:256]) + mod8[:, None, 0:128]
+    zt8 = bf(F.silu(F.linear(bf(xm8), wz8)))
+    ref8 = res8 + mod8[:, None, 256:384] * F.linear(bf((F.layer_norm(y8, (256,), go8, bo8, 1e-5) * zt8 + loc8[:, None])), w8)
+    m8d = mod8.cuda()
+    out8 = torch.empty(B, H, W, 128, device="cuda", dtype=torch.bfloat16)
+    got8 = run(ConvW(w8, None, e.dev, e.tdt), y8.cuda().to(torch.bfloat16), out8, prologue=L.PRO_LN_GATE_ZRE,
+               epi=L.EPI_GATE_RES, res=res8.cuda().to(torch.bfloat16), gate=C.c_void_p(m8d.data_ptr() + 256 * 4), gate_ld=6 * 128,
+               ln_gamma=go8.cuda(), ln_beta=bo8.cuda(), ln_eps=1e-5, ln_shift=loc8.cuda(), ln_ld=256,
+               zre=dict(w=wz8.cuda().to(torch.bfloat16), gamma=g8.cuda(), beta=b8.cuda(), shift=C.c_void_p(m8d.data_ptr()),
+                        scale=C.c_void_p(m8d.data_ptr() + 128 * 4), ld=6 * 128, eps=1e-5))
+    assert rel_err(got8.reshape(B, hw, 128), ref8) < 1.5e-2
     # (3) res_conv over a concat (128 + 64 -> 128) fused with GroupNorm+SiLU of the 3x3 output
     a, c = bf(torch.randn(B, hw, 128)), bf(torch.randn(B, hw, 64))
     w3, bias3 = bf(torch.randn(128, 192) / 14), torch.randn(128)

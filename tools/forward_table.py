@@ -39,7 +39,7 @@ for n, args in trace:
         q = args[0]._obj
         fl = bench.conv_flops(q)
         desc = (f"{KID.get(lib.fd_conv_kernel_id(args[0]), '?')}: {q.KH}x{q.KW} s{q.stride} {q.c0 + q.c1} -> {q.Cout} @ {q.OH}x{q.OW}"
-                f"{' x4 dirs' if q.ndir == 4 else ''} epi {q.epilogue} pro {q.prologue}")
+                f"{' x4 dirs' if q.ndir == 4 else ''} epi {q.epilogue} pro {q.prologue}{' (z recomputed)' if q.prologue == 3 else ''}")
     elif n in ("fd_selective_scan", "fd_selective_scan_xproj"):
         o = 1 if n.endswith("xproj") else 0
         Bq, H, W, D, N, R = args[9 + o:15 + o]
