@@ -69,6 +69,8 @@ SIGNATURES = {
     "fd_pw_dw3x3_gram_nblk": (i32, [i32, i32]),
     "fd_pw_dw3x3_gram_nblk_opts": (i32, [i32, i32, i32]),
     "fd_pw_dw3x3_gram": (i32, [i32, vp, i32, i32, i32, vp, vp, f32, vp, vp, i32, vp, vp, vp, i32, i32, vp, i32, i32, i32, vp]),
+    "fd_pw_dw3x3_proj_ok": (i32, [i32, i32, i32, i32]),
+    "fd_pw_dw3x3_proj": (i32, [i32, vp, i32, i32, i32, vp, vp, f32, vp, vp, i32, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp]),
     "fd_dwconv_gram_ok": (i32, [i32, i32, i32, i32]),
     "fd_dwconv_gram_nblk": (i32, [i32, i32]),
     "fd_dwconv_gram": (i32, [i32, vp, i32, i32, vp, vp, i32, i32, i32, vp]),

@@ -288,7 +288,7 @@ int row_stride(int K) { return K <= 64 ? 128 : (K <= 128 ? 256 : 512); }
 //   -> LN_GATE prologue on y with z from registers -> out_proj MFMAs -> x + gate . (acc + bias) with x from the
 //   registers the prologue loaded.  The matrix pipe of this HBM-bound kernel was 4 % busy; bytes per pixel fall from
 //   (K + K + CX + CX) x 2 to (K + CX + CX) x 2.
-template <int KS, int NT>
+template <int KS, int NT, bool PF>
 __global__ __launch_bounds__(NT) void gemm_rows_zre_kernel(const fd_conv_params p, int wtiles) {
     constexpr int NW = NT / 64, K = 32 * KS, KX = KS / 2, CX = 16 * KS;
     constexpr int RS = K <= 128 ? 256 : 512, RX = CX <= 64 ? 128 : 256;
@@ -329,13 +329,29 @@ __global__ __launch_bounds__(NT) void gemm_rows_zre_kernel(const fd_conv_params 
     bf16 *outp = (bf16 *)p.out + (int64_t)b * hw * p.ldo + p.offo;
     const int rperm = 8 * (fr >> 2) + (fr & 3);       // weight rows permuted so that a lane ends up with 8 consecutive channels
     const int wstride = gridDim.x * NW;
+    // K = 128: the next tile's rows are requested before this tile's arithmetic (a tile is ~550 VALU slots per lane here,
+    // against ~250 in gemm_rows_kernel, which leaves the overlap to its 3-4 waves per SIMD); K = 256 has no registers for it
+    u32x4 yn[PF ? KS : 1], xnx[PF ? KX : 1];
+    auto fetch = [&](int wt, u32x4 *yd, u32x4 *xd) {
+        const int64_t mm = min((int64_t)wt * 16 + fr, hw - 1);    // ragged last tile: rows beyond the image read the last row
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) yd[ks] = *(const u32x4 *)(yin + mm * p.ld0 + ks * 32 + fg * 8);
+#pragma unroll
+        for (int kx = 0; kx < KX; ++kx) xd[kx] = *(const u32x4 *)(xin + mm * p.ld_res + kx * 32 + fg * 8);
+    };
+    if (PF && blockIdx.x * NW + wave < wtiles) fetch(blockIdx.x * NW + wave, yn, xnx);
     for (int wt = blockIdx.x * NW + wave; wt < wtiles; wt += wstride) {
-        const int64_t m = min((int64_t)wt * 16 + fr, hw - 1);     // ragged last tile: rows beyond the image read the last row
+        const int64_t m = min((int64_t)wt * 16 + fr, hw - 1);
         u32x4 yr[KS], xr[KX];
+        if (PF) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) yr[ks] = *(const u32x4 *)(yin + m * p.ld0 + ks * 32 + fg * 8);
+            for (int ks = 0; ks < KS; ++ks) yr[ks] = yn[ks];
 #pragma unroll
-        for (int kx = 0; kx < KX; ++kx) xr[kx] = *(const u32x4 *)(xin + m * p.ld_res + kx * 32 + fg * 8);
+            for (int kx = 0; kx < KX; ++kx) xr[kx] = xnx[kx];
+            fetch(min(wt + wstride, wtiles - 1), yn, xnx);
+        } else {
+            fetch(wt, yr, xr);
+        }
         // the per-channel vectors of a lane do not depend on the tile; an opaque copy of fg keeps their (cheap) LDS reads
         // inside the loop instead of 5 x K/4 permanently live registers (see gemm_rows_kernel)
         int fgo = fg;
@@ -547,6 +563,7 @@ int fd_gemm_rows_launch(const fd_conv_params &p, hipStream_t s) {
     static const int pcmax = [] { const char *e = getenv("FD_ROWS_PER_CU_MAX"); return e ? atoi(e) : 0; }();    // development
     const int pclim = pcmax > 0 ? pcmax : (p.B >= 4 ? 3 : 4);
     if (per_cu > pclim) per_cu = pclim;
+    if (zre && per_cu > 3) per_cu = 3;       // 168 VGPRs with the next tile's rows in flight: 3 waves per SIMD
     if (per_cu < 1) per_cu = 1;
     int nt = per_cu >= 3 ? 256 : ((per_cu == 2 || !fits_768(KS, p.prologue)) ? 512 : 768);
     if (nt == 512 && !fits_512(KS, p.prologue)) nt = 256;
@@ -557,11 +574,13 @@ int fd_gemm_rows_launch(const fd_conv_params &p, hipStream_t s) {
     if (gx > need) gx = need;
     dim3 grid(gx, p.B);
     if (zre) {
-        if (K == 128) hipLaunchKernelGGL((gemm_rows_zre_kernel<4, 256>), grid, dim3(256), lds, s, p, wtiles);
+        static const bool nopf = getenv("FD_ZRE_NOPF") != nullptr;      // development
+        if (K == 128 && nopf) hipLaunchKernelGGL((gemm_rows_zre_kernel<4, 256, false>), grid, dim3(256), lds, s, p, wtiles);
+        else if (K == 128) hipLaunchKernelGGL((gemm_rows_zre_kernel<4, 256, true>), grid, dim3(256), lds, s, p, wtiles);
         else {
             // K = 256: 64 KB of out_proj + 64 KB of W_z rows -- one workgroup per CU, so its waves are the CU's waves
-            (void)hipFuncSetAttribute((const void *)gemm_rows_zre_kernel<8, ZRE8_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL((gemm_rows_zre_kernel<8, ZRE8_NT>), grid, dim3(ZRE8_NT), lds, s, p, wtiles);
+            (void)hipFuncSetAttribute((const void *)gemm_rows_zre_kernel<8, ZRE8_NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((gemm_rows_zre_kernel<8, ZRE8_NT, false>), grid, dim3(ZRE8_NT), lds, s, p, wtiles);
         }
         return 0;
     }

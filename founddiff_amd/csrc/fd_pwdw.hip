@@ -86,11 +86,21 @@ struct PwDwParams {
     int H, W;
     int tpw, ntiles;                  // consecutive tiles per workgroup (round 3: the tap weights / modulation vectors are
                                       // staged once per workgroup, the 1x1 weight prefetch runs across tiles)
+    // PROJ form (fd_pw_dw3x3_proj): a second 1x1 (64 -> 64, per-image weights) on the depthwise output + gated residual
+    const bf16 *w2; int64_t w2_bstride;
+    const float *gate; int gate_ld;
+    bf16 *out2; int ld_o2, off_o2;
 };
 
 // CIN = 64 (round 1: levels 0-1, three workgroups per CU) or 128 (round 3: the C = 128 blocks at 256x256; the halo tile
 // is 48 KB, rows of 256 bytes swizzled over their 16 chunks, K = 128 in four K32 steps; two workgroups per CU).
-template <int CIN>
+// PROJ (round 4, CIN = 64, Cdw = 64, no pass-through): the v branch of TransposedAttention up to the block output,
+//   x2 = x + gate . (Weff[b] . dwconv3x3(W_v . LNmod(x)))                       src/DADiff.py:266-285, 483-488
+// with Weff[b] = project_out . blockdiag(softmax(q k^T)) from fd_chan_attn_weff.  The Gram kernel then handles q and k only
+// and v never reaches HBM: the depthwise output goes as bf16 (the rounding point of the stored v) over the dead
+// LayerNorm'd halo tile, Weff[b] (8 KB) over that tile's unused rows 128..191, and the second 1x1 runs on it like the
+// row-GEMM (transposed issue, 8 consecutive channels per lane) with the residual re-read from L2.
+template <int CIN, bool PROJ = false>
 __global__ __launch_bounds__(256, CIN == 64 ? 3 : 2) void pwdw_kernel(const PwDwParams p) {
     constexpr int CH = CIN / 8, KS = CIN / 32, LCH = CIN == 64 ? 3 : 4;      // 16-byte chunks per pixel row, K32 steps
     __shared__ __attribute__((aligned(16))) unsigned char xs[PMT * 16 * CIN * 2];   // LN'd input halo, [192][CIN] bf16
@@ -138,6 +148,11 @@ __global__ __launch_bounds__(256, CIN == 64 ? 3 : 2) void pwdw_kernel(const PwDw
         }
     };
     wload(0);
+    u32x4 w2r[2] = {};                               // PROJ: this thread's two 16-byte pieces of Weff[img] ([64][64] bf16)
+    if constexpr (PROJ) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) w2r[k] = *(const u32x4 *)(p.w2 + img * p.w2_bstride + (tid + k * 256) * 8);
+    }
     lds_barrier();                                   // sV, sW
     const int tile0 = blockIdx.x * p.tpw;
     for (int tt = 0; tt < p.tpw; ++tt) {
@@ -272,6 +287,14 @@ __global__ __launch_bounds__(256, CIN == 64 ? 3 : 2) void pwdw_kernel(const PwDw
             }
         }
         lds_barrier();
+        if constexpr (PROJ) {
+            // xs is dead (this chunk's 1x1 was its last reader and every wave is past the barrier): Weff over its rows 128..191
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int idx = tid + k * 256;
+                *(u32x4 *)(xs + xs_off(128 + (idx >> 3), idx & 7)) = w2r[k];
+            }
+        }
         // phase 2: depthwise 3x3 on ts
         uint32_t win[3][3][4];
 #pragma unroll
@@ -294,10 +317,55 @@ __global__ __launch_bounds__(256, CIN == 64 ? 3 : 2) void pwdw_kernel(const PwDw
             float acc[8];
             unpack_h8(o2, acc);
             if (p.dw_silu) fd_silu8(acc);
-            const int y = ty0 + 4 * rh + rr, x = tx0 + px;
-            store8(dwout + (__umul24(__umul24(y, p.W) + x, p.ld_dw) + c0), acc);
+            if constexpr (PROJ) {
+                const u32x4 o = {fd_pack_bf16(f32x2{acc[0], acc[1]}), fd_pack_bf16(f32x2{acc[2], acc[3]}),
+                                 fd_pack_bf16(f32x2{acc[4], acc[5]}), fd_pack_bf16(f32x2{acc[6], acc[7]})};
+                *(u32x4 *)(xs + xs_off((4 * rh + rr) * PT_W + px, cv)) = o;       // [128 tile pixels][64 ch]
+            } else {
+                const int y = ty0 + 4 * rh + rr, x = tx0 + px;
+                store8(dwout + (__umul24(__umul24(y, p.W) + x, p.ld_dw) + c0), acc);
+            }
         }
         lds_barrier();                               // ts is rewritten by the next chunk (xs by the next tile)
+    }
+    if constexpr (PROJ) {
+        // ---- second 1x1 on the tile + gated residual: wave w owns tile rows 2w, 2w + 1 (16 pixels each)
+        bf16x8 vb[2][KS];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) vb[i][ks] = *(const bf16x8 *)(xs + xs_off((2 * wave + i) * PT_W + fr, ks * 4 + fg));
+        bf16 *o2 = p.out2 + img * p.H * p.W * p.ld_o2 + p.off_o2;
+#pragma unroll
+        for (int ng = 0; ng < 2; ++ng) {
+            bf16x8 wa[KS], wb[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                wa[ks] = *(const bf16x8 *)(xs + xs_off(128 + 32 * ng + rperm, ks * 4 + fg));
+                wb[ks] = *(const bf16x8 *)(xs + xs_off(128 + 32 * ng + rperm + 4, ks * 4 + fg));
+            }
+            const int n0 = 32 * ng + 8 * fg;
+            float gt[8];
+            load8(p.gate + img * p.gate_ld + n0, gt);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ks], vb[i][ks], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[ks], vb[i][ks], a1, 0, 0, 0);
+                }
+                const int y = ty0 + 2 * wave + i, x = tx0 + fr;
+                const int pix = __umul24(y, p.W) + x;
+                float rs[8];
+                load8(xin + (__umul24(pix, p.ld_x) + n0), rs);                     // the block input again (L2)
+                float val[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) val[e] = rs[e] + gt[e] * val[e];
+                store8(o2 + (__umul24(pix, p.ld_o2) + n0), val);
+            }
+        }
+        lds_barrier();                               // xs is rewritten by the next tile
     }
     }
 }
@@ -384,7 +452,9 @@ __global__ __launch_bounds__(256, 3) void pwdw_gram_kernel(const PwGramParams p)
     const int hd = wave >> 1, mb = wave & 1;
     const int tq = (lane >> 2) & 3, tp = lane & 3;
     f32x4 gacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, gnq = {0.f, 0.f, 0.f, 0.f}, gnk = {0.f, 0.f, 0.f, 0.f};
-    wload(0);
+    // out_v == NULL (round 4): q and k only -- v is recomputed by the kernel that consumes it (pwdw_kernel<64, PROJ>)
+    const int ci0 = p.out_v ? 0 : 1;
+    wload(2 * ci0);
     lds_barrier();                                   // sV, sW
 
     const int tile0 = blockIdx.x * p.tpw;
@@ -428,7 +498,7 @@ __global__ __launch_bounds__(256, 3) void pwdw_gram_kernel(const PwGramParams p)
 
         u32x4 pk[4];                                   // q, then k: this thread's 4 rows x 8 channels, bf16
 #pragma unroll 1
-        for (int ci = 0; ci < 3; ++ci) {
+        for (int ci = ci0; ci < 3; ++ci) {
             const int ch = ci == 0 ? 2 : ci - 1;       // v, q, k
             // phase 1: t[hp][64 ch] = W_chunk . xn, 3 m-tiles per wave
             bf16x8 xh[3][2];
@@ -441,7 +511,7 @@ __global__ __launch_bounds__(256, 3) void pwdw_gram_kernel(const PwGramParams p)
             for (int ng = 0; ng < 2; ++ng) {
                 const bf16x8 wa[2] = {wnext[0], wnext[1]}, wb[2] = {wnext[2], wnext[3]};
                 const int si = 2 * ci + ng + 1;
-                wload(si < 6 ? si : 0);                // after k: the next tile's first v group
+                wload(si < 6 ? si : 2 * ci0);          // after k: the next tile's first group
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
                     f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
@@ -755,7 +825,7 @@ extern "C" int fd_pw_dw3x3(int dtype, const void *x, int ld_x, int off_x, int Ci
     FD_REQUIRE(ld_x % 8 == 0 && off_x % 8 == 0 && ld_dw % 8 == 0 && off_dw % 8 == 0 && ld_z % 8 == 0 && off_z % 8 == 0,
                "fd_pw_dw3x3: strides / offsets must be multiples of 8 channels");
     FD_REQUIRE(((uintptr_t)w_dw & 15) == 0 && (!b_dw || ((uintptr_t)b_dw & 15) == 0), "fd_pw_dw3x3: weights must be 16-byte aligned");
-    PwDwParams p;
+    PwDwParams p = {};
     p.x = (const bf16 *)x; p.ld_x = ld_x; p.off_x = off_x;
     p.ln_gamma = ln_gamma; p.ln_beta = ln_beta; p.ln_shift = ln_shift; p.ln_scale = ln_scale; p.ln_ld = ln_ld; p.ln_eps = ln_eps;
     p.w_pw = (const bf16 *)w_pw;
@@ -773,6 +843,45 @@ extern "C" int fd_pw_dw3x3(int dtype, const void *x, int ld_x, int off_x, int Ci
     if (Cin == 64) hipLaunchKernelGGL(pwdw_kernel<64>, grid, block, pad, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(pwdw_kernel<128>, grid, block, pad, (hipStream_t)stream, p);
     FD_LAUNCH_OK("fd_pw_dw3x3");
+    return FD_OK;
+}
+
+// The v branch of the 64-channel TransposedAttention through project_out and the gated residual (pwdw_kernel<64, PROJ>):
+//   out = x + gate[b] . (w2[b] . dwconv3x3(w_pw . (LN(x) (1 + scale[b]) + shift[b])))
+// w_pw [64][64] (the v rows of qkv.weight), w_dw [9][32] fp16 channel pairs (the v taps of qkv_dwconv), w2 [B][64][64]
+// (fd_chan_attn_weff's output).  With fd_pw_dw3x3_gram(out_v = NULL) in front, v never reaches HBM.
+extern "C" int fd_pw_dw3x3_proj_ok(int dtype_opts, int Cin, int H, int W) {
+    static const bool off = getenv("FD_NO_PWDW_PROJ") != nullptr;      // development switch
+    return !off && Cin == 64 && fd_pw_dw3x3_ok(dtype_opts, Cin, 64, 0, H, W);
+}
+
+extern "C" int fd_pw_dw3x3_proj(int dtype, const void *x, int ld_x, int off_x, int Cin, const float *ln_gamma,
+                                const float *ln_beta, float ln_eps, const float *ln_shift, const float *ln_scale,
+                                int ln_ld, const void *w_pw, const uint32_t *w_dw, const void *w2, const float *gate,
+                                int gate_ld, void *out, int ld_o, int off_o, int B, int H, int W, void *stream) {
+    FD_REQUIRE(fd_pw_dw3x3_proj_ok(dtype, Cin, H, W),
+               "fd_pw_dw3x3_proj: unsupported shape (bf16, Cin=64, H%%8, W%%16, >= 32768 px): Cin=%d H=%d W=%d", Cin, H, W);
+    FD_REQUIRE(x && ln_shift && ln_scale && w_pw && w_dw && w2 && gate && out, "fd_pw_dw3x3_proj: null pointer");
+    FD_REQUIRE(ld_x % 8 == 0 && off_x % 8 == 0 && ld_o % 8 == 0 && off_o % 8 == 0,
+               "fd_pw_dw3x3_proj: strides / offsets must be multiples of 8 channels");
+    FD_REQUIRE(((uintptr_t)w_dw & 15) == 0 && ((uintptr_t)w2 & 15) == 0 && ((uintptr_t)gate & 15) == 0 && gate_ld % 4 == 0,
+               "fd_pw_dw3x3_proj: weights / gate must be 16-byte aligned");
+    PwDwParams p = {};
+    p.x = (const bf16 *)x; p.ld_x = ld_x; p.off_x = off_x;
+    p.ln_gamma = ln_gamma; p.ln_beta = ln_beta; p.ln_shift = ln_shift; p.ln_scale = ln_scale; p.ln_ld = ln_ld; p.ln_eps = ln_eps;
+    p.w_pw = (const bf16 *)w_pw;
+    p.Cdw = 64; p.w_dw = w_dw; p.b_dw = nullptr; p.dw_silu = 0;
+    p.Cz = 0;
+    p.w2 = (const bf16 *)w2; p.w2_bstride = 64 * 64; p.gate = gate; p.gate_ld = gate_ld;
+    p.out2 = (bf16 *)out; p.ld_o2 = ld_o; p.off_o2 = off_o;
+    p.H = H; p.W = W;
+    p.ntiles = (H / PT_H) * (W / PT_W);
+    static const int tpw_env = [] { const char *e = getenv("FD_PWDW_TPW"); return e ? atoi(e) : 0; }();
+    p.tpw = tpw_env > 0 ? tpw_env : (B >= 4 ? 4 : 1);
+    dim3 grid((p.ntiles + p.tpw - 1) / p.tpw, B), block(256);
+    static const size_t pad = fd_occ_pad("PWDW");
+    hipLaunchKernelGGL((pwdw_kernel<64, true>), grid, block, pad, (hipStream_t)stream, p);
+    FD_LAUNCH_OK("fd_pw_dw3x3_proj");
     return FD_OK;
 }
 
@@ -805,7 +914,7 @@ extern "C" int fd_pw_dw3x3_gram(int dtype, const void *x, int ld_x, int off_x, i
     dtype &= 0xff;
     FD_REQUIRE(fd_pw_dw3x3_ok(dtype, Cin, 192, 0, H, W),
                "fd_pw_dw3x3_gram: unsupported shape (bf16, Cin=64, H%%8, W%%16, >= 32768 px): Cin=%d H=%d W=%d", Cin, H, W);
-    FD_REQUIRE(x && ln_shift && ln_scale && w_pw && w_dw && out_v && partial, "fd_pw_dw3x3_gram: null pointer");
+    FD_REQUIRE(x && ln_shift && ln_scale && w_pw && w_dw && partial, "fd_pw_dw3x3_gram: null pointer");      // out_v may be NULL: q, k only
     FD_REQUIRE(ld_x % 8 == 0 && off_x % 8 == 0 && ld_v % 8 == 0 && off_v % 8 == 0,
                "fd_pw_dw3x3_gram: strides / offsets must be multiples of 8 channels");
     FD_REQUIRE(((uintptr_t)w_dw & 15) == 0, "fd_pw_dw3x3_gram: weights must be 16-byte aligned");

@@ -105,6 +105,8 @@ class DAEngine:
         # z gate of SS2D recomputed inside out_proj instead of written by in_proj and read back (mamba_block); 0 = round-3 dataflow
         # (development: 64 = only in the 64-channel blocks)
         self.z_recompute = int(os.environ.get("FOUNDDIFF_Z_RECOMPUTE", "1"))
+        # v of the 64-channel TransposedAttention recomputed inside the kernel that applies Weff (mamba_block); 0 = stored v
+        self.v_recompute = os.environ.get("FOUNDDIFF_V_RECOMPUTE", "1") == "1"
         self.dev = torch.device(device)
         self.f32 = dict(device=self.dev, dtype=torch.float32)
         sd = _Sub(state_dict, prefix)
@@ -196,6 +198,7 @@ class DAEngine:
         # tap weights of the two depthwise convs in the operand layout of the fused 1x1 -> 3x3 kernel
         d["dw_wm"], d["qdw_wm"] = self._dw_masked(d["dw_w"]), self._dw_masked(d["qdw_w"])
         d["qdw_w_v"] = d["qdw_w"][:, 2 * C_:].contiguous()          # the v third alone (fd_dwconv_gram serves q and k)
+        d["qdw_wm_v"] = self._dw_masked(d["qdw_w_v"])               # ... in the fused kernels' layout (fd_pw_dw3x3_proj)
         assert d["heads"] * 32 == C_, "TransposedAttention heads must be C/32 (src/DADiff.py:468)"
         d["adaln_w"] = s["adaLN_modulation.1.weight"].detach().float()
         d["adaln_b"] = s["adaLN_modulation.1.bias"].detach().float()
@@ -507,15 +510,25 @@ class DAEngine:
             # partial per workgroup do (fd_pwdw.hip: pwdw_gram_kernel)
             gdt = getattr(self, 'scan_dt', self.dt)          # carries FD_OPT_LOW_LATENCY: tiles per workgroup of the Gram kernel
             nblk = L.lib().fd_pw_dw3x3_gram_nblk_opts(gdt, H, W)
-            vbuf = self._b("attn_v", (B, H, W, Cc))
+            # v recomputed where it is consumed (fd_pw_dw3x3_proj: LN -> W_v -> depthwise -> Weff -> gated residual in one
+            # pass over x1): the Gram kernel then runs q and k only and v never reaches HBM
+            vre = getattr(self, "v_recompute", False) and bool(L.lib().fd_pw_dw3x3_proj_ok(gdt, Cc, H, W))
+            vbuf = None if vre else self._b("attn_v", (B, H, W, Cc))
             part = self._b("gram", (B, m["heads"], nblk, 1024 + 64), torch.float32)
             L.call("fd_pw_dw3x3_gram", gdt, _p(x1), Cc, 0, Cc, None, None, 1e-6, mp(3), mp(4), ml,
-                   _p(m["qkv"].w), _p(m["qdw_wm"]), _p(vbuf), Cc, 0, _p(part), B, H, W, s)
-            self._pr(tag + ".qkv2", vbuf)
+                   _p(m["qkv"].w), _p(m["qdw_wm"]), _p(vbuf) if vbuf is not None else None, Cc, 0, _p(part), B, H, W, s)
+            if not vre:
+                self._pr(tag + ".qkv2", vbuf)
             weff = self._b("weff", (B, Cc, Cc))
             L.call("fd_chan_attn_weff", self.dt, _p(part), nblk, _p(m["temp"]), _p(m["wproj"]), _p(weff), B, Cc, s)
             self._pr(tag + ".weff", weff)
             x2 = self._b(tag + ".x2", (B, H, W, Cc))
+            if vre:
+                wv = C.c_void_p(m["qkv"].w.data_ptr() + 2 * Cc * Cc * m["qkv"].w.element_size())
+                L.call("fd_pw_dw3x3_proj", gdt, _p(x1), Cc, 0, Cc, None, None, 1e-6, mp(3), mp(4), ml, wv, _p(m["qdw_wm_v"]),
+                       _p(weff), mp(5), ml, _p(x2), Cc, 0, B, H, W, s)
+                self._pr(tag, x2)
+                return x2
             self.conv(None, vbuf, B, H, W, x2, c0=Cc, ld0=Cc, off0=0, weight=weff, w_batch_stride=Cc * Cc,
                       bias=None, Cout=Cc, KH=1, KW=1, epi=L.EPI_GATE_RES, res=x1, gate=mp(5), gate_ld=ml)
             self._pr(tag, x2)

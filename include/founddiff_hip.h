@@ -217,6 +217,19 @@ int fd_pw_dw3x3_gram(int dtype, const void *x, int ld_x, int off_x, int Cin, con
                      const float *ln_beta, float ln_eps, const float *ln_shift, const float *ln_scale,
                      int ln_ld, const void *w_pw, const uint32_t *w_dw, void *out_v, int ld_v, int off_v,
                      float *partial, int B, int H, int W, void *stream);
+/* out_v may be NULL (round 4): q and k only, for use with fd_pw_dw3x3_proj below, which recomputes v where it is
+ * consumed.
+ *
+ * The v branch of the same attention through project_out and the block's gated residual (src/DADiff.py:266-285, 483-488):
+ *   out = x + gate[b] . (w2[b] . dwconv3x3(w_pw . (LN(x) (1 + scale[b]) + shift[b])))
+ * w_pw [64][64] (the v rows of qkv.weight), w_dw [9][32] fp16 channel pairs (the v taps of qkv_dwconv, fd_pw_dw3x3's
+ * layout), w2 [B][64][64] = fd_chan_attn_weff's output, gate entries [b*gate_ld + n].  bf16, Cin = 64; v never reaches
+ * HBM.  The depthwise output is rounded to bf16 before the second 1x1, as the stored v of the unfused sequence is.   */
+int fd_pw_dw3x3_proj_ok(int dtype_opts, int Cin, int H, int W);
+int fd_pw_dw3x3_proj(int dtype, const void *x, int ld_x, int off_x, int Cin, const float *ln_gamma,
+                     const float *ln_beta, float ln_eps, const float *ln_shift, const float *ln_scale,
+                     int ln_ld, const void *w_pw, const uint32_t *w_dw, const void *w2, const float *gate,
+                     int gate_ld, void *out, int ld_o, int off_o, int B, int H, int W, void *stream);
 
 /* ---- qkv_dwconv + L2 norms + q k^T for the wider blocks (C >= 128, src/DADiff.py:267-276): the depthwise 3x3 of the q
  * and k channels of a qkv tensor [B,H,W,ld] (q at channel 0, k at channel C) feeding the per-head Gram directly -- q and k

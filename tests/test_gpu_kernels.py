@@ -823,6 +823,28 @@ def test_pw_dw3x3_gram(eng_factory, hw):
            6 * Cin, wpd.data_ptr(), wm.data_ptr(), v.data_ptr(), 64 + 8, 8, part2.data_ptr(), B, H, W, s)
     torch.cuda.synchronize()
     assert torch.equal(part1, part2)
+    # q, k only (out_v = NULL): the same partials bit for bit; v recomputed inside the kernel that consumes it
+    # (fd_pw_dw3x3_proj: LN -> W_v -> depthwise -> Weff[b] -> x + gate . ()) against the row-GEMM on the STORED v
+    part3 = torch.empty_like(part1)
+    L.call("fd_pw_dw3x3_gram", L.FD_BF16, xd.data_ptr(), Cin, 0, Cin, None, None, 1e-6, md.data_ptr(), md.data_ptr() + Cin * 4,
+           6 * Cin, wpd.data_ptr(), wm.data_ptr(), None, 0, 0, part3.data_ptr(), B, H, W, s)
+    torch.cuda.synchronize()
+    assert torch.equal(part1, part3)
+    assert L.lib().fd_pw_dw3x3_proj_ok(L.FD_BF16, Cin, H, W)
+    e = eng_factory("bf16")
+    weff = (torch.randn(B, 64, 64) / 8).to(torch.bfloat16).cuda()
+    wm_v = DAEngine._dw_masked(wdw.reshape(192, 9)[128:].t().contiguous().cuda())
+    vs = v[..., 8:].contiguous()
+    ref = torch.empty(B, H, W, 64, device="cuda", dtype=torch.bfloat16)
+    e.conv(None, vs, B, H, W, ref, c0=64, ld0=64, off0=0, weight=weff, w_batch_stride=64 * 64, bias=None, Cout=64, KH=1, KW=1,
+           epi=L.EPI_GATE_RES, res=xd, gate=C.c_void_p(md.data_ptr() + 5 * Cin * 4), gate_ld=6 * Cin)
+    got = torch.full((B, H, W, 64 + 8), 7.0, device="cuda", dtype=torch.bfloat16)
+    L.call("fd_pw_dw3x3_proj", L.FD_BF16, xd.data_ptr(), Cin, 0, Cin, None, None, 1e-6, md.data_ptr(), md.data_ptr() + Cin * 4,
+           6 * Cin, wpd.data_ptr() + 128 * Cin * 2, wm_v.data_ptr(), weff.data_ptr(), md.data_ptr() + 5 * Cin * 4, 6 * Cin,
+           got.data_ptr(), 64 + 8, 8, B, H, W, s)
+    torch.cuda.synchronize()
+    assert float((got[..., :8].float() - 7.0).abs().max()) == 0.0
+    assert torch.equal(got[..., 8:], ref)          # same operands, same rounding points, same MFMA order
 
 
 @pytest.mark.parametrize("cfg", [(128, 64, 48), (256, 24, 32), (512, 8, 16)])

@@ -222,6 +222,26 @@ def bench_pwdw(B, sizes=((512, 512), (256, 256))):
         print(f"pwdw in_proj {H}x{W} B={B}: {t:8.1f} us  chk={float(xc.float().abs().mean()):.5f} {float(xz[..., 128:].float().abs().mean()):.5f}", flush=True)
 
 
+def bench_pwdwc(B, sizes=((512, 512),)):
+    """fused LN -> 1x1 -> depthwise at Cdw = 64 / 128 / 192 without pass-through channels: base and per-chunk cost"""
+    from founddiff_amd import _lib as L
+    from founddiff_amd.engine import DAEngine
+    s = torch.cuda.current_stream().cuda_stream
+    for H, W in sizes:
+        torch.manual_seed(0)
+        x = torch.randn(B, H, W, 64, device="cuda").to(torch.bfloat16)
+        mod = torch.randn(B, 384, device="cuda") * 0.5
+        for cdw in (64, 128, 192):
+            wpw = (torch.randn(cdw, 64, device="cuda") / 8).to(torch.bfloat16)
+            wm = DAEngine._dw_masked((torch.randn(cdw, 9, device="cuda") / 3).t().contiguous())
+            o = torch.empty(B, H, W, cdw, device="cuda", dtype=torch.bfloat16)
+
+            def run():
+                L.call("fd_pw_dw3x3", L.FD_BF16, x.data_ptr(), 64, 0, 64, None, None, 1e-6, mod.data_ptr(), mod.data_ptr() + 256,
+                       384, wpw.data_ptr(), cdw, wm.data_ptr(), None, 0, o.data_ptr(), cdw, 0, 0, None, 0, 0, B, H, W, s)
+            print(f"pwdw Cdw={cdw} Cz=0 {H}x{W} B={B}: {timeit(run):8.1f} us", flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("what")
