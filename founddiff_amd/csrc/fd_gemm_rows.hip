@@ -99,7 +99,9 @@ __global__ __launch_bounds__(NT) void gemm_rows_kernel(const fd_conv_params p, i
     };
 
     // No software prefetch: the kernel keeps its register footprint small enough for 3-4 waves
-    // per SIMD and lets the other waves' MFMA/store phases cover this wave's load latency.
+    // per SIMD and lets the other waves' MFMA/store phases cover this wave's load latency.  (Round 4: the next tile's
+    // rows requested one tile ahead in the no-prologue K >= 96 variants, 72-118 VGPRs: 12.65 -> 12.68 ms per batch-8
+    // forward, alternated -- not kept.)
     const int wstride = gridDim.x * NW;
     for (int wt = blockIdx.x * NW + wave; wt < wtiles; wt += wstride) {
         bf16x8 xb[S][KS];

@@ -852,14 +852,16 @@ extern "C" int fd_pw_dw3x3(int dtype, const void *x, int ld_x, int off_x, int Ci
 // (fd_chan_attn_weff's output).  With fd_pw_dw3x3_gram(out_v = NULL) in front, v never reaches HBM.
 extern "C" int fd_pw_dw3x3_proj_ok(int dtype_opts, int Cin, int H, int W) {
     static const bool off = getenv("FD_NO_PWDW_PROJ") != nullptr;      // development switch
-    return !off && Cin == 64 && fd_pw_dw3x3_ok(dtype_opts, Cin, 64, 0, H, W);
+    // (`dtype | FD_OPT_LOW_LATENCY`: for ONE slice the row-GEMM on the stored v is the shorter chain -- 151.7 against
+    //  152.7 ms per 50-step slice at batch 1; the throughput set gains 0.8 % per batch-8 forward with this kernel)
+    return !off && !(dtype_opts & FD_OPT_LOW_LATENCY) && Cin == 64 && fd_pw_dw3x3_ok(dtype_opts, Cin, 64, 0, H, W);
 }
 
 extern "C" int fd_pw_dw3x3_proj(int dtype, const void *x, int ld_x, int off_x, int Cin, const float *ln_gamma,
                                 const float *ln_beta, float ln_eps, const float *ln_shift, const float *ln_scale,
                                 int ln_ld, const void *w_pw, const uint32_t *w_dw, const void *w2, const float *gate,
                                 int gate_ld, void *out, int ld_o, int off_o, int B, int H, int W, void *stream) {
-    FD_REQUIRE(fd_pw_dw3x3_proj_ok(dtype, Cin, H, W),
+    FD_REQUIRE(fd_pw_dw3x3_proj_ok(dtype & 0xff, Cin, H, W),
                "fd_pw_dw3x3_proj: unsupported shape (bf16, Cin=64, H%%8, W%%16, >= 32768 px): Cin=%d H=%d W=%d", Cin, H, W);
     FD_REQUIRE(x && ln_shift && ln_scale && w_pw && w_dw && w2 && gate && out, "fd_pw_dw3x3_proj: null pointer");
     FD_REQUIRE(ld_x % 8 == 0 && off_x % 8 == 0 && ld_o % 8 == 0 && off_o % 8 == 0,
