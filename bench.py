@@ -123,9 +123,9 @@ def forward_bounds(eng, H, W, traffic, t_measured_ms):
 
 def roofline_leg(dif, x, noise, t_measured_ms=None, clock_replay=True):
     """Roofline of the dominant kernel symbol of one UNet forward -- the symbol with the largest total time, which is
-    also the top symbol of the rocprofv3 --stats summary of this command (profiles/).  Candidates: pwdw_kernel<64|128> and
-    pwdw_gram_kernel (fused LayerNorm+modulate -> 1x1 -> depthwise 3x3 [-> Gram] of the 64- / 128-channel Mamba blocks: HBM
-    roofline), the two instantiations of conv3x3_halo_kernel (MFMA roofline) and dwconv3x3_bf16_kernel (HBM).  Each is
+    also the top symbol of the rocprofv3 --stats summary of this command (profiles/).  Candidates: pwdw_kernel<64|128,false>, pwdw_kernel<64,true> and
+    pwdw_gram_kernel (fused LayerNorm+modulate -> 1x1 -> depthwise 3x3 [-> Gram | -> project_out] of the 64- / 128-channel Mamba
+    blocks: HBM roofline), gemm_rows_zre_kernel (out_proj with the z gate recomputed: HBM), the two instantiations of conv3x3_halo_kernel (MFMA roofline) and dwconv3x3_bf16_kernel (HBM).  Each is
     measured by replaying exactly its launches of one forward between HIP events on the launch stream; the largest
     becomes `roofline`, the rest `roofline.others`.  `forward`: the whole-forward bounds (forward_bounds)."""
     from founddiff_amd import _lib as L
@@ -166,13 +166,25 @@ def roofline_leg(dif, x, noise, t_measured_ms=None, clock_replay=True):
         pw = [(n, a) for n, a in trace if n == "fd_pw_dw3x3" and a[4] == cin]
         if pw:
             pw_bytes = sum(1.0 * a[23] * a[24] * a[25] * (a[4] + a[12] + a[19]) * esz for _, a in pw)   # in + dw out + z out, once
-            cands.append(hbm_entry("pwdw_kernel<%d>" % cin, pw, pw_bytes, "pwdw%d_hbm_bytes_per_launch" % cin))
+            cands.append(hbm_entry("pwdw_kernel<%d,false>" % cin, pw, pw_bytes, "pwdw%d_hbm_bytes_per_launch" % cin))
+    # the v branch of the channel attention through project_out (pwdw_kernel<64,true>): args = (dtype, x, ld_x, off_x, Cin, gamma,
+    #      beta, eps, shift, scale, ln_ld, w_pw, w_dw, w2, gate, gate_ld, out, ld_o, off_o, B, H, W, stream): 64 channels in, 64 out
+    pj = [(n, a) for n, a in trace if n == "fd_pw_dw3x3_proj"]
+    if pj:
+        pj_bytes = sum(1.0 * a[19] * a[20] * a[21] * (64 + 64) * esz for _, a in pj)
+        cands.append(hbm_entry("pwdw_kernel<64,true>", pj, pj_bytes, "pwdw_proj_hbm_bytes_per_launch"))
+    # out_proj with the z gate recomputed (gemm_rows_zre_kernel): y (K) + block input (Cout) in, Cout out, once
+    zr = [(n, a) for n, a in trace if n == "fd_conv2d" and a[0]._obj.prologue == 3]
+    if zr:
+        zr_bytes = sum(1.0 * a[0]._obj.B * a[0]._obj.H * a[0]._obj.W * (a[0]._obj.c0 + 2 * a[0]._obj.Cout) * esz for _, a in zr)
+        cands.append(hbm_entry("gemm_rows_zre_kernel", zr, zr_bytes, "gemm_rows_zre_hbm_bytes_per_launch"))
     # ... with the Gram: args = (dtype, x, ld_x, off_x, Cin, gamma, beta, eps, shift, scale, ln_ld, w_pw, w_dw, out_v, ld_v,
     #      off_v, partial, B, H, W, stream): reads 64 channels, writes v (64 channels) + one Gram partial per workgroup
     pg = [(n, a) for n, a in trace if n == "fd_pw_dw3x3_gram"]
     if pg:
-        pg_bytes = sum(1.0 * a[17] * a[18] * a[19] * (64 + 64) * esz + 1.0 * a[17] * 2 * lib.fd_pw_dw3x3_gram_nblk_opts(a[0], a[18], a[19]) * 1088 * 4
-                       for _, a in pg)
+        has_v = lambda a: bool(getattr(a[13], "value", a[13]))        # out_v == NULL: q, k only (v recomputed by fd_pw_dw3x3_proj)
+        pg_bytes = sum(1.0 * a[17] * a[18] * a[19] * (64 + (64 if has_v(a) else 0)) * esz
+                       + 1.0 * a[17] * 2 * lib.fd_pw_dw3x3_gram_nblk_opts(a[0], a[18], a[19]) * 1088 * 4 for _, a in pg)
         cands.append(hbm_entry("pwdw_gram_kernel", pg, pg_bytes, "pwdw_gram_hbm_bytes_per_launch"))
     # the two instantiations of the halo 3x3 kernel separately (separate symbols in the rocprof summary: <128,8> serves
     # Cout > 64, <64,16> / <64,8> Cout <= 64)

@@ -54,8 +54,13 @@ for n, args in trace:
             desc = f"LN -> 1x1 {Cin} -> {Cdw}+{Cz} -> dw3x3 @ {H}x{W}"
         else:
             H, W = args[18], args[19]
-            fl = 2.0 * B * H * W * 64 * 192 + 2.0 * B * H * W * 192 * 9 + 2.0 * B * H * W * 64 * 32
-            desc = f"LN -> qkv 64 -> 192 -> dw3x3 -> Gram @ {H}x{W}"
+            nch = 192 if getattr(args[13], "value", args[13]) else 128       # out_v == NULL: q, k only
+            fl = 2.0 * B * H * W * 64 * nch + 2.0 * B * H * W * nch * 9 + 2.0 * B * H * W * 64 * 32
+            desc = f"LN -> {'qkv' if nch == 192 else 'qk'} 64 -> {nch} -> dw3x3 -> Gram @ {H}x{W}"
+    elif n == "fd_pw_dw3x3_proj":
+        H, W = args[20], args[21]
+        fl = 2.0 * B * H * W * 64 * 64 * 2 + 2.0 * B * H * W * 64 * 9
+        desc = f"LN -> v 64 -> 64 -> dw3x3 -> Weff 64 -> 64 -> gated residual @ {H}x{W}"
     rows.append((n, desc, ms, fl))
     tot_ms += ms
     tot_fl += fl

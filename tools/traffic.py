@@ -48,8 +48,10 @@ res = {"note": __doc__.strip(),
        "total_hbm_bytes_per_forward": round(sum(v["hbm_bytes_per_launch"] * v["n"] for v in per.values()) / nfwd),
        "pwdw_gram_hbm_bytes_per_launch": fam("pwdw_gram_kernel"),
        "pwdw_hbm_bytes_per_launch": fam("pwdw_kernel"),
-       "pwdw64_hbm_bytes_per_launch": fam("pwdw_kernel<64>"),
-       "pwdw128_hbm_bytes_per_launch": fam("pwdw_kernel<128>"),
+       "pwdw64_hbm_bytes_per_launch": fam("pwdw_kernel<64, false>"),
+       "pwdw128_hbm_bytes_per_launch": fam("pwdw_kernel<128, false>"),
+       "pwdw_proj_hbm_bytes_per_launch": fam("pwdw_kernel<64, true>"),
+       "gemm_rows_zre_hbm_bytes_per_launch": fam("gemm_rows_zre_kernel"),
        "dwconv3x3_bf16_hbm_bytes_per_launch": fam("dwconv3x3_bf16_kernel"),
        "conv3x3_halo_hbm_bytes_per_launch": fam("conv3x3_halo_kernel"),
        "per_kernel": per}
