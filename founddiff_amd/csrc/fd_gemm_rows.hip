@@ -290,8 +290,12 @@ int row_stride(int K) { return K <= 64 ? 128 : (K <= 128 ? 256 : 512); }
 //   -> LN_GATE prologue on y with z from registers -> out_proj MFMAs -> x + gate . (acc + bias) with x from the
 //   registers the prologue loaded.  The matrix pipe of this HBM-bound kernel was 4 % busy; bytes per pixel fall from
 //   (K + K + CX + CX) x 2 to (K + CX + CX) x 2.
+__device__ __forceinline__ float zre_dot2(uint32_t a, uint32_t b, float c) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b), c, false);
+}
+
 template <int KS, int NT, bool PF>
-__global__ __launch_bounds__(NT) void gemm_rows_zre_kernel(const fd_conv_params p, int wtiles) {
+__global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void gemm_rows_zre_kernel(const fd_conv_params p, int wtiles) {
     constexpr int NW = NT / 64, K = 32 * KS, KX = KS / 2, CX = 16 * KS;
     constexpr int RS = K <= 128 ? 256 : 512, RX = CX <= 64 ? 128 : 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -361,18 +365,18 @@ __global__ __launch_bounds__(NT) void gemm_rows_zre_kernel(const fd_conv_params 
         // ---- z = SiLU(W_z . LNmod(x)): a pixel's CX channels sit in the 4 lanes fr, fr + 16, fr + 32, fr + 48
         u32x4 zb[KS];
         {
-            f32x2 s = {0.f, 0.f}, q = {0.f, 0.f};
+            // sum and sum of squares straight from the packed pairs: v_dot2_f32_bf16 against (1, 1) and against itself
+            // (exact products, fp32 accumulation) -- no unpack for the statistics
+            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int kx = 0; kx < KX; ++kx) {
                 const uint32_t rw[4] = {xr[kx].x, xr[kx].y, xr[kx].z, xr[kx].w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const f32x2 v = fd_unpack_bf16(rw[j]);
-                    s += v;
-                    q = v * v + q;
+                    s1 = zre_dot2(rw[j], 0x3F803F80u, s1);
+                    s2 = zre_dot2(rw[j], rw[j], s2);
                 }
             }
-            float s1 = s.x + s.y, s2 = q.x + q.y;
             s1 += __shfl_xor(s1, 16, 64);
             s2 += __shfl_xor(s2, 16, 64);
             s1 += __shfl_xor(s1, 32, 64);
@@ -409,34 +413,26 @@ __global__ __launch_bounds__(NT) void gemm_rows_zre_kernel(const fd_conv_params 
                                  fd_pack_bf16(f32x2{val[4], val[5]}), fd_pack_bf16(f32x2{val[6], val[7]})};
             }
         }
-        // ---- out_norm(y) * z + local (two-pass statistics: the arithmetic of the LN_GATE prologue)
+        // ---- out_norm(y) * z + local (one-pass statistics like the x row's)
         bf16x8 xb[KS];
         {
-            f32x2 s = {0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const uint32_t rw[4] = {yr[ks].x, yr[ks].y, yr[ks].z, yr[ks].w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) s += fd_unpack_bf16(rw[j]);
-            }
-            float s1 = s.x + s.y;
-            s1 += __shfl_xor(s1, 16, 64);
-            s1 += __shfl_xor(s1, 32, 64);
-            const float mean = s1 * (1.f / K);
-            f32x2 q = {0.f, 0.f};
+            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const uint32_t rw[4] = {yr[ks].x, yr[ks].y, yr[ks].z, yr[ks].w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const f32x2 d = fd_unpack_bf16(rw[j]) - mean;
-                    q = d * d + q;
+                    s1 = zre_dot2(rw[j], 0x3F803F80u, s1);
+                    s2 = zre_dot2(rw[j], rw[j], s2);
                 }
             }
-            float s2 = q.x + q.y;
+            s1 += __shfl_xor(s1, 16, 64);
             s2 += __shfl_xor(s2, 16, 64);
+            s1 += __shfl_xor(s1, 32, 64);
             s2 += __shfl_xor(s2, 32, 64);
-            const float rstd = rsqrtf(s2 * (1.f / K) + p.ln_eps);
+            const float mean = s1 * (1.f / K);
+            const float var = fmaxf(s2 * (1.f / K) - mean * mean, 0.f);
+            const float rstd = __builtin_amdgcn_rsqf(var + p.ln_eps), nm = -mean * rstd;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const int c = ks * 32 + fgo * 8;
@@ -445,7 +441,7 @@ __global__ __launch_bounds__(NT) void gemm_rows_zre_kernel(const fd_conv_params 
                 uint32_t o[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const f32x2 t = (fd_unpack_bf16(rw[j]) - mean) * rstd;
+                    const f32x2 t = fd_unpack_bf16(rw[j]) * rstd + nm;
                     const f32x2 u = t * *(const f32x2 *)&sV[c + 2 * j] + *(const f32x2 *)&sV[K + c + 2 * j];
                     o[j] = fd_pack_bf16(u * fd_unpack_bf16(zw[j]) + *(const f32x2 *)&sV[2 * K + c + 2 * j]);
                 }
