@@ -349,6 +349,11 @@ class ResidualDiffusion(nn.Module):
         self.final_outer_levels = int(os.environ.get("FOUNDDIFF_FINAL_OUTER_LEVELS", "2"))
         # how many of those levels also run their DOWN stage on the tail engine (default: all of them)
         self.final_down_levels = int(os.environ.get("FOUNDDIFF_FINAL_DOWN_LEVELS", "-1"))
+        # adaLN vectors of all DDIM steps in one pass in front of the captured loop (DAEngine.time_cond_table) instead of six
+        # small launches per step: "auto" = with the one-slice kernel set only (151.4 -> 149.8 ms per 50-step slice at batch 1;
+        # in the two-stream throughput mode the small launches of one stream hide under the other's kernels and the table
+        # measured -0.3 %: 13.27 vs 13.21 slices/s, alternated); 1 / 0 force it on / off.  Bit for bit the same vectors.
+        self._time_table = os.environ.get("FOUNDDIFF_TIME_TABLE", "auto")
         for k, v in residual_schedule(timesteps, after_init=False).items():
             self.register_buffer(k, v)
         self._host_sched = None
@@ -768,6 +773,12 @@ class ResidualDiffusion(nn.Module):
             gt.replay()
         self._anc_steps_run = rem + reps * G + K
 
+    @property
+    def time_table(self):
+        if self._time_table in ("0", "1"):
+            return self._time_table == "1"
+        return bool(getattr(self._eng(), "low_latency", False))
+
     @torch.no_grad()
     def ddim_sample(self, x_input, shape, last=True, noise=None):
         """src/DADiff.py:1276-1365 (eta = 0, type 'use_pred_noise')."""
@@ -796,11 +807,18 @@ class ResidualDiffusion(nn.Module):
 
         def run_steps(forward, fold=False):
             """fold: the forward applies the DDIM update itself (DAEngine.forward sched=: in the bf16 mode inside the
-            epilogue of its last kernel), with the step's constants baked into the captured loop graph."""
+            epilogue of its last kernel), with the step's constants baked into the captured loop graph; the adaLN vectors
+            of all steps come from ONE pass in front of the loop (DAEngine.time_cond_table) instead of six small launches
+            per step."""
+            if fold and self.time_table:
+                eng.time_cond_table()
             for i, (time, time_next) in enumerate(time_pairs):
-                time_buf.fill_(float(acs[time] * T))
                 lastf = time_next < 0
                 alpha = 0.0 if lastf else float(acs[time] - acs[time_next])
+                if fold and self.time_table and i < S - K:
+                    forward(eng, (alpha, lastf), i)
+                    continue
+                time_buf.fill_(float(acs[time] * T))
                 if fold:
                     forward(e32 if i >= S - K else eng, (alpha, lastf))
                     continue
@@ -813,16 +831,20 @@ class ResidualDiffusion(nn.Module):
         if self.use_graph and last and os.environ.get("FOUNDDIFF_LOOP_GRAPH", "1") != "0":
             # the whole S-step loop as ONE HIP graph (S x (time fill + 141 kernels + DDIM update), every
             # scheduler constant baked into its node): replayed per sample() on the persistent loop buffers
-            key = ("ddim", tuple(shape), eng.mode, eng.gen, S, T, K, e32.gen if e32 else 0, self.final_outer_levels, self.final_down_levels)
+            key = ("ddim", tuple(shape), eng.mode, eng.gen, S, T, K, e32.gen if e32 else 0, self.final_outer_levels, self.final_down_levels,
+                   self.time_table)
 
-            def fwd(e, sched=None):
+            def fwd(e, sched=None, step=None):
                 if e is eng:
-                    e.forward(img, x_in, time_buf, out=mo, sched=sched)
+                    e.forward(img, x_in, time_buf, out=mo, sched=sched, step=step)
                 else:
                     self._tail_forward(e, eng, img, x_in, time_buf, mo, sched=sched)
             loops = eng.loop_graphs
             if key not in loops:
                 start = img.clone()
+                if self.time_table:                                # (host -> device copy and buffers: before the capture)
+                    eng.time_table_prepare([acs[t] * T for t, _ in time_pairs], shape[0])
+                    eng.time_cond_table()
                 for e in (eng, e32):
                     if e is not None:
                         fwd(e)                                    # warm-up: every workspace buffer exists

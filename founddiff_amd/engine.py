@@ -678,7 +678,37 @@ class DAEngine:
         self.mod_all = self.linear(tt, self.adaln_w, self.adaln_b,
                                    self._b("mod_all", (B, self.mod_total), torch.float32), pre_silu=True)
 
-    def forward(self, x_t, x_in, time, out=None, x_cond2=None, sched=None):
+    def time_table_prepare(self, times, B):
+        """Device vector of the loop's step times, every time repeated for the B slices (rows s * B + b).  A host -> device
+        copy: call it BEFORE a graph capture; time_cond_table() then only launches kernels."""
+        S = len(times)
+        tv = self._b(f"tab_time_{S}x{B}", (S * B,), torch.float32)
+        tv.copy_(torch.tensor([float(t) for t in times], dtype=torch.float32).repeat_interleave(B))
+        self._tab_S, self._tab_B = S, B
+        return tv
+
+    def time_cond_table(self):
+        """The adaLN vectors of ALL steps of a sampling loop in one pass: the step times are known before the loop starts
+        (src/DADiff.py:1276-1300), so the six launches of time_cond per step -- sinusoidal, two linears, + prompt, the adaLN
+        linear; ~75 us of latency-bound work in front of every forward -- become five launches per LOOP on S * B rows.
+        Every row is computed by itself (fd_linear: one wave per output feature, rows in turn): bit for bit the vectors
+        time_cond produces.  forward(..., step=s) takes its vectors from the table."""
+        S, B = self._tab_S, self._tab_B
+        assert self.prompt_emb.shape[0] == B
+        M = S * B
+        s = self.stream
+        tv = self._b(f"tab_time_{S}x{B}", (M,), torch.float32)
+        emb = self._b("tab_emb", (M, self.dim), torch.float32)
+        L.call("fd_sinusoidal", _p(tv), _p(emb), M, self.dim, s)
+        tm = self.tm
+        h = self.linear(emb, tm["w1"], tm["b1"], self._b("tab_h", (M, self.time_dim), torch.float32), L.ACT_GELU)
+        t = self.linear(h, tm["w2"], tm["b2"], self._b("tab_t", (M, self.time_dim), torch.float32))
+        tt = self._b("tab_sum", (M, self.time_dim), torch.float32)
+        torch.add(t.view(S, B, self.time_dim), self.prompt_emb[None], out=tt.view(S, B, self.time_dim))
+        self.mod_tab = self.linear(tt, self.adaln_w, self.adaln_b, self._b("mod_tab", (M, self.mod_total), torch.float32),
+                                   pre_silu=True)
+
+    def forward(self, x_t, x_in, time, out=None, x_cond2=None, sched=None, step=None):
         """x_t, x_in: (B,1,H,W) fp32 device tensors in [-1,1]; time (B,) fp32.  Returns the raw
         model output (B,1,H,W) fp32.  encode_condition(x_in) must have been called.  x_cond2: the
         third input plane of an input_condition model (src/DADiff.py:1157-1158).  `sched` = (alpha, last): also
@@ -692,7 +722,10 @@ class DAEngine:
         div = 2 ** sum(1 for d in self.downs if d["stride"] == 2)
         if H % div or W % div:       # what the reference's own down / up-sampling needs (skip shapes must match)
             raise ValueError(f"H,W must be multiples of {div} (got {H}x{W})")
-        self.time_cond(time)
+        if step is None:
+            self.time_cond(time)
+        else:                                   # vectors of loop step `step` from time_cond_table()
+            self.mod_all = self.mod_tab[step * B:(step + 1) * B]
         r = self._head(x_t, x_in, x_cond2)
         x, h, w = r, H, W
         self._skips = []

@@ -212,6 +212,13 @@ def test_ddim_tiny_bf16_drift(golden):
     assert torch.equal(out, again)
     eager = dif.sample([g["x_input"].cuda()], batch_size=2, last=False, noise=g["ddim.noise0"].cuda())[-1].cpu()
     assert torch.equal(out, eager)                     # whole-loop graph == per-step graphs, both engines
+    # adaLN vectors of all steps from ONE pass in front of the loop (DAEngine.time_cond_table; the default of the one-slice
+    # kernel set): bit for bit the per-step vectors
+    assert dif.time_table is False
+    dif._time_table = "1"
+    tab = dif.sample([g["x_input"].cuda()], batch_size=2, last=True, noise=g["ddim.noise0"].cuda())[-1].cpu()
+    dif._time_table = "auto"
+    assert torch.equal(out, tab)
     dif.final_fp32_steps = 0
     pure = dif.sample([g["x_input"].cuda()], batch_size=2, last=True, noise=g["ddim.noise0"].cuda())[-1].cpu()
     assert l2rel(pure, ref) < 2e-2 and psnr(pure, ref) > 40.0
