@@ -125,7 +125,7 @@ def roofline_leg(dif, x, noise, t_measured_ms=None, clock_replay=True):
     """Roofline of the dominant kernel symbol of one UNet forward -- the symbol with the largest total time, which is
     also the top symbol of the rocprofv3 --stats summary of this command (profiles/).  Candidates: pwdw_kernel<64|128,false>, pwdw_kernel<64,true> and
     pwdw_gram_kernel (fused LayerNorm+modulate -> 1x1 -> depthwise 3x3 [-> Gram | -> project_out] of the 64- / 128-channel Mamba
-    blocks: HBM roofline), gemm_rows_zre_kernel (out_proj with the z gate recomputed: HBM), the two instantiations of conv3x3_halo_kernel (MFMA roofline) and dwconv3x3_bf16_kernel (HBM).  Each is
+    blocks: HBM roofline), gemm_rows_zre_kernel (out_proj with the z gate recomputed: HBM), down_fused_kernel (GroupNorm apply + 4x4 / stride-2 convolution: HBM), the two instantiations of conv3x3_halo_kernel (MFMA roofline) and dwconv3x3_bf16_kernel (HBM).  Each is
     measured by replaying exactly its launches of one forward between HIP events on the launch stream; the largest
     becomes `roofline`, the rest `roofline.others`.  `forward`: the whole-forward bounds (forward_bounds)."""
     from founddiff_amd import _lib as L
@@ -173,6 +173,12 @@ def roofline_leg(dif, x, noise, t_measured_ms=None, clock_replay=True):
     if pj:
         pj_bytes = sum(1.0 * a[19] * a[20] * a[21] * (64 + 64) * esz for _, a in pj)
         cands.append(hbm_entry("pwdw_kernel<64,true>", pj, pj_bytes, "pwdw_proj_hbm_bytes_per_launch"))
+    # GroupNorm apply + 4x4 / stride-2 convolution in one pass (down_fused_kernel): args = (dtype, h, x, mean_rstd, gamma, beta,
+    #      groups, skip, w, bias, out, B, H, W, C, Cout, stream): h and x in, skip and the down-sampled tensor out, once
+    dn = [(n, a) for n, a in trace if n == "fd_gn_apply_down4x4"]
+    if dn:
+        dn_bytes = sum(1.0 * a[11] * a[12] * a[13] * (3 * a[14] + a[15] / 4.0) * esz for _, a in dn)
+        cands.append(hbm_entry("down_fused_kernel", dn, dn_bytes, "down_fused_hbm_bytes_per_launch"))
     # out_proj with the z gate recomputed (gemm_rows_zre_kernel): y (K) + block input (Cout) in, Cout out, once
     zr = [(n, a) for n, a in trace if n == "fd_conv2d" and a[0]._obj.prologue == 3]
     if zr:

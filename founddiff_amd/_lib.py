@@ -59,6 +59,8 @@ SIGNATURES = {
     "fd_conv_fp8_ok": (i32, [C.POINTER(ConvParams)]),
     "fd_gn_finalize": (i32, [vp, i32, i32, i32, i32, i64, f32, vp, vp]),
     "fd_gn_silu_apply": (i32, [i32, vp, vp, vp, vp, vp, vp, i32, i64, i32, i32, vp]),
+    "fd_gn_apply_down4x4_ok": (i32, [i32, i32, i32, i32, i32]),
+    "fd_gn_apply_down4x4": (i32, [i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "fd_ln_modulate": (i32, [i32, vp, vp, vp, f32, vp, vp, i32, vp, i32, i64, i32, vp]),
     "fd_ln_gate": (i32, [i32, vp, vp, vp, f32, vp, i32, i32, vp, i32, vp, i32, i64, i32, vp]),
     "fd_dwconv3x3": (i32, [i32, vp, i32, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]),

@@ -107,6 +107,8 @@ class DAEngine:
         self.z_recompute = int(os.environ.get("FOUNDDIFF_Z_RECOMPUTE", "1"))
         # v of the 64-channel TransposedAttention recomputed inside the kernel that applies Weff (mamba_block); 0 = stored v
         self.v_recompute = os.environ.get("FOUNDDIFF_V_RECOMPUTE", "1") == "1"
+        # GroupNorm apply of the down-path blocks fused with the 4x4 / stride-2 convolution behind them (_down); 0 = two passes
+        self.down_fuse = os.environ.get("FOUNDDIFF_DOWN_FUSE", "1") == "1"
         self.dev = torch.device(device)
         self.f32 = dict(device=self.dev, dtype=torch.float32)
         sd = _Sub(state_dict, prefix)
@@ -386,8 +388,10 @@ class DAEngine:
         return out
 
     # ------------------------------------------------------------------ blocks
-    def res_block(self, r, in0, c0, in1, c1, B, H, W, tag):
-        """DADiff ResnetBlock: conv3x3(WS)+GN+SiLU, + res_conv(x) or x (src/DADiff.py:397-430)."""
+    def res_block(self, r, in0, c0, in1, c1, B, H, W, tag, defer_apply=False):
+        """DADiff ResnetBlock: conv3x3(WS)+GN+SiLU, + res_conv(x) or x (src/DADiff.py:397-430).  defer_apply (identity
+        residual only): stop after the GroupNorm statistics and return (h, mean_rstd, out buffer) -- the caller fuses the
+        apply pass into its consumer (_down: fd_gn_apply_down4x4)."""
         cw = r["conv"]
         Co = cw.Cout
         hw = H * W
@@ -399,6 +403,9 @@ class DAEngine:
         self._pr(tag + ".conv3", hraw)
         L.call("fd_gn_finalize", _p(part), B, mt, Co, 8, hw, 1e-5, _p(mr), self.stream)
         out = self._b(tag, (B, H, W, Co))
+        if defer_apply:
+            assert r["res"] is None and in1 is None
+            return hraw, mr, out
         if r["res"] is not None:
             self.conv(r["res"], in0, B, H, W, out, c0=c0, in1=in1, c1=c1, epi=L.EPI_GNSILU_ADD, h=hraw, gn=mr,
                       gamma=r["gamma"], beta=r["beta"], groups=8)
@@ -796,9 +803,23 @@ class DAEngine:
     def _down(self, i, x, B, h, w):
         d = self.downs[i]
         x = self.mamba_block(d["mamba"], x, B, h, w, f"d{i}m")
-        x = self.res_block(d["res"], x, x.shape[-1], None, 0, B, h, w, f"d{i}r")
-        self._skips.append((x, h, w))
         cw = d["samp"]
+        Cx = x.shape[-1]
+        if (d["stride"] == 2 and d["res"]["res"] is None and getattr(self, "down_fuse", False) and cw.KH == 4 and cw.KW == 4
+                and getattr(cw, "w8", None) is None
+                and L.lib().fd_gn_apply_down4x4_ok(getattr(self, "scan_dt", self.dt), Cx, cw.Cout, h, w)):
+            # GroupNorm apply + SiLU + residual of the block AND the 4x4 / stride-2 convolution behind it in one pass: the
+            # block output (the skip) is written once and read back by nothing (fd_downfuse.hip)
+            hraw, mr, sk = self.res_block(d["res"], x, Cx, None, 0, B, h, w, f"d{i}r", defer_apply=True)
+            o = self._b(f"d{i}s", (B, h // 2, w // 2, cw.Cout))
+            L.call("fd_gn_apply_down4x4", self.dt, _p(hraw), _p(x), _p(mr), _p(d["res"]["gamma"]), _p(d["res"]["beta"]), 8,
+                   _p(sk), _p(cw.w), _p(cw.b), _p(o), B, h, w, Cx, cw.Cout, self.stream)
+            self._pr(f"d{i}r", sk)
+            self._skips.append((sk, h, w))
+            self._pr(f"d{i}s", o)
+            return o, h // 2, w // 2
+        x = self.res_block(d["res"], x, Cx, None, 0, B, h, w, f"d{i}r")
+        self._skips.append((x, h, w))
         if d["stride"] == 2:
             o = self._b(f"d{i}s", (B, h // 2, w // 2, cw.Cout))
             self.conv(cw, x, B, h, w, o, stride=2, pad=1)

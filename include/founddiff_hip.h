@@ -160,6 +160,16 @@ int fd_gn_finalize(const float *stats_partial, int B, int mtiles, int C, int gro
 int fd_gn_silu_apply(int dtype, const void *h, const float *mean_rstd, const float *gamma,
                      const float *beta, const void *res, void *out, int B, int64_t hw, int C,
                      int groups, void *stream);
+/* The tail of an identity-residual ResnetBlock AND the down-sampling convolution behind it in one pass (round 4, bf16, C = 64):
+ *   skip = x + SiLU(GroupNorm(h)) -- bit for bit fd_gn_silu_apply's result -- and
+ *   out  = Conv2d(C, Cout, 4, stride 2, padding 1)(skip) + bias        (src/DADiff.py:128-131, 213-229, 418-430, 578-584)
+ * h, x, skip [B,H,W,64]; mean_rstd [B][groups][2] from fd_gn_finalize; w [Cout][16 taps x 64] in K order (kh, kw, c) as for
+ * fd_conv2d; out [B,H/2,W/2,Cout], Cout in {64, 128}; H % 16 == 0, W % 32 == 0.  The applied tensor is read back by nothing:
+ * the convolution runs on the tile the apply left in LDS, with the weights resident in registers.                       */
+int fd_gn_apply_down4x4_ok(int dtype_opts, int C, int Cout, int H, int W);
+int fd_gn_apply_down4x4(int dtype, const void *h, const void *x, const float *mean_rstd, const float *gamma,
+                        const float *beta, int groups, void *skip, const void *w, const float *bias, void *out,
+                        int B, int H, int W, int C, int Cout, void *stream);
 
 /* ---- LayerNorm family (channel-last rows) ------------------------------------------------
  * fd_ln_modulate: out = LN(x) * (1 + scale[b]) + shift[b]      src/DADiff.py:450-451, 486-487

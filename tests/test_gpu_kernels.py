@@ -846,6 +846,54 @@ def test_pw_dw3x3_gram(eng_factory, hw):
     assert float((got[..., :8].float() - 7.0).abs().max()) == 0.0
     assert torch.equal(got[..., 8:], ref)          # same operands, same rounding points, same MFMA order
 
+@pytest.mark.parametrize("cfg", [dict(B=2, hw=(128, 256), cout=64), dict(B=12, hw=(144, 160), cout=64), dict(B=3, hw=(128, 256), cout=128)])
+def test_gn_apply_down4x4(eng_factory, cfg):
+    """fd_gn_apply_down4x4 (GroupNorm apply + SiLU + identity residual of a ResnetBlock and the 4x4 / stride-2
+    convolution behind it in one pass; src/DADiff.py:128-131, 213-229, 418-430) against the two-pass HIP sequence
+    fd_gn_silu_apply + fd_conv2d: the skip tensor bit for bit, the down-sampled tensor to fp32 summation order; and
+    against torch.  The second case has a ragged last workgroup (45 tiles, two per workgroup)."""
+    from founddiff_amd import _lib as L
+    from founddiff_amd.engine import ConvW
+    e = eng_factory("bf16")
+    torch.manual_seed(51)
+    B, (H, W), Co = cfg["B"], cfg["hw"], cfg["cout"]
+    C_ = 64
+    assert L.lib().fd_gn_apply_down4x4_ok(L.FD_BF16, C_, Co, H, W)
+    bf = lambda t: t.to(torch.bfloat16).float()
+    h = bf(torch.randn(B, H, W, C_) * 2 + 0.5)
+    x = bf(torch.randn(B, H, W, C_))
+    gam, bet = torch.randn(C_), torch.randn(C_)
+    hv = h.reshape(B, H * W, 8, 8).permute(0, 2, 1, 3).reshape(B, 8, -1)
+    mr = torch.stack([hv.mean(-1), torch.rsqrt(hv.var(-1, unbiased=False) + 1e-5)], -1).contiguous()
+    wt, bias = bf(torch.randn(Co, C_, 4, 4) / 32), torch.randn(Co)
+    cw = ConvW(wt, bias, e.dev, e.tdt)
+    hd, xd, mrd, gd, bd = h.cuda().to(torch.bfloat16), x.cuda().to(torch.bfloat16), mr.cuda(), gam.cuda(), bet.cuda()
+    s = torch.cuda.current_stream().cuda_stream
+    # two passes
+    sk0 = torch.empty(B, H, W, C_, device="cuda", dtype=torch.bfloat16)
+    L.call("fd_gn_silu_apply", L.FD_BF16, hd.data_ptr(), mrd.data_ptr(), gd.data_ptr(), bd.data_ptr(), xd.data_ptr(),
+           sk0.data_ptr(), B, H * W, C_, 8, s)
+    o0 = torch.empty(B, H // 2, W // 2, Co, device="cuda", dtype=torch.bfloat16)
+    e.conv(cw, sk0, B, H, W, o0, stride=2, pad=1)
+    # one pass
+    sk1 = torch.full((B, H, W, C_), 3.0, device="cuda", dtype=torch.bfloat16)
+    o1 = torch.full((B, H // 2, W // 2, Co), 5.0, device="cuda", dtype=torch.bfloat16)
+    L.call("fd_gn_apply_down4x4", L.FD_BF16, hd.data_ptr(), xd.data_ptr(), mrd.data_ptr(), gd.data_ptr(), bd.data_ptr(), 8,
+           sk1.data_ptr(), cw.w.data_ptr(), cw.b.data_ptr(), o1.data_ptr(), B, H, W, C_, Co, s)
+    torch.cuda.synchronize()
+    assert torch.equal(sk0, sk1)
+    assert rel_err(o1.float().cpu(), o0.float().cpu()) < 8e-3              # bf16 outputs of fp32 sums in two orders
+    ref = F.conv2d(sk0.float().cpu().permute(0, 3, 1, 2), wt, bias, stride=2, padding=1).permute(0, 2, 3, 1)
+    assert rel_err(o1.float().cpu(), ref) < 8e-3
+    gn = F.group_norm(h.permute(0, 3, 1, 2), 8, gam, bet, 1e-5).permute(0, 2, 3, 1)
+    assert rel_err(sk1.float().cpu(), x + F.silu(gn)) < 1.5e-2
+    # deterministic
+    o2 = torch.empty_like(o1)
+    L.call("fd_gn_apply_down4x4", L.FD_BF16, hd.data_ptr(), xd.data_ptr(), mrd.data_ptr(), gd.data_ptr(), bd.data_ptr(), 8,
+           sk1.data_ptr(), cw.w.data_ptr(), cw.b.data_ptr(), o2.data_ptr(), B, H, W, C_, Co, s)
+    torch.cuda.synchronize()
+    assert torch.equal(o1, o2)
+
 
 @pytest.mark.parametrize("cfg", [(128, 64, 48), (256, 24, 32), (512, 8, 16)])
 def test_dwconv_gram(eng_factory, cfg):

@@ -57,6 +57,10 @@ for n, args in trace:
             nch = 192 if getattr(args[13], "value", args[13]) else 128       # out_v == NULL: q, k only
             fl = 2.0 * B * H * W * 64 * nch + 2.0 * B * H * W * nch * 9 + 2.0 * B * H * W * 64 * 32
             desc = f"LN -> {'qkv' if nch == 192 else 'qk'} 64 -> {nch} -> dw3x3 -> Gram @ {H}x{W}"
+    elif n == "fd_gn_apply_down4x4":
+        Bq, H, W, Cq, Co = args[11:16]
+        fl = 2.0 * Bq * (H // 2) * (W // 2) * Co * 16 * Cq
+        desc = f"GN apply + SiLU + residual -> skip; 4x4 s2 {Cq} -> {Co} @ {H // 2}x{W // 2}"
     elif n == "fd_pw_dw3x3_proj":
         H, W = args[20], args[21]
         fl = 2.0 * B * H * W * 64 * 64 * 2 + 2.0 * B * H * W * 64 * 9
