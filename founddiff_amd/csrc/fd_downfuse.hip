@@ -12,7 +12,7 @@
 //            one tile) and park the bf16 tile in LDS, out-of-image pixels as the convolution's zero padding;
 //   phase 2  the convolution on MFMA with the WEIGHTS RESIDENT IN REGISTERS: wave w owns 16 output channels, i.e. the
 //            16 x 1024 slice of the weight matrix = 32 K32 fragments = 128 VGPRs, loaded once per (persistent)
-//            workgroup; a tap is a pixel offset into the LDS tile (stride-2 columns: the XOR swizzle runs on column / 2),
+//            workgroup; a tap is a pixel offset into the LDS tile (stride-2 columns: even and odd columns stored apart),
 //            256 ds_read_b128 + 256 MFMAs per wave and tile;
 //   epilogue bias, bf16, 8-byte stores straight from the accumulators (the output is a quarter of the input).
 // 78 KB of LDS: two 4-wave workgroups per CU (Cout = 64) whose phases overlap; Cout = 128 runs 8 waves per workgroup.
@@ -35,7 +35,13 @@ struct DownParams {
     int H, W, tiles_x, ntiles, tpw;
 };
 
-__device__ __forceinline__ int dt_off(int pix, int col, int chunk) { return pix * 128 + ((chunk ^ ((col >> 1) & 7)) << 4); }
+// LDS image of the tile: the pixels of a row are stored EVEN columns first, then the odd ones (slot = (c & 1) * 17 + c / 2):
+// the 16 lanes of a fragment read columns 2 fr + kw, i.e. 16 CONSECUTIVE slots, and with the 16-byte chunks XORed by
+// slot & 7 a ds_read_b128 lane group ({0-3, 12-15, 20-27} ...: MI355X_MICROARCH.md, LDS) hits 16 distinct 16-byte bank
+// groups of the 64-bank array for every tap -- the layout of the 3x3 halo kernel.  (Stored in column order, all 16 lanes
+// sit on pixels of one parity and use half of the banks: 47 % of the LDS cycles were conflicts, PMC.)
+__device__ __forceinline__ int dt_slot(int c) { return (c & 1) * (DT_IW / 2) + (c >> 1); }
+__device__ __forceinline__ int dt_off(int row, int slot, int chunk) { return (row * DT_IW + slot) * 128 + ((chunk ^ (slot & 7)) << 4); }
 
 template <int NW, int BATCH>
 __global__ __launch_bounds__(64 * NW, 2) void down_fused_kernel(const DownParams p) {
@@ -84,7 +90,7 @@ __global__ __launch_bounds__(64 * NW, 2) void down_fused_kernel(const DownParams
 #pragma unroll
     for (int kw = 0; kw < 4; ++kw)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) boff[kw][ks] = dt_off(2 * fr + kw, 2 * fr + kw, ks * 4 + fg);
+        for (int ks = 0; ks < 2; ++ks) boff[kw][ks] = dt_off(0, dt_slot(2 * fr + kw), ks * 4 + fg);
 
     const int tile0 = blockIdx.x * p.tpw;
     for (int tt = 0; tt < p.tpw; ++tt) {
@@ -129,7 +135,7 @@ __global__ __launch_bounds__(64 * NW, 2) void down_fused_kernel(const DownParams
                     *(u32x4 *)(skip + ((__umul24(iy, p.W) + ix) * 64 + v * 8)) = ov;
                 const bool inimg = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
                 if (!inimg) ov = (u32x4){0, 0, 0, 0};        // the convolution's zero padding
-                *(u32x4 *)(tile + dt_off(pix, c, v)) = ov;
+                *(u32x4 *)(tile + dt_off(r, dt_slot(c), v)) = ov;
             }
         }
         __syncthreads();
