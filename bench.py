@@ -208,6 +208,16 @@ def roofline_leg(dif, x, noise, t_measured_ms=None, clock_replay=True):
                       "launches_per_forward": len(part), "avg_launch_us": round(ms * 1e3 / len(part), 2),
                       "alg_gflop_per_launch": round(fl / 1e9 / len(part), 2),
                       "kernel_ms_per_forward": round(ms, 3)})
+    # 3x3 64 -> 64 with the weights resident in registers (conv3x3_rw_kernel): MFMA roofline like the halo kernel
+    rw = [(n, a) for n, a in trace if n == "fd_conv2d" and lib.fd_conv_kernel_id(a[0]) == 13]
+    if rw:
+        fl = sum(conv_flops(a[0]._obj) for _, a in rw)
+        ms = _time_launches(lib, rw)
+        tf = fl / (ms * 1e-3) / 1e12
+        cands.append({"bound": "mfma", "kernel": "conv3x3_rw_kernel", "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS,
+                      "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4), "traffic": traffic.get("conv3x3_rw_hbm_bytes_per_launch"),
+                      "launches_per_forward": len(rw), "avg_launch_us": round(ms * 1e3 / len(rw), 2),
+                      "alg_gflop_per_launch": round(fl / 1e9 / len(rw), 2), "kernel_ms_per_forward": round(ms, 3)})
     # depthwise 3x3 alone: args = (dtype, in, ld_in, off_in, w, bias, silu, out, ld_out, off_out, B, H, W, C, stream)
     dws = [(n, a) for n, a in trace if n == "fd_dwconv3x3"]
     if dws:

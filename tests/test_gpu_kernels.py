@@ -717,6 +717,52 @@ def test_conv3x3_halo(eng_factory, cfg):
         assert torch.equal(out, first) and torch.equal(part, first_part)
 
 
+@pytest.mark.parametrize("hw", [(256, 512), (272, 512)])
+def test_conv3x3_weights_in_registers(eng_factory, hw):
+    """3x3 64 -> 64 with the weight matrix resident in registers (fd_conv3x3_rw.hip, kernel id 13; the first convolution of the
+    64-channel ResnetBlocks at >= 131072 pixels) against torch and against the halo-tiled kernel (FD_NO_CONV3_RW is read once
+    per process, so the halo kernel is reached through a two-source split of the same channels), with the GroupNorm partial
+    sums; the second size leaves the last workgroup one tile of three."""
+    from founddiff_amd import _lib as L
+    from founddiff_amd.engine import ConvW
+    e = eng_factory("bf16")
+    torch.manual_seed(23)
+    B, (H, W) = 2, hw
+    x = rq(torch.randn(B, 64, H, W), "bf16")
+    w = rq(torch.randn(64, 64, 3, 3) / 24, "bf16")
+    bias = torch.randn(64)
+    ref = F.conv2d(x, w, bias, padding=1)
+    cw = ConvW(w, bias, e.dev, e.tdt)
+    xa = nhwc(x, e.tdt)
+    out = torch.empty(B, H, W, 64, device="cuda", dtype=e.tdt)
+    part = torch.full((B, L.lib().fd_conv_mtiles(H, W), 64, 2), 7.0, device="cuda")       # must be overwritten
+    kw = dict(c0=64, stats=part)
+    assert e.conv(cw, xa, B, H, W, out, probe="kid", **kw) == 13
+    e.conv(cw, xa, B, H, W, out, **kw)
+    torch.cuda.synchronize()
+    assert rel_err(nchw(out), ref) < 1.2e-2
+    s = part.sum(1).cpu()
+    assert rel_err(s[..., 0], ref.sum((2, 3))) < 5e-3 and rel_err(s[..., 1], (ref ** 2).sum((2, 3))) < 5e-3
+    # the halo-tiled kernel on the same operands (input handed over as two 32-channel sources is not eligible for id 13 -- c0 must
+    # be 64 -- nor for the halo kernel's 64-channel slabs; use the plain kernel through a 128-channel zero-extended input instead)
+    x2 = torch.zeros(B, H, W, 128, device="cuda", dtype=e.tdt)
+    x2[..., :64] = xa
+    w2 = torch.zeros(64, 128, 3, 3)
+    w2[:, :64] = w
+    out2 = torch.empty_like(out)
+    cw2 = ConvW(w2, bias, e.dev, e.tdt)
+    assert e.conv(cw2, x2, B, H, W, out2, probe="kid", c0=128) == 11
+    e.conv(cw2, x2, B, H, W, out2, c0=128)
+    torch.cuda.synchronize()
+    assert rel_err(out.float().cpu(), out2.float().cpu()) < 4e-3          # bf16 outputs of fp32 sums in two orders
+    first, first_part = out.clone(), part.clone()
+    for _ in range(4):
+        out.zero_()
+        e.conv(cw, xa, B, H, W, out, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(out, first) and torch.equal(part, first_part)
+
+
 @pytest.mark.parametrize("cfg", [dict(cdw=128, cz=128, silu=1, bias=True, affine=True, hw=(128, 256)),     # SS2D in_proj + conv2d
                                  dict(cdw=192, cz=0, silu=0, bias=False, affine=False, hw=(256, 128)),    # qkv + qkv_dwconv
                                  dict(cdw=256, cz=256, silu=1, bias=True, affine=True, hw=(128, 256), cin=128),   # C = 128 in_proj

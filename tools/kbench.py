@@ -171,7 +171,7 @@ def bench_conv3(B, shapes=None):
         kw = dict(c0=c0, stats=part, upsample=up)
         if c1:
             kw.update(in1=xb, c1=c1)
-        assert e.conv(cw, xa, B, H, H, out, probe="kid", **kw) == 11
+        assert e.conv(cw, xa, B, H, H, out, probe="kid", **kw) in (11, 13)
         t = timeit(lambda: e.conv(cw, xa, B, H, H, out, **kw))
         fl = 2.0 * B * OH * OH * cout * 9 * cin
         print(f"conv3x3 {cin:4d}->{cout:4d} @{OH} up={int(up)} B={B}: {t:8.1f} us  {fl / t / 1e6:7.1f} TFLOP/s  ({fl / t / 1e6 / 2500:.3f} of peak)", flush=True)

@@ -53,6 +53,7 @@ res = {"note": __doc__.strip(),
        "pwdw_proj_hbm_bytes_per_launch": fam("pwdw_kernel<64, true>"),
        "gemm_rows_zre_hbm_bytes_per_launch": fam("gemm_rows_zre_kernel"),
        "down_fused_hbm_bytes_per_launch": fam("down_fused_kernel"),
+       "conv3x3_rw_hbm_bytes_per_launch": fam("conv3x3_rw_kernel"),
        "dwconv3x3_bf16_hbm_bytes_per_launch": fam("dwconv3x3_bf16_kernel"),
        "conv3x3_halo_hbm_bytes_per_launch": fam("conv3x3_halo_kernel"),
        "per_kernel": per}
