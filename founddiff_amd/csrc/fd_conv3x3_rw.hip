@@ -176,6 +176,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rw_kernel(const fd_conv_params
     }
 }
 
+
 }  // namespace
 
 int fd_conv3x3_rw_ok(const fd_conv_params &p) {
@@ -199,6 +200,8 @@ int fd_conv3x3_rw_launch(const fd_conv_params &p, hipStream_t s) {
     int tpw = tpw_env > 0 ? tpw_env : (int)(((int64_t)tiles_xy * p.B + 511) / 512);
     if (tpw < 1) tpw = 1;
     dim3 grid((tiles_xy + tpw - 1) / tpw, p.B);
+    // (a 16-channel-per-wave form -- 72 VGPRs of weights, three workgroups per CU, fragment reads 1:1 with the MFMAs -- measured
+    //  246 us against 218: the LDS reads, not the tiles in flight, then set the pace)
     hipLaunchKernelGGL(conv3x3_rw_kernel, grid, dim3(256), 0, s, p, tpw, tiles_xy);
     return 0;
 }
