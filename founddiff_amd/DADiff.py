@@ -362,9 +362,6 @@ class ResidualDiffusion(nn.Module):
         # scan, HBM row-GEMMs, MFMA convolutions) overlap when they come from independent launch sequences
         # (measured: 2 x 8 slices on two streams 1.79 ms per slice-forward, one stream of 8 or 16: 1.90 / 1.84)
         self.streams = int(os.environ.get("FOUNDDIFF_STREAMS", "2"))
-        # phase offset between the concurrent sub-batches (microseconds; sub-batch k starts k * offset late): identical
-        # launch sequences that start together pair every kernel with its twin, which is bound by the same resource
-        self.stream_offset_us = float(os.environ.get("FOUNDDIFF_STREAM_OFFSET_US", "0"))
         self._side_streams = {}
 
     def init(self):
@@ -945,8 +942,6 @@ class ResidualDiffusion(nn.Module):
             self._slot = k
             try:
                 with torch.cuda.stream(st):
-                    if k and self.stream_offset_us > 0:
-                        L.call("fd_stream_delay", float(k * self.stream_offset_us), C.c_void_p(st.cuda_stream))
                     sl = slice(k * per, (k + 1) * per)
                     if seeds is None:
                         o = self.ddim_sample([x_in[sl].contiguous()], (per,) + tuple(size[1:]), last=True,

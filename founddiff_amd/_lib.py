@@ -81,9 +81,6 @@ SIGNATURES = {
     "fd_selective_scan_fuses_xproj": (i32, [i32, i32, i32, i32]),
     "fd_selective_scan_plan": (i32, [i32, i32, i32, i32, i32, i32]),
     "fd_selective_scan_xproj": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
-    "fd_selective_scan_fused_ok": (i32, [i32, i32, i32, i32, i32, i32]),
-    "fd_scan_fused_ws_floats": (i64, [i32, i32, i32, i32, i32, i32]),
-    "fd_selective_scan_fused": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "fd_selective_scan_fwd_f32": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i64, vp, vp, vp]),
     "fd_chan_attn_nblk": (i32, [i64]),
     "fd_chan_attn_gram": (i32, [i32, vp, i32, i64, i32, vp, vp]),
@@ -106,7 +103,6 @@ SIGNATURES = {
     "fd_res_ddim_step": (i32, [vp, vp, vp, vp, f32, f32, i32, vp, i64, vp]),
     "fd_res_step_obj": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i64, vp]),
     "fd_res_posterior_step": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i64, vp]),
-    "fd_stream_delay": (i32, [f32, vp]),
     "fd_keyed_normal": (i32, [vp, i32, vp, i32, i64, vp]),
     "fd_ancestral_begin": (i32, [vp, vp, vp, i32, vp]),
     "fd_res_posterior_step_keyed": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i64, vp]),

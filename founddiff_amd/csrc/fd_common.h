@@ -154,6 +154,12 @@ __device__ __forceinline__ f32x2 fd_unpack_bf16(uint32_t w) {
 // neighbouring lanes (src/DADiff.py:450-451, 477-488: x_n = LN(x) * g + b with g = gamma (1 + scale), b = beta (1 + scale)
 // + shift folded by the caller).  One pass (sum and sum of squares, fp32), packed fp32 arithmetic, DPP group sums:
 // ~40 issue slots per chunk (the two-pass scalar form with ds_bpermute shuffles took ~120 and six LDS round trips).
+// Why one pass is enough HERE (and only here: ln_rows_kernel, which also serves the fp32 modes, centres its rows): the
+// inputs are bf16.  var = E[x^2] - mean^2 in fp32 carries a relative error of ~2^-24 (1 + (mean / std)^2) (the products of
+// bf16 values are exact in fp32); a bf16 row cannot hold |mean| / std above ~2^8 at all (the spacing of bf16 at |mean| is
+// |mean| / 2^8: beyond that ratio the row is its own quantisation noise), so the error of var stays below 2^-24 2^16 =
+// 0.4 % at that extreme and below 1e-4 for |mean| / std <= 40.  tests/test_gpu_round5.py::test_ln_rows_with_common_offset
+// pins both forms against F.layer_norm on rows with a large common offset.
 template <int LANES>
 __device__ __forceinline__ u32x4 fd_ln_mod_chunk(u32x4 raw, const f32x2 (&g)[4], const f32x2 (&b)[4], float eps) {
     const uint32_t rw[4] = {raw.x, raw.y, raw.z, raw.w};
@@ -178,6 +184,17 @@ __device__ __forceinline__ u32x4 fd_ln_mod_chunk(u32x4 raw, const f32x2 (&g)[4],
     }
     return u32x4{o[0], o[1], o[2], o[3]};
 }
+
+// Accumulators written by inline-asm MFMAs: the compiler's hazard recognizer does not see into asm, so the last MFMAs'
+// results need wait states before the first VALU read.  A bare `asm volatile("s_nop ..." ::: "memory")` only orders MEMORY
+// operations: a register-only consumer (acc + bias) has no dependence on it and may legally be scheduled above the nops.
+// These macros make every accumulator an in/out operand of the nop block (or of an empty volatile asm that follows it --
+// volatile asm statements keep their order): any read of an accumulator now depends on the wait.  (tools/kres.py checks
+// the ISA: no VALU read of an accumulator between the last v_mfma of a loop and the s_nop block.)
+#define FD_TIE2(a) "+v"((a)[0]), "+v"((a)[1])
+#define FD_TIE4(a) FD_TIE2(a), "+v"((a)[2]), "+v"((a)[3])
+#define FD_TIE8(a) FD_TIE4(a), "+v"((a)[4]), "+v"((a)[5]), "+v"((a)[6]), "+v"((a)[7])
+#define FD_MFMA_ASM_DRAIN "s_nop 15\n\ts_nop 15\n\ts_nop 15"
 
 // Development switch FD_PAD_<NAME>=<KiB>: extra dynamic LDS requested per workgroup of kernel family NAME, i.e. a cap on
 // its workgroups per CU -- used to study how kernels of the two concurrent sub-batch streams share a CU

@@ -438,7 +438,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
         }
         // F8: the last inline-asm MFMAs must have written their accumulators before the epilogue reads them (the
         // compiler's hazard recognizer does not see into asm); volatile + memory clobber keeps the LDS stores below it
-        if constexpr (F8) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+        // (every accumulator is an in/out operand of the nop block, so no register-only consumer can be scheduled above it: fd_common.h)
+        if constexpr (F8) {
+            static_assert(MT == 4 && (NT == 4 || NT == 2), "accumulator ties below");
+            if constexpr (NT == 4) asm volatile(FD_MFMA_ASM_DRAIN : FD_TIE4(acc[0]), FD_TIE4(acc[1]), FD_TIE4(acc[2]), FD_TIE4(acc[3]) :: "memory");
+            else asm volatile(FD_MFMA_ASM_DRAIN : FD_TIE2(acc[0]), FD_TIE2(acc[1]), FD_TIE2(acc[2]), FD_TIE2(acc[3]) :: "memory");
+        }
 
         // ---- epilogue.  acc[i][2 q + h][e] of lane (fr, fg) = pixel (tile row 4 wm + i, column fr), output channel
         // cb + 32 q + 4 h + e with cb = the wave's channel base + 8 fg (tile_row_channel above).  Every wave is past its

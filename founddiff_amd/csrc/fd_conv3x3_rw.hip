@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rw_kernel(const fd_conv_params
                             asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[a][i]) : "v"(wf[a][(kh * 3 + kw) * 2 + ks]), "v"(bq[i]));
                     __builtin_amdgcn_sched_barrier(0);
                 }
-        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");      // the last MFMAs' results (asm: no hazard tracking)
+        asm volatile(FD_MFMA_ASM_DRAIN : FD_TIE4(acc[0]), FD_TIE4(acc[1]) :: "memory");      // the last MFMAs' results (fd_common.h)
 
         // ---- epilogue: lane (fr, fg) holds channels n0 .. n0 + 7 (a = 0: + 0..3, a = 1: + 4..7) of pixel (ty0 + 4 wm + i, tx0 + fr)
         const int n0 = 32 * wn + 8 * fg;

@@ -161,7 +161,8 @@ __global__ __launch_bounds__(64 * NW, 2) void down_fused_kernel(const DownParams
                         asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[m]) : "v"(a), "v"(bq[m]));
                     __builtin_amdgcn_sched_barrier(0);
                 }
-        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");    // the last MFMAs' results before the epilogue reads them (asm: no hazard tracking)
+        static_assert(DT_OH == 8, "FD_TIE8");
+        asm volatile(FD_MFMA_ASM_DRAIN : FD_TIE8(acc) :: "memory");    // the last MFMAs' results before the epilogue reads them (fd_common.h)
         // ---- epilogue: lane (fr, fg) holds channels cb + 4 fg .. + 3 of output pixel (oy0 + m, ox0 + fr)
 #pragma unroll
         for (int m = 0; m < DT_OH; ++m) {

@@ -188,7 +188,9 @@ __global__ __launch_bounds__(PG_NTHR, 2) void pw_gemm_kernel(const fd_conv_param
             if (g8 == 0) pending = false;
         }
         // the last inline-asm MFMAs must have written their accumulators before the epilogue's VALU reads them
-        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory");
+        // (every accumulator an operand of the nop block or of the empty volatile asm behind it: fd_common.h)
+        asm volatile(FD_MFMA_ASM_DRAIN : FD_TIE8(acc[0]), FD_TIE8(acc[1]) :: "memory");
+        asm volatile("" : FD_TIE8(acc[2]), FD_TIE8(acc[3]));
         // ---- end of tile: accumulators -> packed outputs (lane = pixel fr of row block i; 8 consecutive channels per
         // pair of permuted 16-channel tiles), stored during the next tile's first eight stages
 #pragma unroll

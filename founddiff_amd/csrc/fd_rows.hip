@@ -51,9 +51,10 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(
         for (int e = 0; e < 4; ++e) {
             const f32x2 d = v[j][e] - mean;
             q2 = d * d + q2;
+            v[j][e] = d;                    // the apply below works on the centred value: (x - mean) * rstd, not x * rstd - mean * rstd
+                                            // (a row with |mean| >> std would lose the difference's low bits in the second form)
         }
     const float rstd = rsqrtf(allsum(q2.x + q2.y) / C + eps);
-    const float nm = -mean * rstd;
     if (!active) return;
 #pragma unroll
     for (int j = 0; j < VPL; ++j) {
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            f32x2 y = v[j][e] * rstd + nm;
+            f32x2 y = v[j][e] * rstd;
             if (gamma) y = y * f32x2{gg[2 * e], gg[2 * e + 1]} + f32x2{bb[2 * e], bb[2 * e + 1]};
             const f32x2 sh2 = {sh[2 * e], sh[2 * e + 1]};
             if (GATE) y = y * f32x2{zz[2 * e], zz[2 * e + 1]} + sh2;       // shift == local

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 8 ? (CPL == 2 ? 4 : 5) : 
     // interleaved forms were built -- x_proj block by block in front of its 16 recurrence steps, fragment and u loads
     // one group apart (fetch +14 %, time equal) or issued together (the extra live registers spill at 4 waves per
     // SIMD: 2x slower) -- and dropped; the kernel is VALU-bound and the second read costs bytes, not time.)
-    if constexpr (!FINAL && sizeof(T) == 2) {
+    if constexpr (!FINAL && sizeof(T) == 2 && CPL != 2) {
         if (g.xw) {
             const bf16 *Wk = (const bf16 *)g.xw + (int64_t)k * CD * g.D;
             const bf16 *ubx = (const bf16 *)xc + (int64_t)b * g.H * g.W * g.D;
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 8 ? (CPL == 2 ? 4 : 5) : 
             }
         }
     }
-    // ---- stage the chunk's rows
+    // ---- stage the chunk's rows (phase A with the fused x_proj writes them itself)
     if (FINAL || sizeof(T) != 2 || !g.xw)
     for (int idx = threadIdx.x; idx < (l1 - l0) * CD; idx += blockDim.x) {
         const int row = idx / CD, e = idx - row * CD;
@@ -334,6 +334,104 @@ __global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 8 ? (CPL == 2 ? 4 : 5) : 
         if (ODD) co += wrap ? 1 : 0;
         pixc += s_i + (wrap ? wrap_fix : 0);
     };
+    // ---- phase A, two channels per lane (one wave = all 128 channels of the chunk), fused x_proj: ONE read of u (round 5).
+    // Block by block (16 positions): the block's pixels arrive as MFMA B fragments (lane (fr, fg): pixel fr, channels
+    // 32 ks + 8 fg ..), the x_proj rows go from the accumulators into sx (and out to x_dbl for phase C), the SAME
+    // fragments are parked in a 4 KB LDS block [16 positions][128 channels] and the 16 recurrence steps read their u pair
+    // from there (ds_read_b32) -- the recurrence issues no global load at all, the next block's fragments are in flight in
+    // registers meanwhile.  Until round 4 the whole chunk's x_proj ran first and the recurrence re-read every u from
+    // global memory up to 128 steps (~12 us) later: an XCD's L2 turns over in ~3 us (tools/probes/fetch_calib.hip), so that
+    // second read went back to HBM (FETCH_SIZE of this phase = 2 x u).  Same MFMAs on the same operands in the same order,
+    // same u bits: results are bitwise those of the two-read form.
+    if constexpr (!FINAL && CPL == 2) {
+        if (g.xw) {
+            unsigned char *su = (unsigned char *)(sx + g.CL * CDP);            // [16][256 B], 16-byte chunks XOR (row & 15)
+            const bf16 *Wk = (const bf16 *)g.xw + (int64_t)k * CD * g.D;
+            const bf16 *ubx = (const bf16 *)xc + (int64_t)b * g.H * g.W * g.D;
+            float *xo = g.xdbl_out + ((int64_t)k * g.B + b) * g.L * g.CD;
+            constexpr int MB = (CD + 15) / 16, KSM = 4;                       // d_inner == 128 (launcher)
+            const int fr = lane & 15, fg = lane >> 4;
+            const int nblk = (l1 - l0 + 15) >> 4;
+            struct BlkPos { int l, lrow; };
+            auto bfetch = [&](int nb, BlkPos &q, bf16x8 (&bq)[KSM]) {
+                const int l = l0 + nb * 16 + fr;
+                int h2, w2;
+                if (odd) { w2 = l / g.H2; h2 = l - w2 * g.H2; }
+                else { h2 = l / g.W2; w2 = l - h2 * g.W2; }
+                const int hh = 2 * h2 + ph, ww = 2 * w2 + pw;
+                const bool inimg = l < l1 && hh < g.H && ww < g.W;          // odd sizes: padded positions are zero rows, u = 0
+                const bf16 *px = ubx + ((int64_t)hh * g.W + ww) * g.D + 8 * fg;
+                q.l = l;
+                q.lrow = h2 * g.W2 + w2;
+#pragma unroll
+                for (int ks = 0; ks < KSM; ++ks) {
+                    bq[ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                    if (inimg) bq[ks] = *(const bf16x8 *)(px + 32 * ks);
+                }
+            };
+            // the weight fragments of the chunk's direction: MB x 4 x 16 bytes per lane, loaded once (they were re-read from
+            // L2 for every block)
+            bf16x8 afr[MB][KSM];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const int e = mb * 16 + fr;
+#pragma unroll
+                for (int ks = 0; ks < KSM; ++ks) {
+                    afr[mb][ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                    if (e < CD) afr[mb][ks] = *(const bf16x8 *)(Wk + (int64_t)e * g.D + 32 * ks + 8 * fg);
+                }
+            }
+            // this lane's u pair of block position s: channels 2 lane, 2 lane + 1 = bytes 4 lane .. of row s
+            const int su_rd = ((lane >> 2) << 4) | ((lane & 3) << 2);
+            auto ld_su = [&](int s_) -> uint32_t { return *(const uint32_t *)(su + s_ * 256 + (su_rd ^ ((s_ & 15) << 4))); };
+            BlkPos cur, nxt;
+            bf16x8 bcur[KSM], bnxt[KSM];
+            bfetch(0, cur, bcur);
+            for (int nb = 0; nb < nblk; ++nb) {
+                const bool more = nb + 1 < nblk;
+                if (more) bfetch(nb + 1, nxt, bnxt);
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < KSM; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[mb][ks], bcur[ks], acc, 0, 0, 0);
+                    const int e0 = mb * 16 + 4 * fg;                        // CD % 4 == 0 (launcher): all four or none
+                    if (cur.l < l1 && e0 < CD) {
+                        *(f32x4 *)&sx[(nb * 16 + fr) * CDP + e0] = acc;
+                        *(f32x4 *)&xo[(int64_t)cur.lrow * CD + e0] = acc;
+                    }
+                }
+#pragma unroll
+                for (int ks = 0; ks < KSM; ++ks) *(bf16x8 *)(su + fr * 256 + (((ks * 4 + fg) ^ fr) << 4)) = bcur[ks];
+                const int ns = min(16, l1 - l0 - nb * 16);                  // wave-uniform
+                if (ns == 16) {
+                    RowV r0 = ld_row(nb * 16);
+                    uint32_t u0 = ld_su(0);
+#pragma unroll
+                    for (int st = 0; st < 16; ++st) {
+                        RowV r1 = r0;
+                        uint32_t u1 = u0;
+                        if (st + 1 < 16) { r1 = ld_row(nb * 16 + st + 1); u1 = ld_su(st + 1); }
+                        __builtin_amdgcn_sched_barrier(0);                  // the reads stay a step ahead of their use
+                        step(nullptr, r0, u0, 0);
+                        r0 = r1;
+                        u0 = u1;
+                    }
+                } else {
+                    for (int st = 0; st < ns; ++st) step(nullptr, ld_row(nb * 16 + st), ld_su(st), 0);
+                }
+                if (more) {
+                    cur = nxt;
+#pragma unroll
+                    for (int ks = 0; ks < KSM; ++ks) bcur[ks] = bnxt[ks];
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < N; ++n) *(f32x2 *)&wsH[cbase + (int64_t)n * g.D] = h[n];
+            *(f32x2 *)&wsP[((int64_t)bk * g.nch + chunk) * g.D + d] = sdt2;
+            return;
+        }
+    }
     constexpr int U = (N >= 16) ? 8 : 16;  // steps per group
     // Two groups of u values in registers: group g+1 is loaded while group g runs the recurrence, so a
     // wave always has U loads in flight behind ~U steps of arithmetic (HBM latency under load is longer
@@ -785,7 +883,8 @@ void launch_scan(const T *xc, const float *xdbl, const float *dtw, const float *
     const int nw = g.D >= 4 * cw ? 4 : g.D / cw;       // waves per workgroup
     dim3 grid(g.nch * (g.D / (cw * nw)), g.B * 4), block(64 * nw);
     static const size_t pad = fd_occ_pad("SCAN");
-    const size_t lds = (size_t)g.CL * ((g.CD + 3) & ~3) * sizeof(float) + pad;
+    // (+ 4 KB behind the rows: the u block of the two-channel phase A with the fused x_proj)
+    const size_t lds = (size_t)g.CL * ((g.CD + 3) & ~3) * sizeof(float) + (two && g.xw ? 4096 : 0) + pad;
     if (two) hipLaunchKernelGGL((scan_chunk_kernel<T, N, R, false, ODD, CPL>), grid, block, lds, s, xc, xdbl, dtw, dtb, A, Ds, y, wsH, wsP, g);
     else hipLaunchKernelGGL((scan_chunk_kernel<T, N, R, false, ODD>), grid, block, lds, s, xc, xdbl, dtw, dtb, A, Ds, y, wsH, wsP, g);
     if (g.nch > 1)

@@ -95,22 +95,9 @@ __global__ void res_posterior_keyed_kernel(const float *__restrict__ mo, const f
     }
 }
 
-__global__ void stream_delay_kernel(long long ticks) {
-    const long long t0 = wall_clock64();                       // constant 100 MHz, independent of the shader clock
-    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
-}
-
 inline int g4(int64_t npix) { int64_t b = ((npix + 3) / 4 + 255) / 256; return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b)); }
 
 }  // namespace
-
-extern "C" int fd_stream_delay(float usec, void *stream) {
-    FD_REQUIRE(usec >= 0.f && usec <= 1e6f, "fd_stream_delay: %g us is outside [0, 1 s]", (double)usec);
-    if (usec > 0.f)
-        hipLaunchKernelGGL(stream_delay_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long)(usec * 100.f));
-    FD_LAUNCH_OK("fd_stream_delay");
-    return FD_OK;
-}
 
 extern "C" int fd_keyed_normal(const int64_t *seeds, int t, float *out, int B, int64_t npix, void *stream) {
     FD_REQUIRE(seeds && out && B > 0 && npix > 0 && npix < (1ll << 33), "fd_keyed_normal: bad args");

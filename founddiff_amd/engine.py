@@ -101,7 +101,6 @@ class DAEngine:
         # chosen for throughput at a batch that fills the chip; both are functions of the image size only.
         self.low_latency = bool(low_latency)
         self.scan_dt = self.dt | (L.FD_OPT_LOW_LATENCY if low_latency else 0)
-        self.scan_fused = os.environ.get("FOUNDDIFF_SCAN_FUSED", "0") == "1"      # single-launch scan (opt-in, see mamba_block)
         # z gate of SS2D recomputed inside out_proj instead of written by in_proj and read back (mamba_block); 0 = round-3 dataflow
         # (development: 64 = only in the 64-channel blocks)
         self.z_recompute = int(os.environ.get("FOUNDDIFF_Z_RECOMPUTE", "1"))
@@ -479,17 +478,9 @@ class DAEngine:
         xdbl = self._b("xdbl", (4, B, Lq, CD), torch.float32)
         nws = L.lib().fd_scan_ws_floats(B, H, W, D, N)
         ws = self._b("scan_ws", (nws,), torch.float32)
-        if getattr(self, 'scan_fused', False) and L.lib().fd_selective_scan_fused_ok(getattr(self, 'scan_dt', self.dt), D, N, R, H, W):
-            # ONE launch: u tile in LDS, x_proj on MFMA, decays cached between the passes, in-launch carry tree
-            # (fd_scan_fused.hip): x_dbl and the chunk states never reach HBM.  OPT-IN (FOUNDDIFF_SCAN_FUSED=1): correct
-            # and deterministic, but measured 2x slower than the 3-phase form at level 0
-            fws = self._b("scan_fws", (L.lib().fd_scan_fused_ws_floats(B, H, W, D, N, R),), torch.float32)
-            L.call("fd_selective_scan_fused", self.dt, _p(xc), _p(m["x_proj"]), _p(m["dtw"]), _p(m["dtb"]), _p(m["A"]),
-                   _p(m["Ds"]), _p(y), _p(fws), B, H, W, D, N, R, s)
-            self._pr(tag + ".xdbl", y)
-        elif L.lib().fd_selective_scan_plan(getattr(self, 'scan_dt', self.dt), D, N, R, H, W):
+        if L.lib().fd_selective_scan_plan(getattr(self, 'scan_dt', self.dt), D, N, R, H, W):
             # x_proj inside the scan's first phase (one workgroup per chunk at d_inner <= 256): no separate pass over xc
-            L.call("fd_selective_scan_xproj", self.dt, _p(xc), _p(m["x_proj"]), _p(xdbl), _p(m["dtw"]), _p(m["dtb"]),
+            L.call("fd_selective_scan_xproj", getattr(self, "scan_dt", self.dt), _p(xc), _p(m["x_proj"]), _p(xdbl), _p(m["dtw"]), _p(m["dtb"]),
                    _p(m["A"]), _p(m["Ds"]), _p(y), _p(ws), B, H, W, D, N, R, s)
             self._pr(tag + ".xdbl", xdbl)
         else:

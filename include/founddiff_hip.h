@@ -280,20 +280,6 @@ int fd_selective_scan_fuses_xproj(int dtype, int D, int N, int R);
 int fd_selective_scan_xproj(int dtype, const void *xc, const void *x_proj_w, float *xdbl, const float *dtw,
                             const float *dtb, const float *A, const float *Ds, void *y, float *ws, int B, int H,
                             int W, int D, int N, int R, void *stream);
-/* The same op as ONE launch for the high-resolution levels (fd_scan_fused.hip, round 4): a workgroup keeps its chunk's u
- * tile in LDS (read once; x_proj runs on MFMA from it, x_dbl never reaches HBM), caches the decays exp(dt A) and dt u of
- * its positions in registers between the local scan and the re-run from the carry-in (no second softplus / exp), and
- * gets its carry-in inside the launch from the aggregates of earlier chunks through a FIXED binary tree (deterministic:
- * bitwise independent of batch, timing and placement).  Arguments as fd_selective_scan_xproj without xdbl; ws =
- * fd_scan_fused_ws_floats(...) floats, 16-byte aligned: its head (ticket, timeout word, flags) is zeroed by the call
- * itself (a memset node under graph capture).  After a synchronisation ((uint32_t *)ws)[1] != 0 means a bounded spin
- * timed out (never observed; the result is then undefined).  fd_selective_scan_fused_ok: bf16, even H / W, the built
- * (d_inner, d_state, dt_rank) = (128, 4, 4), H*W/4 a multiple of the 64-position chunk; a function of the shape only. */
-int fd_selective_scan_fused_ok(int dtype_opts, int D, int N, int R, int H, int W);
-int64_t fd_scan_fused_ws_floats(int B, int H, int W, int D, int N, int R);
-int fd_selective_scan_fused(int dtype, const void *xc, const void *x_proj_w, const float *dtw, const float *dtb,
-                            const float *A, const float *Ds, void *y, float *ws, int B, int H, int W, int D, int N,
-                            int R, void *stream);
 /* 1: call fd_selective_scan_xproj for this block; 0: run the x_proj launch, then fd_selective_scan (the single-pass
  * form takes its x_dbl rows from the workspace).                                                              */
 int fd_selective_scan_plan(int dtype, int D, int N, int R, int H, int W);
@@ -427,11 +413,6 @@ int fd_ancestral_begin(int *t_dev, const float *times, float *time_buf, int B, v
 int fd_res_posterior_step_keyed(const float *model_out, const float *x_t, const float *x_in,
                                 const float *coef_table, const int *t_dev, const int64_t *seeds,
                                 float *img_out, float *x_start_out, int B, int64_t npix, void *stream);
-/* fd_stream_delay: one wave that idles for `usec` microseconds (s_sleep on the constant-rate 100 MHz counter) on
- *   `stream`.  The sampler runs a batch as two concurrent half-batches on two HIP streams; delaying
- *   one of them by part of a UNet forward makes the MFMA-bound kernels of one half meet the VALU- / HBM-bound kernels
- *   of the other instead of their twins.  No reference counterpart (the reference is single-stream).              */
-int fd_stream_delay(float usec, void *stream);
 /* ---- vanilla DDPM U-Net extras (src/denoising_diffusion_pytorch.py) -----------------------
  * fd_gn_film_silu_apply: silu(GN(h)*(1+scale[b]) + shift[b])   Block w/ scale_shift, 190-199, 213-221
  * fd_chan_ln:            LN over channels * g (+ res)           LayerNorm/PreNorm/Residual, 95-101,127-146

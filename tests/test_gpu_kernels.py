@@ -1111,64 +1111,6 @@ def test_selective_scan_fused_xproj(cfg):
     assert rel_err(nchw(y), ref) < 1e-2
 
 
-@pytest.mark.parametrize("cfg", [(128, 4, 4, 32, 64), (128, 4, 4, 128, 128), (128, 4, 4, 256, 320)])
-def test_selective_scan_fused_single_launch(cfg):
-    """fd_selective_scan_fused (fd_scan_fused.hip): the scan of the 512x512 / 256x256 levels as ONE launch -- u tile in
-    LDS, x_proj on MFMA, decays cached in registers between the two passes, carry-in through the fixed binary tree of
-    chunk aggregates -- against the CPU einsum + sequential oracle (src/emamba2.py:295-367).  Shapes: 8 chunks, exactly
-    one supergroup of 64 chunks, and 5 supergroups (320 chunks: the top-level carry chain).  Also: the timeout word stays
-    0, two runs give the same bits, a slice's result does not depend on its batch (bitwise), and the result agrees
-    with the 3-phase kernel to bf16 rounding."""
-    from founddiff_amd import _lib as L
-    from oracle import nets
-    D, N, R, H, W = cfg
-    lib = L.lib()
-    assert lib.fd_selective_scan_fused_ok(L.FD_BF16, D, N, R, H, W) == 1
-    assert lib.fd_selective_scan_fused_ok(L.FD_F32, D, N, R, H, W) == 0 and lib.fd_selective_scan_fused_ok(L.FD_BF16, D, N, R, H + 1, W) == 0
-    torch.manual_seed(8)
-    B, CD = 3, R + 2 * N
-    H2, W2 = H // 2, W // 2
-    Lq = H2 * W2
-    xc = (torch.randn(B, D, H, W) * 0.5).to(torch.bfloat16).float()
-    xw = (torch.randn(4, CD, D) / D ** 0.5).to(torch.bfloat16).float()
-    dtw = (torch.rand(4, D, R) * 2 - 1) * R ** -0.5
-    dtb = torch.randn(4, D) * 0.5 - 3
-    A = -torch.exp(torch.log(torch.arange(1, N + 1).float())[None].repeat(4 * D, 1) + 0.1 * torch.randn(4 * D, N))
-    Ds = 1 + 0.1 * torch.randn(4 * D)
-    xs = nets.efficient_scan(xc)
-    xd_scan = torch.einsum("bkdl,kcd->bklc", xs, xw)
-    dts = torch.einsum("bklr,kdr->bkdl", xd_scan[..., :R], dtw)
-    Bs = xd_scan[..., R:R + N].permute(0, 1, 3, 2).contiguous()
-    Cs = xd_scan[..., R + N:].permute(0, 1, 3, 2).contiguous()
-    ys = nets.selective_scan(xs.reshape(B, 4 * D, Lq), dts.reshape(B, 4 * D, Lq), A, Bs, Cs, Ds, dtb.reshape(-1))
-    ref = nets.efficient_merge(ys.view(B, 4, D, Lq), H, W).view(B, D, H, W)
-    st = torch.cuda.current_stream().cuda_stream
-    t = [v.contiguous().cuda() for v in (dtw, dtb, A, Ds)]
-    xcd, xwd = nhwc(xc, torch.bfloat16), xw.to("cuda", torch.bfloat16).contiguous()
-
-    def run(xin, nb):
-        ws = torch.empty(lib.fd_scan_fused_ws_floats(nb, H, W, D, N, R), device="cuda")
-        y = torch.full((nb, H, W, D), float("nan"), device="cuda", dtype=torch.bfloat16)
-        L.call("fd_selective_scan_fused", L.FD_BF16, xin.data_ptr(), xwd.data_ptr(), t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(),
-               t[3].data_ptr(), y.data_ptr(), ws.data_ptr(), nb, H, W, D, N, R, st)
-        torch.cuda.synchronize()
-        assert int(ws[:2].view(torch.int32)[1]) == 0, "a bounded spin of the look-back timed out"
-        return y
-    y = run(xcd, B)
-    assert torch.isfinite(y.float()).all()
-    assert rel_err(nchw(y), ref) < 1e-2
-    assert torch.equal(run(xcd, B), y)                                       # run to run
-    assert torch.equal(run(xcd[1:2].contiguous(), 1)[0], y[1])                # batch invariance, bitwise
-    # against the 3-phase kernel (same arithmetic up to the chunking / summation order)
-    ws3 = torch.empty(lib.fd_scan_ws_floats(B, H, W, D, N), device="cuda")
-    y3 = torch.empty_like(y)
-    xdbl = torch.empty(4, B, Lq, CD, device="cuda")
-    L.call("fd_selective_scan_xproj", L.FD_BF16, xcd.data_ptr(), xwd.data_ptr(), xdbl.data_ptr(), t[0].data_ptr(), t[1].data_ptr(),
-           t[2].data_ptr(), t[3].data_ptr(), y3.data_ptr(), ws3.data_ptr(), B, H, W, D, N, R, st)
-    torch.cuda.synchronize()
-    assert rel_err(y.float().cpu(), y3.float().cpu()) < 6e-3
-
-
 def test_integration_recipe_for_the_reference_extension():
     """the reference imports its native op as
     `from selective_scan_vmamba_pt202 import selective_scan_cuda_core` (src/emamba2.py:27) and calls

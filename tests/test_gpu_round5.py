@@ -1,0 +1,147 @@
+"""Round-5 GPU tests (through the drop-in Python API / the C ABI):
+
+* the whole sampling loop on the `fp32s` engine (fp32 storage, split-bf16 contractions: 3 bf16 MFMAs per product)
+  held to the SAME 1e-3 gate the exact-f32 parity engine meets -- against the reference's goldens (config 1 at every
+  DDIM step, the shipped architecture at 64x64) and against the CPU oracle at the bench size
+  (src/DADiff.py:1276-1365 is the loop whose output the north star's tolerance applies to);
+* the production mode (bf16 kernels + precision tail) against the CPU ORACLE over a loop, not only against this
+  library's own fp32 engine: BASELINE configs[1] geometry, 10-step DDIM.
+"""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import GOLDEN, rel_err
+from test_gpu_e2e import TINY_CLIP, _tiny_model, l2rel, psnr
+
+pytestmark = pytest.mark.gpu
+
+
+def test_ddim_tiny_fp32s(golden):
+    """config 1 (64x64, 10-step DDIM, DA path) with precision='fp32s': every step's image within 1e-3 of the reference."""
+    g, dif = _tiny_model(golden, "fp32s")
+    assert dif._eng().mode == "fp32s" and dif._eng().f32_split == 1
+    imgs = dif.sample([g["x_input"].cuda()], batch_size=2, last=False, noise=g["ddim.noise0"].cuda())
+    ref = g["ddim.imgs"]
+    assert len(imgs) == ref.shape[0]
+    for i, im in enumerate(imgs):
+        assert rel_err(im.cpu(), ref[i]) < 1e-3, i
+    out = dif.sample([g["x_input"].cuda()], batch_size=2, last=True, noise=g["ddim.noise0"].cuda())
+    assert rel_err(out[-1].cpu(), g["ddim.out"]) < 1e-3
+    assert torch.equal(out[-1], imgs[-1])          # whole-loop graph == per-step graphs
+
+
+def test_full_arch_64_fp32s(golden):
+    """The shipped architecture at 64x64, one forward + 2-step DDIM, precision='fp32s' vs the reference: 1e-3."""
+    if not os.path.exists(os.path.join(GOLDEN, "full_arch_64.npz")):
+        pytest.skip("full_arch_64.npz not generated")
+    from founddiff_amd.DADiff import ResidualDiffusion, UnetRes
+    g = golden("full_arch_64")
+    net = UnetRes(dim=64, dim_mults=(1, 2, 4, 8), num_unet=1, condition=True, objective="pred_res",
+                  test_res_or_noise="res", precision="fp32s")
+    dif = ResidualDiffusion(net, image_size=64, timesteps=1000, sampling_timesteps=2, objective="pred_res",
+                            loss_type="l2", condition=True, sum_scale=0.01, test_res_or_noise="res")
+    missing, unexpected = dif.load_state_dict(g.weights("model."), strict=False)
+    assert not [k for k in missing if k.startswith("model.")] and not unexpected
+    dif = dif.to("cuda")
+    dif.init()
+    xi = (g["x_input"] * 2 - 1).cuda()
+    xt = xi + 0.1 * g["noise0"].cuda()
+    tt = torch.full((1,), 999, dtype=torch.long, device="cuda")
+    out = dif.model(torch.cat((xt, xi), 1), [dif.alphas_cumsum[tt] * 1000, dif.betas_cumsum[tt] * 1000])[0]
+    assert rel_err(out.cpu(), g["unet.out"]) < 1e-3
+    res = dif.sample([g["x_input"].cuda()], batch_size=1, last=True, noise=g["noise0"].cuda())
+    assert rel_err(res[-1].cpu(), g["ddim2.out"]) < 1e-3
+
+
+def test_vs_oracle_512_one_forward_fp32s():
+    """BASELINE configs[2] geometry (512x512, full architecture), ONE model_predictions call on the fp32s engine against
+    the CPU oracle: the 1e-3 parity gate at the bench size (same inputs as test_gpu_e2e.test_vs_oracle_512_one_forward)."""
+    from founddiff_amd import arch, synth
+    from founddiff_amd.DADiff import ResidualDiffusion, UnetRes, load_weights
+    from oracle import sampler
+    spec = arch.da_unet_spec(64, (1, 2, 4, 8), prefix="model.unet0.")
+    w = synth.synth_state_dict(spec, seed=0)
+    _, ld = synth.ct_phantom(1, 512, seed=10)
+    x_in = torch.from_numpy(ld) * 2 - 1
+    x_t = x_in + 0.1 * torch.randn(1, 1, 512, 512, generator=torch.Generator().manual_seed(4))
+    tt = torch.full((1,), 500, dtype=torch.long)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    ref = sampler.ResidualOracle(w, prefix="model.unet0.", sampling_timesteps=50).model_predictions(x_in, x_t, tt)
+    net = UnetRes(dim=64, dim_mults=(1, 2, 4, 8), num_unet=1, condition=True, objective="pred_res",
+                  test_res_or_noise="res", precision="fp32s")
+    dif = ResidualDiffusion(net, image_size=512, timesteps=1000, sampling_timesteps=50, objective="pred_res",
+                            loss_type="l2", condition=True, sum_scale=0.01, test_res_or_noise="res")
+    load_weights(dif, w)
+    dif = dif.to("cuda")
+    dif.init()
+    p = dif.model_predictions(x_in.cuda(), x_t.cuda(), tt.cuda())
+    assert rel_err(p.pred_res.cpu(), ref[0]) < 1e-3
+    assert rel_err(p.pred_x_start.cpu(), ref[2]) < 1e-3
+
+
+def test_config2_256_production_vs_oracle_50step():
+    """BASELINE configs[1] (256x256, full architecture + DA-CLIP, 50-step DDIM): the PRODUCTION mode (bf16 kernels, levels 0-1
+    of the last step on the fp32s engine) and the fp32s whole-loop mode against oracle.sampler.ResidualOracle.sample on the
+    same x_T -- the CPU restatement of the reference loop (src/DADiff.py:1276-1365), not this library's own fp32 engine.
+    Production: L2 <= 1e-2 and >= 45 dB (the drift gate of SURVEY section 7); fp32s: max-rel <= 1e-3 (the north star's
+    tolerance, over the whole loop).  Measured in round 5: production 7.3e-3-class (engine-vs-engine figure of
+    test_config2_256_bf16_50step_drift), and at 10 steps 1.37e-2 / 47.3 dB (fewer, larger steps weigh the bf16 steps more);
+    fp32s 6e-5.  ~50 CPU forwards at 256x256: about a minute on 32 host threads."""
+    from founddiff_amd import arch, synth
+    from founddiff_amd.DADiff import ResidualDiffusion, UnetRes, load_weights
+    from oracle import sampler
+    S = 50
+    spec = arch.da_unet_spec(64, (1, 2, 4, 8), prefix="model.unet0.")
+    w = synth.synth_state_dict(spec, seed=0)
+    _, ld = synth.ct_phantom(1, 256, seed=10)
+    x_in = torch.from_numpy(ld)
+    noise = torch.randn(1, 1, 256, 256, generator=torch.Generator().manual_seed(7))
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    ref = sampler.ResidualOracle(w, prefix="model.unet0.", sampling_timesteps=S).sample(x_in, noise)[-1]
+    outs = {}
+    for prec in ("bf16", "fp32s"):
+        net = UnetRes(dim=64, dim_mults=(1, 2, 4, 8), num_unet=1, condition=True, objective="pred_res",
+                      test_res_or_noise="res", precision=prec)
+        dif = ResidualDiffusion(net, image_size=256, timesteps=1000, sampling_timesteps=S, objective="pred_res",
+                                loss_type="l2", condition=True, sum_scale=0.01, test_res_or_noise="res")
+        load_weights(dif, w)
+        dif = dif.to("cuda")
+        dif.init()
+        if prec == "bf16":
+            assert dif.final_fp32_steps == 1 and dif.final_outer_levels == 2      # the benchmarked configuration
+        outs[prec] = dif.sample([x_in.cuda()], batch_size=1, noise=noise.cuda())[-1].float().cpu()
+        del dif, net
+        torch.cuda.empty_cache()
+    e, db = l2rel(outs["bf16"], ref), psnr(outs["bf16"], ref)
+    print(f"production vs oracle, 256x256 / {S} steps: L2 {e:.3e}, {db:.1f} dB; fp32s max-rel {rel_err(outs['fp32s'], ref):.2e}")
+    assert e < 1e-2 and db > 45.0, (e, db)
+    assert rel_err(outs["fp32s"], ref) < 1e-3
+
+
+def test_ln_rows_with_common_offset():
+    """LayerNorm rows whose common offset dwarfs their spread: ln_rows_kernel (every mode; centred two-pass
+    statistics, applies (x - mean) * rstd) on fp32 rows x = 50 + 0.1 randn, and the one-pass packed statistics of the fused bf16
+    kernels (fd_ln_mod_chunk through fd_pw_dw3x3's LayerNorm prologue is covered by its own tests; here the row kernel in bf16)
+    on rows x = 8 + 0.25 randn -- the largest |mean| / std a bf16 row can carry with its spread still resolved."""
+    import ctypes as C
+    from founddiff_amd import _lib as L
+    torch.manual_seed(3)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for dt, tdt, Cc, off, sd, tol in ((L.FD_F32, torch.float32, 256, 50.0, 0.1, 5e-4), (L.FD_F32, torch.float32, 64, -300.0, 0.05, 2e-3),
+                                      (L.FD_BF16, torch.bfloat16, 128, 8.0, 0.25, 2e-2)):
+        B, hw = 2, 512
+        x = (off + sd * torch.randn(B, hw, Cc)).to(tdt)
+        g, b = torch.randn(Cc), torch.randn(Cc)
+        shift, scale = torch.randn(B, Cc) * 0.2, torch.randn(B, Cc) * 0.2
+        ref = F.layer_norm(x.float().double(), (Cc,), g.double(), b.double(), 1e-5) * (1 + scale.double()[:, None]) + shift.double()[:, None]
+        xd, out = x.cuda(), torch.empty(B, hw, Cc, device="cuda", dtype=tdt)
+        gd, bd, shd, scd = g.cuda(), b.cuda(), shift.cuda().contiguous(), scale.cuda().contiguous()
+        L.call("fd_ln_modulate", dt, C.c_void_p(xd.data_ptr()), C.c_void_p(gd.data_ptr()), C.c_void_p(bd.data_ptr()), 1e-5,
+               C.c_void_p(shd.data_ptr()), C.c_void_p(scd.data_ptr()), Cc, C.c_void_p(out.data_ptr()), B, hw, Cc, s)
+        torch.cuda.synchronize()
+        err = float((out.float().cpu().double() - ref).abs().max() / ref.abs().max())
+        print(f"ln rows offset {off} sd {sd} {tdt}: max-rel {err:.2e}")
+        assert err < tol, (off, sd, tdt, err)

@@ -74,38 +74,6 @@ def bench_scanx(B):
         print(f"scanx D={D} N={N} R={R} {H}x{W} B={B}: {t:8.1f} us  ({t / B / 1e3:.4f} ms/slice)  y={float(y.float().abs().mean()):.6f} xdbl={float(xdbl.abs().mean()):.6f}", flush=True)
 
 
-def bench_scanf(B):
-    """single-launch fused scan (fd_scan_fused.hip) next to the 3-phase form with x_proj in phase A"""
-    from founddiff_amd import _lib as L
-    s = torch.cuda.current_stream().cuda_stream
-    for D, N, R, H, W in [(128, 4, 4, 512, 512), (128, 4, 4, 256, 256)]:
-        torch.manual_seed(0)
-        CD, Lq = R + 2 * N, (H // 2) * (W // 2)
-        xc = (torch.randn(B, H, W, D, device="cuda") * 0.5).to(torch.bfloat16)
-        xw = (torch.randn(4, CD, D, device="cuda") * D ** -0.5).to(torch.bfloat16)
-        xdbl = torch.empty(4, B, Lq, CD, device="cuda")
-        dtw = ((torch.rand(4, D, R, device="cuda") * 2 - 1) * R ** -0.5)
-        dtb = torch.randn(4, D, device="cuda") * 0.5 - 3
-        A = -torch.exp(torch.log(torch.arange(1, N + 1, device="cuda").float())[None].repeat(4 * D, 1))
-        Ds = torch.ones(4 * D, device="cuda")
-        ws = torch.empty(L.lib().fd_scan_ws_floats(B, H, W, D, N), device="cuda")
-        fws = torch.empty(L.lib().fd_scan_fused_ws_floats(B, H, W, D, N, R), device="cuda")
-        y = torch.empty(B, H, W, D, device="cuda", dtype=torch.bfloat16)
-        y2 = torch.empty_like(y)
-
-        def run3():
-            L.call("fd_selective_scan_xproj", L.FD_BF16, xc.data_ptr(), xw.data_ptr(), xdbl.data_ptr(), dtw.data_ptr(),
-                   dtb.data_ptr(), A.data_ptr(), Ds.data_ptr(), y.data_ptr(), ws.data_ptr(), B, H, W, D, N, R, s)
-
-        def runf():
-            L.call("fd_selective_scan_fused", L.FD_BF16, xc.data_ptr(), xw.data_ptr(), dtw.data_ptr(), dtb.data_ptr(),
-                   A.data_ptr(), Ds.data_ptr(), y2.data_ptr(), fws.data_ptr(), B, H, W, D, N, R, s)
-        t3, tf = timeit(run3), timeit(runf)
-        err = float((y.float() - y2.float()).norm() / y.float().norm())
-        print(f"scan D={D} N={N} {H}x{W} B={B}: 3-phase {t3:8.1f} us, fused {tf:8.1f} us  (x{t3 / tf:.2f})  rel diff {err:.2e} "
-              f"timeout_word={int(fws[:2].view(torch.int32)[1])}", flush=True)
-
-
 def bench_attn(B, sizes=((512, 512), (256, 256))):
     """channel-attention branch of a 64-channel Mamba block: fused (qkv+dw+Gram) vs unfused (qkv+dw, Gram)"""
     from founddiff_amd import _lib as L

@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """Experiments on the two-stream production mode, all inside ONE process / one box:
-  * phase offset: sub-batch 1 starts a fraction of a UNet forward after sub-batch 0 (FOUNDDIFF_STREAM_OFFSET_US)
+  (the phase-offset experiment of round 4 -- sub-batch 1 started a fraction of a forward late through fd_stream_delay:
+   12.17 / 12.11 / 11.98 / 12.02 against 12.15 slices/s, profiles/r04_overlap_experiments.txt -- was removed with that entry point in round 5)
   * CU-masked streams: each sub-batch's stream restricted to a subset of the 256 CUs (hipExtStreamCreateWithCUMask)
   * stream counts 1 / 2 / 4
 Every configuration runs the real `ResidualDiffusion.sample()` of bench.py's workload (B = 16, 512x512, 50-step DDIM) and
-reports slices/s.        usage: overlap_experiments.py [reps] [what,...]   what in {offset, mask, streams}"""
+reports slices/s.        usage: overlap_experiments.py [reps] [what,...]   what in {mask, streams}"""
 import ctypes as C
 import json
 import os
@@ -18,7 +19,7 @@ import bench  # noqa: E402
 from founddiff_amd import synth  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-what = set((sys.argv[2] if len(sys.argv) > 2 else "offset,mask,streams").split(","))
+what = set((sys.argv[2] if len(sys.argv) > 2 else "mask,streams").split(","))
 dev = torch.device("cuda")
 B = 16
 dif, _ = bench.build_model(dev)
@@ -44,13 +45,7 @@ def run(label, **kw):
     return out
 
 
-ref = run("default: 2 streams, no offset", streams=2, stream_offset_us=0.0)
-fwd_us = 8 * 1700.0                        # ~ one batch-8 forward
-if "offset" in what:
-    for frac in (0.125, 0.25, 0.5, 0.75):
-        o = run(f"2 streams, offset {frac} forward ({frac * fwd_us:.0f} us)", streams=2, stream_offset_us=frac * fwd_us)
-        assert torch.equal(o, ref), "phase offset changed the result"
-    dif.stream_offset_us = 0.0
+ref = run("default: 2 streams", streams=2)
 if "streams" in what:
     run("1 stream (B = 16)", streams=1)
     run("4 streams (B = 4 each)", streams=4)
