@@ -208,6 +208,19 @@ def roofline_leg(dif, x, noise, t_measured_ms=None, clock_replay=True):
                       "launches_per_forward": len(part), "avg_launch_us": round(ms * 1e3 / len(part), 2),
                       "alg_gflop_per_launch": round(fl / 1e9 / len(part), 2),
                       "kernel_ms_per_forward": round(ms, 3)})
+    # the up-sampling 3x3 convolutions as four 2x2 convolutions on the source grid (conv3x3_halo_kernel<..., UP>, kernel id 14):
+    # priced with the FLOPs the kernel EXECUTES (4 taps per output; the reference's 9-tap form of the same sums is 2.25 x that)
+    up = [(n, a) for n, a in trace if n == "fd_conv2d" and lib.fd_conv_kernel_id(a[0]) == 14]
+    if up:
+        fl9 = sum(conv_flops(a[0]._obj) for _, a in up)
+        fl = fl9 * 4.0 / 9.0
+        ms = _time_launches(lib, up)
+        tf = fl / (ms * 1e-3) / 1e12
+        cands.append({"bound": "mfma", "kernel": "conv3x3_halo_kernel<128|64,8|16,false,UP> (up-sampling 3x3 as four 2x2 on the source grid)",
+                      "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4),
+                      "traffic": traffic.get("conv3x3_up_hbm_bytes_per_launch"), "launches_per_forward": len(up),
+                      "avg_launch_us": round(ms * 1e3 / len(up), 2), "alg_gflop_per_launch": round(fl / 1e9 / len(up), 2),
+                      "gflop_per_launch_of_the_9_tap_form": round(fl9 / 1e9 / len(up), 2), "kernel_ms_per_forward": round(ms, 3)})
     # 3x3 64 -> 64 with the weights resident in registers (conv3x3_rw_kernel): MFMA roofline like the halo kernel
     rw = [(n, a) for n, a in trace if n == "fd_conv2d" and lib.fd_conv_kernel_id(a[0]) == 13]
     if rw:

@@ -45,6 +45,7 @@ class ConvParams(C.Structure):
         ("fin_xin", vp), ("fin_alpha", f32),
         ("zre_w", vp), ("zre_gamma", vp), ("zre_beta", vp), ("zre_shift", vp), ("zre_scale", vp), ("zre_ld", i32),
         ("zre_eps", f32),
+        ("weight_up2x", vp),
     ]
 
 

@@ -74,8 +74,19 @@ __device__ __forceinline__ float row16_sum(float x) {
     return x;
 }
 
-template <int BN, int TH, bool F8>
+// UP (round 5): the nearest x2 up-sampling convolutions (`Upsample`: nn.Upsample(scale_factor=2) -> Conv2d 3x3, src/DADiff.py:121-127)
+// as FOUR 2x2 convolutions on the LOW-resolution input, one per output parity class (a, b) = (row & 1, column & 1): the three
+// taps of a 3x3 row / column fall on only TWO source pixels (a = 0: kh = 0 -> source row i - 1, kh = 1, 2 -> i; a = 1: kh = 0, 1
+// -> i, kh = 2 -> i + 1), so the taps that share a source pixel are summed into one weight at pack time (fp32, then one bf16
+// rounding): 4 MACs per output pixel, input and output channel instead of 9 -- the same sums in exact arithmetic, borders
+// included (a pixel the 3x3 reads from the zero padding is a source pixel outside the low-resolution image).  A workgroup owns a
+// LOW-resolution tile; its units are (class, slab) with 4 taps each, all classes read the same (TH + 2) x 18 source halo; the
+// weight matrix is [Cout][4 classes][2 x 2 taps][Cin] (fd_conv_params.weight_up2x).  With 4 taps per unit the 3-slot weight
+// ring no longer starts every unit at slot 0: the slot offsets so[] rotate by one per unit.
+template <int BN, int TH, bool F8, bool UP = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_params p, const int tpw, const int tiles_xy) {
+    static_assert(!(UP && F8), "the up-sampling form is bf16 only");
+    constexpr int NTAP = UP ? 4 : 9, NCLS = UP ? 4 : 1;
     constexpr int BM = TH * TW, HY = TH + 2, HP = HY * HX;
     constexpr int HL = (HP * 8 + 255) / 256;          // halo 16-byte LDS chunks per thread
     constexpr int SLABC = F8 ? 128 : 64;              // channels per K slab
@@ -94,16 +105,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
     __shared__ float s_stat[4][BN][2];
     __shared__ __attribute__((aligned(16))) float s_bias[BN], s_wsc[BN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tiles_x = p.OW / TW;
+    const int tiles_x = (UP ? p.W : p.OW) / TW;
     // a workgroup owns tpw consecutive tiles (row-major: neighbours share halo columns through L2) of image b,
     // channel tile nt
     const int t_begin = blockIdx.x * tpw, t_end = min(t_begin + tpw, tiles_xy);
     const int nt = blockIdx.y, b = blockIdx.z;
-    const int Cin = p.c0 + p.c1, K = 9 * Cin, nslab = Cin / SLABC;
-    const int Hs = p.OH, Ws = p.OW;                   // conv input grid == output grid (stride 1, pad 1)
+    const int Cin = p.c0 + p.c1, K = NTAP * NCLS * Cin, nslab = Cin / SLABC;
+    const int Hs = UP ? p.H : p.OH, Ws = UP ? p.W : p.OW;       // conv input grid == output grid (stride 1, pad 1); UP: the source grid
     const bf16 *in0 = (const bf16 *)p.in0 + (int64_t)b * p.H * p.W * p.ld0 + p.off0;
     const bf16 *in1 = p.in1 ? (const bf16 *)p.in1 + (int64_t)b * p.H * p.W * p.ld1 + p.off1 : nullptr;
-    const unsigned char *wgt = (const unsigned char *)(F8 ? p.weight_f8 : p.weight);
+    const unsigned char *wgt = (const unsigned char *)(UP ? p.weight_up2x : (F8 ? p.weight_f8 : p.weight));
 
     // ---- halo loader: chunk ids hid = tid + 256*i -> (halo pixel, 16-byte channel chunk)
     // Every load is issued (from a clamped in-image address, zeroed on the LDS store where it was
@@ -138,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
             y = min(max(y, 0), Hs - 1);
             x = min(max(x, 0), Ws - 1);
         }
-        if (p.upsample) { y >>= 1; x >>= 1; }
+        if constexpr (!UP) { if (p.upsample) { y >>= 1; x >>= 1; } }
         return y * p.W + x;
     };
     u32x4 rh[HL][HG];
@@ -234,11 +245,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
     // store (or any other VMEM operation) still in flight only makes a counted wait longer, never shorter.
     const unsigned lds_w = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)smem + HALO_B +
                            __builtin_amdgcn_readfirstlane(wave) * NB * 1024;
-    auto w_dma = [&](int slab, int tap, int buf) {
-        const char *wb = (const char *)(wgt + (tap * Cin + slab * SLABC) * ESZ);
+    // weight-ring slot (byte offset) of tap ct of the current unit, ct continuing into the next unit (ct >= NTAP): 9 taps
+    // start every unit at slot 0; with 4 taps per unit (UP) the offsets rotate by one slot per unit (rotated at the unit's end)
+    int so[3] = {0, WT_B, 2 * WT_B};
+    auto slot = [&](int ct) -> int {
+        if constexpr (UP) return so[ct % 3];
+        else return (ct % NWB) * WT_B;
+    };
+    auto w_dma = [&](int cls, int slab, int tap, int bufoff) {
+        const char *wb = (const char *)(wgt + (((UP ? 4 * cls : 0) + tap) * Cin + slab * SLABC) * ESZ);
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const unsigned dst = lds_w + buf * WT_B + i * 1024;       // wave-uniform: M0
+            const unsigned dst = lds_w + bufoff + i * 1024;           // wave-uniform: M0
             unsigned m0_saved;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\t"
                          "s_mov_b32 m0, %0"
@@ -259,7 +277,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
     // and the second K32 step of a 64-channel slab flips bit 6 of the swizzled chunk (chunk ^ 4).  Before,
     // the per-tap swizzle arithmetic cost 3.6 VALU instructions per MFMA (PMC) -- more than the 8 issue
     // cycles a 16x16x32 MFMA leaves free.
-    int aoff[6][3], boff[NT];
+    int aoff[UP ? 5 : 6][UP ? 2 : 3], boff[NT];
+    // UP: the four taps (r, c) of parity class (a, b) are the taps (a + r, b + c) of the 3x3 offset table: 5 x 2 offsets per class
+    auto set_class = [&](int cls) {
+        int tl = tid;
+        asm volatile("" : "+v"(tl));                  // (recomputed per class: not a tile-loop invariant worth 10 live registers)
+        const int a = cls >> 1, bq_ = cls & 1, fr_ = tl & 15, fg_ = (tl >> 4) & 3, wm_ = (tl >> 6) / WNW;
+#pragma unroll
+        for (int j = 0; j < (UP ? 5 : 6); ++j)
+#pragma unroll
+            for (int kw = 0; kw < (UP ? 2 : 3); ++kw) {
+                const int hp = (4 * wm_ + j + a) * HX + fr_ + kw + bq_;
+                aoff[j][kw] = hp * ROWB + swz<F8>(hp, F8 ? 2 * fg_ : fg_);  // F8: chunks 2 fg, 2 fg + 1 (= offset ^ 16)
+            }
+    };
+    if constexpr (UP) set_class(0);
+    else {
 #pragma unroll
     for (int j = 0; j < 6; ++j)
 #pragma unroll
@@ -267,6 +300,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
             const int hp = (4 * wm + j) * HX + fr + kw;
             aoff[j][kw] = hp * ROWB + swz<F8>(hp, F8 ? 2 * fg : fg);        // F8: chunks 2 fg, 2 fg + 1 (= offset ^ 16)
         }
+    }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int r = (BN / WNW) * wn + 16 * j + fr;
@@ -285,11 +319,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
         return o;
     };
     auto load_a = [&](int tap, int ks, int i) {
-        const int kh = tap / 3, kw = tap - kh * 3;
+        const int kh = UP ? tap >> 1 : tap / 3, kw = UP ? tap & 1 : tap - kh * 3;
         fa[i] = *(const bf16x8 *)(smem + koff(aoff[i + kh][kw], ks));              // pixel tile i = tile row 4 wm + i
     };
-    auto load_b = [&](int tap, int ks, bf16x8 (&bq)[NT]) {
-        const unsigned char *sB = smem + HALO_B + (tap % NWB) * WT_B;
+    auto load_b = [&](int ct, int ks, bf16x8 (&bq)[NT]) {                          // ct: slot() above
+        const unsigned char *sB = smem + HALO_B + slot(ct);
 #pragma unroll
         for (int j = 0; j < NT; ++j) bq[j] = *(const bf16x8 *)(sB + koff(boff[j], ks));
     };
@@ -312,9 +346,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
         s_wsc[tid] = (F8 && n < p.Cout) ? p.w_scale[n] / p.act_scale : 1.f;
     }
     int ty0 = (t_begin / tiles_x) * TH, tx0 = (t_begin % tiles_x) * TW;
-    w_dma(0, 0, 0);
-    w_dma(0, 1, 1);
-    if constexpr (!F8) w_dma(0, 2, 2);
+    w_dma(0, 0, 0, 0);
+    w_dma(0, 0, 1, WT_B);
+    if constexpr (!F8) w_dma(0, 0, 2, 2 * WT_B);
     halo_gload(0, ty0, tx0);
     halo_lstore();                                   // consumes the youngest loads: everything above has landed
     FD_WAIT_VM(0);
@@ -326,9 +360,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
     }
 
     for (int t = t_begin; t < t_end; ++t) {
-        const bool more_tiles = t + 1 < t_end;
-        const int tn = more_tiles ? t + 1 : t;
-        const int nty0 = (tn / tiles_x) * TH, ntx0 = (tn % tiles_x) * TW;
+        const bool more_tiles_t = t + 1 < t_end;
+        const int tn = more_tiles_t ? t + 1 : t;
+        const int nty0_t = (tn / tiles_x) * TH, ntx0_t = (tn % tiles_x) * TW;
+      for (int cls = 0; cls < NCLS; ++cls) {             // UP: the four output parity classes of the (low-resolution) tile
+        // what follows this (tile, class): the tile's next class (same halo), or the workgroup's next tile
+        const bool more_cls = UP && cls + 1 < NCLS;
+        const bool more_tiles = more_cls || more_tiles_t;                     // "another (tile, class) follows"
+        const int nty0 = more_cls ? ty0 : nty0_t, ntx0 = more_cls ? tx0 : ntx0_t;
+        const int ncls = more_cls ? cls + 1 : 0;
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -340,6 +380,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
             const bool last_slab = slab + 1 == nslab;
             const bool has_next = !last_slab || more_tiles;
             const int nslab_i = last_slab ? 0 : slab + 1;
+            const int ncls_i = last_slab ? ncls : cls;
             if constexpr (F8) {
                 const unsigned char *sH = smem;
 #pragma unroll
@@ -349,7 +390,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
                     if (tap == 0 && has_next) {                   // in flight during this slab's 9 taps
                         if (last_slab) halo_gload(0, nty0, ntx0); else halo_gload(slab + 1, ty0, tx0);
                     }
-                    if (dma) w_dma(tap + 2 < 9 ? slab : nslab_i, (tap + 2) % 9, (tap + 2) % NWB);
+                    if (dma) w_dma(0, tap + 2 < 9 ? slab : nslab_i, (tap + 2) % 9, ((tap + 2) % NWB) * WT_B);
                     const unsigned char *sB = smem + HALO_B + (tap % NWB) * WT_B;
                     const int kh = tap / 3, kw = tap - kh * 3;
                     // operands are 8 VGPRs each: the pixel fragments of the wave's 4 m-tiles stay live (32 VGPRs), the
@@ -398,8 +439,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
                 //               B reads(t+1, 0) | MFMA(t, 1) + A reads(t+1, 0)
                 // vmcnt order of a unit: ... DMA(2) | B_0 | DMA(3), next unit's halo loads | B_1 | DMA(4) | B_2 | DMA(5) ...
 #pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {
-                    const bool next_tile = tap + 1 < 9 || has_next;
+                for (int tap = 0; tap < NTAP; ++tap) {
+                    const bool next_tile = tap + 1 < NTAP || has_next;
                     load_b(tap, 1, fb[1]);
                     __builtin_amdgcn_sched_barrier(0);
                     half_step(fb[0], true, tap, 1);
@@ -408,31 +449,38 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
                         // loads; and this wave's reads of tile t have returned: all but the MT youngest LDS reads (the
                         // pixel fragments of (t, 1), from the halo).  A bare s_barrier: __syncthreads() would drain those
                         // as well, an LDS round trip in front of every barrier.
-                        const bool t2 = tap + 2 < 9 || has_next;
+                        const bool t2 = tap + 2 < NTAP || has_next;
                         const bool halo_young = has_next && (tap == 1 || tap == 2);
                         asm volatile("" ::: "memory");
-                        // (B_8 drains them too: behind it the halo buffer is overwritten -- next slab / C staging)
-                        if (tap == 8) { if (t2) FD_WAIT_VM_LGKM(NB, 0); else FD_WAIT_VM_LGKM(0, 0); }
+                        // (the unit's last barrier drains them too: behind it the halo buffer is overwritten -- next slab / C staging)
+                        if (tap == NTAP - 1) { if (t2) FD_WAIT_VM_LGKM(NB, 0); else FD_WAIT_VM_LGKM(0, 0); }
                         else if (t2) { if (halo_young) FD_WAIT_VM_LGKM(NB + HL * HG, MT); else FD_WAIT_VM_LGKM(NB, MT); }
                         else FD_WAIT_VM_LGKM(0, MT);
                         __builtin_amdgcn_s_barrier();
                         asm volatile("" ::: "memory");
-                        if (tap + 3 < 9 || has_next) w_dma(tap + 3 < 9 ? slab : nslab_i, (tap + 3) % 9, tap % NWB);
+                        if (tap + 3 < NTAP || has_next)
+                            w_dma(tap + 3 < NTAP ? cls : ncls_i, tap + 3 < NTAP ? slab : nslab_i, (tap + 3) % NTAP, slot(tap + 3));
                         if (tap == 0 && has_next) {               // in flight during this unit's taps
                             if (last_slab) halo_gload(0, nty0, ntx0); else halo_gload(slab + 1, ty0, tx0);
                         }
                     }
-                    if (tap < 8) {
+                    if (tap < NTAP - 1) {
                         load_b(tap + 1, 0, fb[0]);
                         __builtin_amdgcn_sched_barrier(0);
                         half_step(fb[1], true, tap + 1, 0);
                     } else if (!last_slab) {                      // every wave is done with this slab's halo
                         halo_lstore();
                         __syncthreads();
-                        load_b(0, 0, fb[0]);
+                        load_b(NTAP, 0, fb[0]);                   // tap 0 of the next unit
                         __builtin_amdgcn_sched_barrier(0);
                         half_step(fb[1], true, 0, 0);
                     } else half_step(fb[1], false, 0, 0);         // the tile's last MFMAs; the epilogue follows
+                }
+                if constexpr (UP) {                               // 4 taps per unit: the ring's phase moves on by one slot
+                    const int s0 = so[0];
+                    so[0] = so[1];
+                    so[1] = so[2];
+                    so[2] = s0;
                 }
             }
         }
@@ -553,8 +601,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
             if (n0 < p.Cout) {
                 // row r0 + 32 k is pixel (ty0 + r0 / 16 + 2 k, tx0 + r0 % 16): one 32-bit byte offset + a uniform step
                 // from the image's (wave-uniform) base
-                const unsigned step = 4u * (unsigned)p.OW * (unsigned)p.ldo;
-                unsigned ob = 2u * ((unsigned)((ty0 + (r0 >> 4)) * p.OW + tx0 + (r0 & 15)) * (unsigned)p.ldo + (unsigned)n0);
+                // (UP: tile pixel (i, j) of class (a, b) = (cls >> 1, cls & 1) is output pixel (2 i + a, 2 j + b))
+                const unsigned step = (UP ? 8u : 4u) * (unsigned)p.OW * (unsigned)p.ldo;
+                unsigned ob = UP ? 2u * ((unsigned)((2 * (ty0 + (r0 >> 4)) + (cls >> 1)) * p.OW + 2 * (tx0 + (r0 & 15)) + (cls & 1)) * (unsigned)p.ldo + (unsigned)n0)
+                                 : 2u * ((unsigned)((ty0 + (r0 >> 4)) * p.OW + tx0 + (r0 & 15)) * (unsigned)p.ldo + (unsigned)n0);
 #pragma unroll
                 for (int k = 0; k < RB; ++k, ob += step) *(u32x4 *)((char *)outp + ob) = cv[k];
             }
@@ -563,12 +613,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
             __syncthreads();                             // the next tile's halo is published
             ty0 = nty0;
             tx0 = ntx0;
+            if constexpr (UP) set_class(ncls);
             if constexpr (!F8) {
 #pragma unroll
                 for (int i = 0; i < MT; ++i) load_a(0, 0, i);
                 load_b(0, 0, fb[0]);
             }
         }
+      }
     }
 #undef FD_WAIT_VM
 #undef FD_WAIT_VM_LGKM
@@ -590,7 +642,7 @@ int fd_conv3x3_ok(const fd_conv_params &p) {
     // at <= 16384 pixels per image the generic tiles (64-row / 8-wave 128x256) fill the chip better
     if ((int64_t)p.OH * p.OW < 4096) return 0;
     if ((int64_t)p.H * p.W * (p.ld0 > p.ld1 ? p.ld0 : p.ld1) >= (1ll << 30)) return 0;   // 32-bit byte offsets
-    if ((int64_t)p.Cout * 9 * Cin >= (1ll << 30)) return 0;
+    if ((int64_t)p.Cout * 16 * Cin >= (1ll << 30)) return 0;
     if ((int64_t)p.OH * p.OW * p.ldo >= (1ll << 30)) return 0;
     return 1;
 }
@@ -603,8 +655,25 @@ int fd_conv3x3_fp8_ok(const fd_conv_params &p) {
     return (p.c0 + p.c1) % 128 == 0 && p.c0 % 16 == 0 && (p.in1 == nullptr || p.c1 % 16 == 0);
 }
 
+// 1 if `p` (an up-sampling 3x3 with its sub-pixel weight matrix, weight_up2x) runs as four 2x2 convolutions on the source grid
+int fd_conv3x3_up2x_ok(const fd_conv_params &p) {
+    static const bool off = getenv("FD_NO_CONV3_UP2X") != nullptr;    // development: the 9-tap form through the up-sampling index map
+    return !off && p.weight_up2x && p.upsample && !p.weight_f8 && !p.stats_partial && p.epilogue == FD_EPI_NONE &&
+           p.H % 8 == 0 && p.W % TW == 0 && fd_conv3x3_ok(p);
+}
+
 int fd_conv3x3_launch(const fd_conv_params &p, hipStream_t s) {
     const bool wide = p.Cout > 64;
+    if (fd_conv3x3_up2x_ok(p)) {
+        // tiles over the SOURCE grid; one tile per workgroup = 4 classes x Cin / 64 slabs of 4 taps
+        const int th = (!wide && p.H % 16 == 0) ? 16 : 8;
+        const int tiles_xy = (p.H / th) * (p.W / TW), gy = cdiv(p.Cout, wide ? 128 : 64);
+        dim3 grid(tiles_xy, gy, p.B), block(256);
+        if (wide) hipLaunchKernelGGL((conv3x3_halo_kernel<128, 8, false, true>), grid, block, 0, s, p, 1, tiles_xy);
+        else if (th == 16) hipLaunchKernelGGL((conv3x3_halo_kernel<64, 16, false, true>), grid, block, 0, s, p, 1, tiles_xy);
+        else hipLaunchKernelGGL((conv3x3_halo_kernel<64, 8, false, true>), grid, block, 0, s, p, 1, tiles_xy);
+        return 0;
+    }
     static const bool th8 = getenv("FD_CONV3_TH8") != nullptr;        // development: 8-row tiles for Cout <= 64 too
     const int th = (!wide && p.OH % 16 == 0 && !th8) ? 16 : 8;
     const int tiles_xy = (p.OH / th) * (p.OW / TW), gy = cdiv(p.Cout, wide ? 128 : 64);

@@ -35,7 +35,7 @@ def _po(t, off_elems):
 class ConvW:
     """Packed convolution / linear weight: [Cout][KH*KW*Cin] in the compute dtype, fp32 bias."""
 
-    def __init__(self, w_oihw, bias, dev, tdt, cin_pad=None, fp8=False):
+    def __init__(self, w_oihw, bias, dev, tdt, cin_pad=None, fp8=False, up2x=False):
         w = w_oihw.detach().float()
         if w.dim() == 2:
             w = w[:, :, None, None]
@@ -47,12 +47,31 @@ class ConvW:
         wk = w.permute(0, 2, 3, 1).reshape(o, kh * kw * i).contiguous()
         self.w = wk.to(dev, tdt)
         self.b = bias.detach().float().contiguous().to(dev) if bias is not None else None
-        self.w8 = self.ws = None
+        self.w8 = self.ws = self.w_up = None
+        if up2x and kh == 3 and kw == 3 and tdt == torch.bfloat16 and not fp8 and cin_pad is None:
+            self.w_up = pack_up2x(w).to(dev, tdt)          # the up-sampling convs as four 2x2 convs on the source grid
         if fp8 and kh == 3 and kw == 3 and i % 128 == 0:
             # per-output-channel scaled OCP e4m3 (largest finite value 448): w ~= w8 * ws[n]
             ws = (wk.abs().amax(dim=1).clamp(min=1e-12) / 448.0)
             self.w8 = (wk / ws[:, None]).to(torch.float8_e4m3fn).contiguous().to(dev)
             self.ws = ws.contiguous().to(dev)
+
+
+def pack_up2x(w_oihw):
+    """3x3 weights (O, I, 3, 3) of an up-sampling convolution (nn.Upsample(scale_factor=2, nearest) -> Conv2d, src/DADiff.py:121-127)
+    -> the sub-pixel matrix [O][cls = 2 a + b][r][c][I] of include/founddiff_hip.h (fd_conv_params.weight_up2x): the 3x3 taps that
+    read the same SOURCE pixel from output parity (a, b) summed in fp32 (a = 0: rows {0}, {1, 2}; a = 1: rows {0, 1}, {2};
+    columns likewise).  Four 2x2 convolutions on the source grid = the same sums with 4 instead of 9 MACs per output."""
+    w = w_oihw.detach().float()
+    o, i = w.shape[:2]
+    sets = {0: ([0], [1, 2]), 1: ([0, 1], [2])}
+    out = w.new_zeros(o, 4, 2, 2, i)
+    for a in (0, 1):
+        for b in (0, 1):
+            for r in (0, 1):
+                for c in (0, 1):
+                    out[:, 2 * a + b, r, c] = w[:, :, sets[a][r]][:, :, :, sets[b][c]].sum(dim=(2, 3))
+    return out.reshape(o, 16 * i).contiguous()
 
 
 def ws_standardize(w, eps=1e-5):
@@ -120,8 +139,8 @@ class DAEngine:
     def _f(self, t):
         return t.detach().float().contiguous().to(self.dev)
 
-    def _convw(self, w, b=None, cin_pad=None):
-        return ConvW(w, b, self.dev, self.tdt, cin_pad, fp8=getattr(self, "fp8", False))
+    def _convw(self, w, b=None, cin_pad=None, up2x=False):
+        return ConvW(w, b, self.dev, self.tdt, cin_pad, fp8=getattr(self, "fp8", False), up2x=up2x)
 
     def _pack_res(self, s):
         r = {"conv": self._convw(ws_standardize(s["block1.proj.weight"]), s["block1.proj.bias"]),
@@ -235,7 +254,7 @@ class DAEngine:
             up = s.has("2.1.weight")
             w, b = (s["2.1.weight"], s["2.1.bias"]) if up else (s["2.weight"], s["2.bias"])
             self.ups.append(dict(res=self._pack_res(s.sub("0.")), mamba=self._pack_mamba(s.sub("1.")),
-                                 samp=self._convw(w, b), up=up))
+                                 samp=self._convw(w, b, up2x=up), up=up))
             i += 1
         self.final_res = self._pack_res(sd.sub("final_res_block."))
         fw = sd["final_conv.weight"]
@@ -373,6 +392,8 @@ class DAEngine:
             p.fin_alpha = float(fin.get("alpha", 0.0))
         if weight is None and cw is not None and getattr(cw, "w8", None) is not None:
             p.weight_f8, p.w_scale, p.act_scale = cw.w8.data_ptr(), cw.ws.data_ptr(), FP8_ACT_SCALE
+        if upsample and weight is None and cw is not None and getattr(cw, "w_up", None) is not None:
+            p.weight_up2x = cw.w_up.data_ptr()
         if probe == "kid":          # which kernel would run (include/founddiff_hip.h: fd_conv_kernel_id)
             return int(L.lib().fd_conv_kernel_id(C.byref(p)))
         if probe:

@@ -132,6 +132,13 @@ typedef struct fd_conv_params {
     const float *zre_shift, *zre_scale;/* entries [b*zre_ld + c]                                                  */
     int32_t zre_ld;
     float zre_eps;
+    /* Up-sampling 3x3 convolutions (`upsample` = 1, KH = KW = 3: nn.Upsample(scale_factor=2, nearest) -> Conv2d,
+     * src/DADiff.py:121-127) as four 2x2 convolutions on the source grid, one per output parity class (round 5, bf16 halo
+     * kernel): weight_up2x[n][cls][r][c][ci], cls = 2 a + b for output pixel (2 i + a, 2 j + b), tap (r, c) reads source pixel
+     * (i + a + r - 1, j + b + c - 1) with the weights of the 3x3 taps that fall on that pixel summed (a = 0: r = 0 <- kh 0,
+     * r = 1 <- kh 1 + 2; a = 1: r = 0 <- kh 0 + 1, r = 1 <- kh 2; columns likewise), i.e. [Cout][16 * Cin] in dtype.  The same
+     * convolution in exact arithmetic with 4 instead of 9 MACs per output.  NULL: the 9-tap form.  Other convs ignore it. */
+    const void *weight_up2x;
 } fd_conv_params;
 
 /* 1 if fd_conv2d would run `p` (weight_f8 / w_scale set) on the fp8 MFMA path.                        */

@@ -145,3 +145,47 @@ def test_ln_rows_with_common_offset():
         err = float((out.float().cpu().double() - ref).abs().max() / ref.abs().max())
         print(f"ln rows offset {off} sd {sd} {tdt}: max-rel {err:.2e}")
         assert err < tol, (off, sd, tdt, err)
+
+
+@pytest.mark.parametrize("cfg", [dict(cin=128, cout=64, hw=(32, 32)),       # <64, 16, up>: u2s of the shipped architecture
+                                 dict(cin=128, cout=64, hw=(40, 48)),       # <64, 8, up>: source rows not a multiple of 16
+                                 dict(cin=256, cout=128, hw=(32, 48)),      # <128, 8, up>: u1s
+                                 dict(cin=192, cout=200, hw=(32, 48)),      # three slabs, a ragged channel tile
+                                 dict(cin=512, cout=256, hw=(64, 64))])     # u0s at its real size: 8 slabs x 4 classes per workgroup
+def test_conv3x3_upsample_as_four_2x2(cfg):
+    """nn.Upsample(scale_factor=2, nearest) -> Conv2d 3x3 (src/DADiff.py:121-127) as four 2x2 convolutions on the source grid
+    (conv3x3_halo_kernel<..., UP>, kernel id 14, fd_conv_params.weight_up2x): against torch on the up-sampled image with the
+    fp32 weights the sub-pixel matrix was summed from, against the 9-tap halo kernel on the same operands, borders included,
+    and bit for bit repeatable (the weight ring's slot rotation and counted waits are manual)."""
+    import ctypes as C
+    from founddiff_amd import _lib as L
+    from founddiff_amd.engine import ConvW
+    from test_gpu_e2e import bare_engine, nhwc, nchw
+    e = bare_engine("bf16")
+    torch.manual_seed(31)
+    B, (H, W), cin, cout = 2, cfg["hw"], cfg["cin"], cfg["cout"]
+    x = torch.randn(B, cin, H, W).to(torch.bfloat16).float()
+    w = torch.randn(cout, cin, 3, 3) / (3 * cin ** 0.5)
+    bias = torch.randn(cout)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, bias, padding=1)
+    cw9 = ConvW(w, bias, e.dev, e.tdt)
+    cw4 = ConvW(w, bias, e.dev, e.tdt, up2x=True)
+    assert cw9.w_up is None and tuple(cw4.w_up.shape) == (cout, 16 * cin)
+    xa = nhwc(x, e.tdt)
+    o9 = torch.empty(B, 2 * H, 2 * W, cout, device="cuda", dtype=e.tdt)
+    o4 = torch.full_like(o9, float("nan"))
+    assert e.conv(cw9, xa, B, H, W, o9, upsample=True, probe="kid") == 11
+    assert e.conv(cw4, xa, B, H, W, o4, upsample=True, probe="kid") == 14
+    e.conv(cw9, xa, B, H, W, o9, upsample=True)
+    e.conv(cw4, xa, B, H, W, o4, upsample=True)
+    torch.cuda.synchronize()
+    e9, e4 = rel_err(nchw(o9), ref), rel_err(nchw(o4), ref)
+    print(f"up-sampling conv {cin} -> {cout} @ {H}x{W} -> {2 * H}x{2 * W}: 9-tap max-rel {e9:.2e}, 4 x 2x2 {e4:.2e}")
+    assert torch.isfinite(o4.float()).all()
+    assert e4 < 1.2e-2 and e4 < 1.5 * e9 + 1e-3                  # the tolerance of test_conv3x3_halo; no worse than the 9-tap form
+    first = o4.clone()
+    for _ in range(8):
+        o4.zero_()
+        e.conv(cw4, xa, B, H, W, o4, upsample=True)
+        torch.cuda.synchronize()
+        assert torch.equal(o4, first)

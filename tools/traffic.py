@@ -38,6 +38,12 @@ def fam(prefix):
     return round(sum(per[k]["hbm_bytes_per_launch"] * per[k]["n"] for k in ks) / n) if n else None
 
 
+def fam_re(pat):
+    ks = [k for k in per if re.match(pat, k)]
+    n = sum(per[k]["n"] for k in ks)
+    return round(sum(per[k]["hbm_bytes_per_launch"] * per[k]["n"] for k in ks) / n) if n else None
+
+
 import glob as _g, hashlib, os
 _h = hashlib.sha256()
 for _f in sorted(_g.glob(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "founddiff_amd", "csrc", "*"))):
@@ -56,6 +62,7 @@ res = {"note": __doc__.strip(),
        "conv3x3_rw_hbm_bytes_per_launch": fam("conv3x3_rw_kernel"),
        "dwconv3x3_bf16_hbm_bytes_per_launch": fam("dwconv3x3_bf16_kernel"),
        "conv3x3_halo_hbm_bytes_per_launch": fam("conv3x3_halo_kernel"),
+       "conv3x3_up_hbm_bytes_per_launch": fam_re(r"conv3x3_halo_kernel<\d+, \d+, false, true>"),
        "per_kernel": per}
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps({k: v for k, v in res.items() if k.endswith("per_launch")}))
