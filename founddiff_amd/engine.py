@@ -712,8 +712,11 @@ class DAEngine:
         linear; ~75 us of latency-bound work in front of every forward -- become five launches per LOOP on S * B rows.
         Every row is computed by itself (fd_linear: one wave per output feature, rows in turn): bit for bit the vectors
         time_cond produces.  forward(..., step=s) takes its vectors from the table."""
+        if getattr(self, "_tab_S", None) is None:
+            raise RuntimeError("time_cond_table(): call time_table_prepare(times, B) first (it owns the host -> device copy)")
         S, B = self._tab_S, self._tab_B
-        assert self.prompt_emb.shape[0] == B
+        if self.prompt_emb.shape[0] != B:
+            raise RuntimeError(f"time_cond_table(): the table was prepared for batch {B}, the conditioning holds {self.prompt_emb.shape[0]} slices")
         M = S * B
         s = self.stream
         tv = self._b(f"tab_time_{S}x{B}", (M,), torch.float32)
@@ -726,6 +729,7 @@ class DAEngine:
         torch.add(t.view(S, B, self.time_dim), self.prompt_emb[None], out=tt.view(S, B, self.time_dim))
         self.mod_tab = self.linear(tt, self.adaln_w, self.adaln_b, self._b("mod_tab", (M, self.mod_total), torch.float32),
                                    pre_silu=True)
+        self._mod_tab_shape = (S, B)            # forward(step=) checks its batch and step against this
 
     def forward(self, x_t, x_in, time, out=None, x_cond2=None, sched=None, step=None):
         """x_t, x_in: (B,1,H,W) fp32 device tensors in [-1,1]; time (B,) fp32.  Returns the raw
@@ -744,6 +748,11 @@ class DAEngine:
         if step is None:
             self.time_cond(time)
         else:                                   # vectors of loop step `step` from time_cond_table()
+            tab = getattr(self, "_mod_tab_shape", None)
+            if tab is None:
+                raise RuntimeError("forward(step=...): no adaLN table -- call time_table_prepare() and time_cond_table() first")
+            if tab[1] != B or not 0 <= int(step) < tab[0]:
+                raise RuntimeError(f"forward(step={step}) on a batch of {B}: the adaLN table holds {tab[0]} steps x {tab[1]} slices")
             self.mod_all = self.mod_tab[step * B:(step + 1) * B]
         r = self._head(x_t, x_in, x_cond2)
         x, h, w = r, H, W
@@ -763,6 +772,8 @@ class DAEngine:
         the outer levels, where most of the bf16 drift of the returned image originates, bf16 below).  `down_levels`
         (default = outer_levels) < outer_levels keeps part of the encoder on `inner`; its skips are cast on their way
         into this engine's up stages."""
+        # (no `step` argument on purpose: the hybrid forward always computes its adaLN vectors from `time` on both engines --
+        #  it runs once per loop, a table would save nothing)
         B, _, H, W = x_t.shape
         nd, nu = len(self.downs), len(self.ups)
         ku = outer_levels

@@ -45,8 +45,14 @@ def main():
     dist.barrier()
     # the ancestral sampler over the same shards: step noise keyed by the global slice index
     vol_a = parallel.sample_volume(build(dev, ancestral=True), torch.from_numpy(ld), world=world, rank=rank, noise_seed=100, batch=2)
+    # what RCCL itself saw: an all-reduce of ones = the number of ranks in the communicator, and the devices they ran on
+    ones = torch.ones(1, device=dev)
+    dist.all_reduce(ones)
+    devs = [None] * world
+    dist.all_gather_object(devs, torch.cuda.current_device())
     if rank == 0:
-        torch.save({"ddim": vol.cpu(), "ancestral": vol_a.cpu()}, out_path)
+        torch.save({"ddim": vol.cpu(), "ancestral": vol_a.cpu(), "world": world, "allreduce_ones": float(ones.item()),
+                    "devices": devs, "backend": dist.get_backend()}, out_path)
     dist.destroy_process_group()
 
 

@@ -36,6 +36,11 @@ def test_sample_volume_over_nccl(tmp_path):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     got = torch.load(out)
+    # the run really used `world` ranks over RCCL: on the first multi-GPU box that sees this test, 2 ranks on 2 devices
+    assert got["world"] == world and got["allreduce_ones"] == float(world) and got["backend"] == "nccl"
+    assert sorted(got["devices"]) == list(range(world)), got["devices"]
+    if torch.cuda.device_count() >= 2:
+        assert world == 2 and len(set(got["devices"])) == 2
     _, ld = synth.ct_phantom(n, 64, seed=10)
     for name, anc, batch in (("ddim", False, 2), ("ancestral", True, 3)):
         # the single-process reference runs with ANOTHER batch composition for the ancestral sampler (3 + 2 instead of
