@@ -34,7 +34,7 @@ def mode(b):
     B = b["config"]["slices_per_gpu_per_step"]
     steps = int(b["metric"].split(",")[1].split()[0])
     t_fwd8 = b["ms_per_step"] * 1e-3 / steps / (B / 8)          # seconds per batch-8 forward's worth of work
-    box = b.get("box_during_timed_region") or {}
+    box = b.get("box_during_untimed_replay") or b.get("box_during_timed_region") or {}
     clk = (box.get("sclk_mhz_mean") or 2400.0) * 1e6
     cyc = t_fwd8 * clk
     return {"slices_per_s": b["value"], "t_fwd8_ms": t_fwd8 * 1e3, "sclk_mhz": clk / 1e6, "power_w": box.get("socket_power_w_mean"),
