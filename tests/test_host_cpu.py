@@ -223,3 +223,18 @@ def test_inspect_checkpoint_tool(tmp_path):
     torch.save(iqa, tmp_path / "Dose-CLIP.pth")
     rep = ic.inspect_dose_clip(str(tmp_path / "Dose-CLIP.pth"), clip=clip)
     assert not rep["ok"] and rep["missing"] == ["dose_encoder.head1.0.weight"]
+
+
+def test_inline_asm_mfma_drains_in_the_isa():
+    """Kernels whose MFMAs are inline asm wait out the last results behind an s_nop block the accumulators are tied to
+    (FD_MFMA_ASM_DRAIN, csrc/fd_common.h).  The ISA is checked as well (tools/kres.py --check-drain, hipcc cross-compiles
+    without a GPU): no VALU instruction reads an MFMA destination between the last v_mfma and the drain block."""
+    import shutil
+    import subprocess
+    import sys
+    if not shutil.which("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    files = [os.path.join(ROOT, "founddiff_amd", "csrc", f) for f in ("fd_conv3x3_rw.hip", "fd_downfuse.hip", "fd_pwgemm.hip", "fd_conv3x3.hip")]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kres.py"), "--check-drain"] + files, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.stdout.count("0 early read(s)") == 4, r.stdout
