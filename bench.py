@@ -592,17 +592,14 @@ def main():
     # shader clock / socket power of this workload on this box: sampled over an identical UNTIMED replay of the timed region
     # (rocm-smi forked every 0.4 s from a host thread: host contention and SMU queries stay out of the headline number)
     smi = None
-    if not a.no_smi:                    # every rank replays (step() ends in a collective); rank 0 samples
-        if rank == 0:
-            smi = SmiSampler()
-            smi.__enter__()
+    if not a.no_smi and world == 1:     # (single-GPU runs only: the multi-rank path stays exactly the timed region + its reduction)
+        smi = SmiSampler()
+        smi.__enter__()
         for _ in range(max(1, min(a.steps, 3))):
             step()
         torch.cuda.synchronize()
-        if smi:
-            smi.__exit__()
+        smi.__exit__()
     if world > 1:
-        dist.barrier()
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())

@@ -34,4 +34,6 @@ python3 tools/stage_times.py --batches 8 --detail > $OUT/stage_detail_b8.md 2> /
 # keep only the summaries (the raw traces are large)
 find $OUT -name "*_kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*agent_info.csv" -delete
 timeout 3000 python3 -m pytest tests -m gpu -q > $OUT/pytest_gpu.txt 2>&1; tail -2 $OUT/pytest_gpu.txt
+python3 -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1; tail -3 $OUT/smoke.txt
+FOUNDDIFF_LOW_LATENCY=1 python3 tools/forward_table.py --batch 1 > $OUT/forward_launches_b1_low_latency.md 2> /dev/null
 ls -la $OUT; cat $OUT/pmc_two_stream.md; cat $OUT/traffic_summary.txt
