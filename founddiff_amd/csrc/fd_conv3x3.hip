@@ -108,7 +108,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
     const int tiles_x = (UP ? p.W : p.OW) / TW;
     // a workgroup owns tpw consecutive tiles (row-major: neighbours share halo columns through L2) of image b,
     // channel tile nt
-    const int t_begin = blockIdx.x * tpw, t_end = min(t_begin + tpw, tiles_xy);
+    // UP: `tpw` is the number of parity classes per workgroup instead (4: one workgroup per tile; 1: a workgroup per (tile, class) --
+    // the one-slice kernel set, where a low-resolution tile grid alone is 64..256 workgroups), one tile per workgroup
+    const int cpw = UP ? tpw : 1, cls_begin = UP ? (int)(blockIdx.x % (NCLS / cpw)) * cpw : 0, cls_end = UP ? cls_begin + cpw : 1;
+    const int t_begin = UP ? (int)(blockIdx.x / (NCLS / cpw)) : blockIdx.x * tpw, t_end = UP ? t_begin + 1 : min(t_begin + tpw, tiles_xy);
     const int nt = blockIdx.y, b = blockIdx.z;
     const int Cin = p.c0 + p.c1, K = NTAP * NCLS * Cin, nslab = Cin / SLABC;
     const int Hs = UP ? p.H : p.OH, Ws = UP ? p.W : p.OW;       // conv input grid == output grid (stride 1, pad 1); UP: the source grid
@@ -291,7 +294,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
                 aoff[j][kw] = hp * ROWB + swz<F8>(hp, F8 ? 2 * fg_ : fg_);  // F8: chunks 2 fg, 2 fg + 1 (= offset ^ 16)
             }
     };
-    if constexpr (UP) set_class(0);
+    if constexpr (UP) set_class(cls_begin);
     else {
 #pragma unroll
     for (int j = 0; j < 6; ++j)
@@ -346,9 +349,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
         s_wsc[tid] = (F8 && n < p.Cout) ? p.w_scale[n] / p.act_scale : 1.f;
     }
     int ty0 = (t_begin / tiles_x) * TH, tx0 = (t_begin % tiles_x) * TW;
-    w_dma(0, 0, 0, 0);
-    w_dma(0, 0, 1, WT_B);
-    if constexpr (!F8) w_dma(0, 0, 2, 2 * WT_B);
+    w_dma(cls_begin, 0, 0, 0);
+    w_dma(cls_begin, 0, 1, WT_B);
+    if constexpr (!F8) w_dma(cls_begin, 0, 2, 2 * WT_B);
     halo_gload(0, ty0, tx0);
     halo_lstore();                                   // consumes the youngest loads: everything above has landed
     FD_WAIT_VM(0);
@@ -363,9 +366,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
         const bool more_tiles_t = t + 1 < t_end;
         const int tn = more_tiles_t ? t + 1 : t;
         const int nty0_t = (tn / tiles_x) * TH, ntx0_t = (tn % tiles_x) * TW;
-      for (int cls = 0; cls < NCLS; ++cls) {             // UP: the four output parity classes of the (low-resolution) tile
+      for (int cls = cls_begin; cls < cls_end; ++cls) {  // UP: the workgroup's output parity classes of the (low-resolution) tile
         // what follows this (tile, class): the tile's next class (same halo), or the workgroup's next tile
-        const bool more_cls = UP && cls + 1 < NCLS;
+        const bool more_cls = UP && cls + 1 < cls_end;
         const bool more_tiles = more_cls || more_tiles_t;                     // "another (tile, class) follows"
         const int nty0 = more_cls ? ty0 : nty0_t, ntx0 = more_cls ? tx0 : ntx0_t;
         const int ncls = more_cls ? cls + 1 : 0;
@@ -670,10 +673,14 @@ int fd_conv3x3_launch(const fd_conv_params &p, hipStream_t s) {
         // tiles over the SOURCE grid; one tile per workgroup = 4 classes x Cin / 64 slabs of 4 taps
         const int th = (!wide && p.H % 16 == 0) ? 16 : 8;              // (8-row tiles at Cout <= 64 measured 221 -> 224 us: no)
         const int tiles_xy = (p.H / th) * (p.W / TW), gy = cdiv(p.Cout, wide ? 128 : 64);
-        dim3 grid(tiles_xy, gy, p.B), block(256);
-        if (wide) hipLaunchKernelGGL((conv3x3_halo_kernel<128, 8, false, true>), grid, block, 0, s, p, 1, tiles_xy);
-        else if (th == 16) hipLaunchKernelGGL((conv3x3_halo_kernel<64, 16, false, true>), grid, block, 0, s, p, 1, tiles_xy);
-        else hipLaunchKernelGGL((conv3x3_halo_kernel<64, 8, false, true>), grid, block, 0, s, p, 1, tiles_xy);
+        // classes per workgroup: 4 (the four classes of a tile share its workgroup), or 1 when the caller asks for the
+        // class-parallel grid (`upsample` = 2: the one-slice kernel set; any split gives the same bits)
+        static const int cpw_env = [] { const char *e = getenv("FD_CONV3_UP_CPW"); return e ? atoi(e) : 0; }();     // development
+        const int cpw = (cpw_env == 1 || cpw_env == 2 || cpw_env == 4) ? cpw_env : (p.upsample == 2 ? 1 : 4);
+        dim3 grid(tiles_xy * (4 / cpw), gy, p.B), block(256);
+        if (wide) hipLaunchKernelGGL((conv3x3_halo_kernel<128, 8, false, true>), grid, block, 0, s, p, cpw, tiles_xy);
+        else if (th == 16) hipLaunchKernelGGL((conv3x3_halo_kernel<64, 16, false, true>), grid, block, 0, s, p, cpw, tiles_xy);
+        else hipLaunchKernelGGL((conv3x3_halo_kernel<64, 8, false, true>), grid, block, 0, s, p, cpw, tiles_xy);
         return 0;
     }
     static const bool th8 = getenv("FD_CONV3_TH8") != nullptr;        // development: 8-row tiles for Cout <= 64 too

@@ -392,11 +392,13 @@ class DAEngine:
             p.fin_alpha = float(fin.get("alpha", 0.0))
         if weight is None and cw is not None and getattr(cw, "w8", None) is not None:
             p.weight_f8, p.w_scale, p.act_scale = cw.w8.data_ptr(), cw.ws.data_ptr(), FP8_ACT_SCALE
-        # (not in the one-slice kernel set: a low-resolution tile grid is 4 x fewer workgroups -- 64..256 for a lone 512x512 slice --
-        #  and the 9-tap form fills the chip better: 150.8 against 146.3 ms per 50-step slice at batch 1, profiles/r05/latency_b1_sweep.txt)
-        if (upsample and weight is None and cw is not None and getattr(cw, "w_up", None) is not None
-                and not getattr(self, "low_latency", False)):
+        # (the one-slice kernel set asks for one workgroup per (tile, parity class) -- `upsample` = 2: a low-resolution tile grid
+        #  alone is 64..256 workgroups for a lone 512x512 slice, 150.8 against 146.3 ms per 50-step slice with the 9-tap form,
+        #  profiles/r05/latency_b1_sweep.txt; any split gives the same bits)
+        if upsample and weight is None and cw is not None and getattr(cw, "w_up", None) is not None:
             p.weight_up2x = cw.w_up.data_ptr()
+            if getattr(self, "low_latency", False):
+                p.upsample = 2
         if probe == "kid":          # which kernel would run (include/founddiff_hip.h: fd_conv_kernel_id)
             return int(L.lib().fd_conv_kernel_id(C.byref(p)))
         if probe:

@@ -137,7 +137,9 @@ typedef struct fd_conv_params {
      * kernel): weight_up2x[n][cls][r][c][ci], cls = 2 a + b for output pixel (2 i + a, 2 j + b), tap (r, c) reads source pixel
      * (i + a + r - 1, j + b + c - 1) with the weights of the 3x3 taps that fall on that pixel summed (a = 0: r = 0 <- kh 0,
      * r = 1 <- kh 1 + 2; a = 1: r = 0 <- kh 0 + 1, r = 1 <- kh 2; columns likewise), i.e. [Cout][16 * Cin] in dtype.  The same
-     * convolution in exact arithmetic with 4 instead of 9 MACs per output.  NULL: the 9-tap form.  Other convs ignore it. */
+     * convolution in exact arithmetic with 4 instead of 9 MACs per output.  NULL: the 9-tap form.  Other convs ignore it.
+     * `upsample` = 2 (otherwise the same as 1) asks for one workgroup per (tile, parity class) instead of per tile: four times
+     * the workgroups for a batch that does not fill the chip; the results are the same bits.                                 */
     const void *weight_up2x;
 } fd_conv_params;
 

@@ -189,3 +189,10 @@ def test_conv3x3_upsample_as_four_2x2(cfg):
         e.conv(cw4, xa, B, H, W, o4, upsample=True)
         torch.cuda.synchronize()
         assert torch.equal(o4, first)
+    # the class-parallel grid of the one-slice kernel set (`upsample` = 2: a workgroup per (tile, parity class)): the same bits
+    e.low_latency = True
+    o1 = torch.full_like(o4, float("nan"))
+    e.conv(cw4, xa, B, H, W, o1, upsample=True)
+    torch.cuda.synchronize()
+    e.low_latency = False
+    assert torch.equal(o1, first)
