@@ -46,6 +46,7 @@ class ConvParams(C.Structure):
         ("zre_w", vp), ("zre_gamma", vp), ("zre_beta", vp), ("zre_shift", vp), ("zre_scale", vp), ("zre_ld", i32),
         ("zre_eps", f32),
         ("weight_up2x", vp),
+        ("weight_split_hi", vp), ("weight_split_lo", vp),
     ]
 
 

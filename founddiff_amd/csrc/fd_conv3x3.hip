@@ -83,14 +83,22 @@ __device__ __forceinline__ float row16_sum(float x) {
 // LOW-resolution tile; its units are (class, slab) with 4 taps each, all classes read the same (TH + 2) x 18 source halo; the
 // weight matrix is [Cout][4 classes][2 x 2 taps][Cin] (fd_conv_params.weight_up2x).  With 4 taps per unit the 3-slot weight
 // ring no longer starts every unit at slot 0: the slot offsets so[] rotate by one per unit.
-template <int BN, int TH, bool F8, bool UP = false>
+// SPL (round 5; fp32 storage, the `fp32s` engine: the last step's outer levels and the parity-grade mode): the split-bf16
+// contraction of fd_conv.hip on this kernel.  x = x_hi + x_lo, w = w_hi + w_lo in bf16; per 64-channel slab THREE units of 9
+// taps accumulate x_hi.w_hi + x_hi.w_lo + x_lo.w_hi into the same fp32 accumulators (4.4e-6 per contraction against the
+// exact-f32 MFMA): the fp32 halo (32 bytes per 8 channels: two loads per chunk, like the fp8 form) is converted to its hi or lo
+// halves on its way into LDS, the weights come pre-split as two bf16 matrices (weight_split_hi / _lo), the LDS image, the ring
+// and the tap loop are the bf16 ones.  fp32 output straight from the accumulators (a lane holds 8 consecutive channels of a
+// pixel = 32 bytes; the four lane groups of a pixel fill a 128-byte line), GroupNorm partial sums as in the bf16 form.
+template <int BN, int TH, bool F8, bool UP = false, bool SPL = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_params p, const int tpw, const int tiles_xy) {
     static_assert(!(UP && F8), "the up-sampling form is bf16 only");
+    static_assert(!(SPL && (F8 || UP)), "the split form: fp32 storage, 9 taps");
     constexpr int NTAP = UP ? 4 : 9, NCLS = UP ? 4 : 1;
     constexpr int BM = TH * TW, HY = TH + 2, HP = HY * HX;
     constexpr int HL = (HP * 8 + 255) / 256;          // halo 16-byte LDS chunks per thread
     constexpr int SLABC = F8 ? 128 : 64;              // channels per K slab
-    constexpr int HG = F8 ? 2 : 1;                    // 16-byte global loads per LDS chunk
+    constexpr int HG = (F8 || SPL) ? 2 : 1;           // 16-byte global loads per LDS chunk
     constexpr int ESZ = F8 ? 1 : 2;                   // bytes per weight element
     constexpr int WMW = TH / 4, WNW = 4 / WMW;        // wave grid
     constexpr int NB = BN / 32, NT = BN / WNW / 16, MT = 4;
@@ -113,11 +121,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
     const int cpw = UP ? tpw : 1, cls_begin = UP ? (int)(blockIdx.x % (NCLS / cpw)) * cpw : 0, cls_end = UP ? cls_begin + cpw : 1;
     const int t_begin = UP ? (int)(blockIdx.x / (NCLS / cpw)) : blockIdx.x * tpw, t_end = UP ? t_begin + 1 : min(t_begin + tpw, tiles_xy);
     const int nt = blockIdx.y, b = blockIdx.z;
-    const int Cin = p.c0 + p.c1, K = NTAP * NCLS * Cin, nslab = Cin / SLABC;
+    // (SPL: three units per 64-channel slab -- the "slab" index below is 3 * slab + part, part 0: x_hi.w_hi, 1: x_hi.w_lo, 2: x_lo.w_hi)
+    const int Cin = p.c0 + p.c1, K = NTAP * NCLS * Cin, nslab = (SPL ? 3 : 1) * (Cin / SLABC);
     const int Hs = UP ? p.H : p.OH, Ws = UP ? p.W : p.OW;       // conv input grid == output grid (stride 1, pad 1); UP: the source grid
-    const bf16 *in0 = (const bf16 *)p.in0 + (int64_t)b * p.H * p.W * p.ld0 + p.off0;
-    const bf16 *in1 = p.in1 ? (const bf16 *)p.in1 + (int64_t)b * p.H * p.W * p.ld1 + p.off1 : nullptr;
-    const unsigned char *wgt = (const unsigned char *)(UP ? p.weight_up2x : (F8 ? p.weight_f8 : p.weight));
+    constexpr int ISZ = SPL ? 2 : 1;                  // input elements are ISZ x 2 bytes
+    const bf16 *in0 = (const bf16 *)p.in0 + ((int64_t)b * p.H * p.W * p.ld0 + p.off0) * ISZ;
+    const bf16 *in1 = p.in1 ? (const bf16 *)p.in1 + ((int64_t)b * p.H * p.W * p.ld1 + p.off1) * ISZ : nullptr;
+    const unsigned char *wgt = (const unsigned char *)(SPL ? p.weight_split_hi : (UP ? p.weight_up2x : (F8 ? p.weight_f8 : p.weight)));
+    const unsigned char *wgt_lo = (const unsigned char *)(SPL ? p.weight_split_lo : nullptr);
 
     // ---- halo loader: chunk ids hid = tid + 256*i -> (halo pixel, 16-byte channel chunk)
     // Every load is issued (from a clamped in-image address, zeroed on the LDS store where it was
@@ -157,7 +168,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
     };
     u32x4 rh[HL][HG];
     uint32_t hvalid = 0;                               // validity bits of the halo waiting in rh
+    int rh_part = 0;                                   // SPL: which half (0, 1: hi; 2: lo) the halo waiting in rh becomes
     auto halo_gload = [&](int slab, int ty0, int tx0) {
+        if constexpr (SPL) { rh_part = slab % 3; slab /= 3; }
         int tl = tid;
         asm volatile("" : "+v"(tl));
         const int c = slab * SLABC + (tl & 7) * (SLABC / 8);      // a thread's 8 (16) channels come from ONE source
@@ -181,8 +194,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
             // a 64-channel slab lies in ONE source (c0 % 64 == 0): wave-uniform base + a 32-bit byte offset per load
             const bool first = slab * SLABC < p.c0;
             const char *src = (const char *)(first ? in0 : in1);
-            const unsigned ld2 = 2u * (unsigned)(first ? p.ld0 : p.ld1);
-            const unsigned cc2 = 2u * (unsigned)(first ? c : c - p.c0);
+            const unsigned ld2 = 2u * ISZ * (unsigned)(first ? p.ld0 : p.ld1);
+            const unsigned cc2 = 2u * ISZ * (unsigned)(first ? c : c - p.c0);
             HaloPos hq = halo_first(tl);
 #pragma unroll
             for (int i = 0; i < HL; ++i, halo_next(hq)) {
@@ -190,6 +203,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
                 const unsigned h = (unsigned)halo_geom(tl, i, hq, ty0, tx0, interior, v);
                 if (v) hvalid |= 1u << i;
                 rh[i][0] = *(const u32x4 *)(src + (h * ld2 + cc2));
+                if constexpr (SPL) rh[i][1] = *(const u32x4 *)(src + (h * ld2 + cc2 + 16));       // 8 fp32 channels = 32 bytes
             }
         }
     };
@@ -216,6 +230,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
                     const u32x4 s4 = rh[i][h];
                     v[2 * h] = cvt2(s4[1], cvt2(s4[0], 0u, false), true);
                     v[2 * h + 1] = cvt2(s4[3], cvt2(s4[2], 0u, false), true);
+                }
+            } else if constexpr (SPL) {
+                // hi = bf16(x) (round to nearest even), lo = bf16(x - hi): the operand halves of the split contraction
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    // (scalar copies: indexing the vector inside this lambda read element 0 four times -- hipcc 7.2, the pitfall
+                    //  DESIGN.md section 3 lists under "compiler pitfalls" (4); found here with delta weights: channel k read as 4 (k / 4))
+                    const u32x4 s4 = rh[i][h];
+                    const uint32_t sw[4] = {s4.x, s4.y, s4.z, s4.w};
+                    f32x2 a = {__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1])};
+                    f32x2 c2 = {__builtin_bit_cast(float, sw[2]), __builtin_bit_cast(float, sw[3])};
+                    uint32_t pa = fd_pack_bf16(a), pc = fd_pack_bf16(c2);
+                    if (rh_part == 2) {
+                        pa = fd_pack_bf16(a - fd_unpack_bf16(pa));
+                        pc = fd_pack_bf16(c2 - fd_unpack_bf16(pc));
+                    }
+                    v[2 * h] = pa;
+                    v[2 * h + 1] = pc;
                 }
             } else v = rh[i][0];
             if (hp < HP) *(u32x4 *)(sH + hp * ROWB + swz<F8>(hp, tl & 7)) = ((hvalid >> i) & 1) ? v : z4;
@@ -256,7 +288,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
         else return (ct % NWB) * WT_B;
     };
     auto w_dma = [&](int cls, int slab, int tap, int bufoff) {
-        const char *wb = (const char *)(wgt + (((UP ? 4 * cls : 0) + tap) * Cin + slab * SLABC) * ESZ);
+        const unsigned char *wm = wgt;
+        if constexpr (SPL) { wm = (slab % 3 == 1) ? wgt_lo : wgt; slab /= 3; }
+        const char *wb = (const char *)(wm + (((UP ? 4 * cls : 0) + tap) * Cin + slab * SLABC) * ESZ);
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const unsigned dst = lds_w + bufoff + i * 1024;           // wave-uniform: M0
@@ -505,6 +539,74 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
         // (lane geometry from an opaque copy of tid: as tile-loop invariants the bias values, staging addresses and
         // output offsets of the epilogue would stay live -- spilled -- across the tap loop)
         constexpr int NQ = NT / 2;
+        if constexpr (SPL) {
+            // ---- fp32 epilogue of the split form: bias, GroupNorm partial sums, 32-byte stores straight from the accumulators
+            int te = tid;
+            asm volatile("" : "+v"(te));
+            const int fr = te & 15, fg = (te >> 4) & 3, wv = te >> 6;
+            const int wm = wv / WNW, wn = wv % WNW;
+            const int cb = (BN / WNW) * wn + 8 * fg;
+            float *outp = (float *)p.out + (int64_t)b * p.OH * p.OW * p.ldo + p.offo;
+            if (!more_tiles) __syncthreads();    // (s_stat below; every wave is past its last LDS read of the unit)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int n0 = nt * BN + cb + 32 * q;
+                float bias[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bias[e] = s_bias[cb + 32 * q + e];
+                f32x2 su[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}}, sq[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    float val[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        const f32x4 a4 = acc[i][2 * q + (e >> 2)];
+                        const f32x2 a = (e & 2) ? f32x2{a4[2], a4[3]} : f32x2{a4[0], a4[1]};
+                        const f32x2 v2 = a + f32x2{bias[e], bias[e + 1]};
+                        su[e >> 1] += v2;
+                        sq[e >> 1] = v2 * v2 + sq[e >> 1];
+                        val[e] = v2.x;
+                        val[e + 1] = v2.y;
+                    }
+                    if (n0 < p.Cout) {
+                        float *op = outp + ((int64_t)(ty0 + 4 * wm + i) * p.OW + tx0 + fr) * p.ldo + n0;
+                        *(f32x4 *)op = f32x4{val[0], val[1], val[2], val[3]};
+                        *(f32x4 *)(op + 4) = f32x4{val[4], val[5], val[6], val[7]};
+                    }
+                }
+                if (p.stats_partial) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float sm = row16_sum(e & 1 ? su[e >> 1].y : su[e >> 1].x), sv = row16_sum(e & 1 ? sq[e >> 1].y : sq[e >> 1].x);
+                        if (fr == 0) *(f32x2 *)&s_stat[wm][cb + 32 * q + e][0] = f32x2{sm, sv};
+                    }
+                }
+            }
+            if (p.stats_partial) {
+                __syncthreads();
+                if (te < BN) {
+                    const int n = nt * BN + te;
+                    if (n < p.Cout) {
+                        float sm = 0.f, sq1 = 0.f;
+#pragma unroll
+                        for (int w = 0; w < WMW; ++w) { sm += s_stat[w][te][0]; sq1 += s_stat[w][te][1]; }
+                        constexpr int EPT = BM / 64;
+                        float *sp = p.stats_partial + (((int64_t)b * EPT * tiles_xy + EPT * t) * p.Cout + n) * 2;
+                        sp[0] = sm;
+                        sp[1] = sq1;
+#pragma unroll
+                        for (int e = 1; e < EPT; ++e) {
+                            sp[2 * e * p.Cout] = 0.f;
+                            sp[2 * e * p.Cout + 1] = 0.f;
+                        }
+                    }
+                }
+            }
+            if (more_tiles) {
+                __syncthreads();
+                halo_lstore();
+            }
+        } else {
         if (!more_tiles) __syncthreads();        // no B_8 behind the workgroup's last unit: halo reads of other waves
         int te = tid;
         asm volatile("" : "+v"(te));
@@ -614,6 +716,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
                 for (int k = 0; k < RB; ++k, ob += step) *(u32x4 *)((char *)outp + ob) = cv[k];
             }
         }
+        }
         if (more_tiles) {
             __syncthreads();                             // the next tile's halo is published
             ty0 = nty0;
@@ -660,6 +763,23 @@ int fd_conv3x3_fp8_ok(const fd_conv_params &p) {
     return (p.c0 + p.c1) % 128 == 0 && p.c0 % 16 == 0 && (p.in1 == nullptr || p.c1 % 16 == 0);
 }
 
+// 1 if `p` (fp32 storage, f32_split, the pre-split bf16 weight matrices set) runs on the split-bf16 form of the halo kernel
+int fd_conv3x3_split_ok(const fd_conv_params &p) {
+    static const bool off = getenv("FD_NO_CONV3_SPLIT") != nullptr;     // development: the generic split implicit GEMM
+    const int Cin = p.c0 + p.c1;
+    if (off || p.dtype != FD_F32 || !p.f32_split || !p.weight_split_hi || !p.weight_split_lo || p.ndir != 1) return 0;
+    if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad_h != 1 || p.pad_w != 1) return 0;
+    if (p.epilogue != FD_EPI_NONE || p.prologue != FD_PRO_NONE) return 0;
+    if (Cin % 64 || p.c0 % 64 || p.Cout % 8) return 0;
+    if (p.ld0 % 4 || p.off0 % 4 || (p.in1 && (p.ld1 % 4 || p.off1 % 4)) || p.ldo % 4 || p.offo % 4) return 0;
+    if (p.OH % 8 || p.OW % TW) return 0;
+    if (p.OH != (p.upsample ? 2 * p.H : p.H) || p.OW != (p.upsample ? 2 * p.W : p.W)) return 0;
+    if ((int64_t)p.OH * p.OW < 4096) return 0;
+    if ((int64_t)p.H * p.W * (p.ld0 > p.ld1 ? p.ld0 : p.ld1) >= (1ll << 29)) return 0;   // 32-bit byte offsets, 4-byte elements
+    if ((int64_t)p.Cout * 9 * Cin >= (1ll << 30)) return 0;
+    return 1;
+}
+
 // 1 if `p` (an up-sampling 3x3 with its sub-pixel weight matrix, weight_up2x) runs as four 2x2 convolutions on the source grid
 int fd_conv3x3_up2x_ok(const fd_conv_params &p) {
     static const bool off = getenv("FD_NO_CONV3_UP2X") != nullptr;    // development: the 9-tap form through the up-sampling index map
@@ -669,6 +789,15 @@ int fd_conv3x3_up2x_ok(const fd_conv_params &p) {
 
 int fd_conv3x3_launch(const fd_conv_params &p, hipStream_t s) {
     const bool wide = p.Cout > 64;
+    if (fd_conv3x3_split_ok(p)) {
+        const int th = (!wide && p.OH % 16 == 0) ? 16 : 8;
+        const int tiles_xy = (p.OH / th) * (p.OW / TW), gy = cdiv(p.Cout, wide ? 128 : 64);
+        dim3 grid(tiles_xy, gy, p.B), block(256);
+        if (wide) hipLaunchKernelGGL((conv3x3_halo_kernel<128, 8, false, false, true>), grid, block, 0, s, p, 1, tiles_xy);
+        else if (th == 16) hipLaunchKernelGGL((conv3x3_halo_kernel<64, 16, false, false, true>), grid, block, 0, s, p, 1, tiles_xy);
+        else hipLaunchKernelGGL((conv3x3_halo_kernel<64, 8, false, false, true>), grid, block, 0, s, p, 1, tiles_xy);
+        return 0;
+    }
     if (fd_conv3x3_up2x_ok(p)) {
         // tiles over the SOURCE grid; one tile per workgroup = 4 classes x Cin / 64 slabs of 4 taps
         const int th = (!wide && p.H % 16 == 0) ? 16 : 8;              // (8-row tiles at Cout <= 64 measured 221 -> 224 us: no)

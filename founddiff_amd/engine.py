@@ -35,7 +35,7 @@ def _po(t, off_elems):
 class ConvW:
     """Packed convolution / linear weight: [Cout][KH*KW*Cin] in the compute dtype, fp32 bias."""
 
-    def __init__(self, w_oihw, bias, dev, tdt, cin_pad=None, fp8=False, up2x=False):
+    def __init__(self, w_oihw, bias, dev, tdt, cin_pad=None, fp8=False, up2x=False, split=False):
         w = w_oihw.detach().float()
         if w.dim() == 2:
             w = w[:, :, None, None]
@@ -47,7 +47,11 @@ class ConvW:
         wk = w.permute(0, 2, 3, 1).reshape(o, kh * kw * i).contiguous()
         self.w = wk.to(dev, tdt)
         self.b = bias.detach().float().contiguous().to(dev) if bias is not None else None
-        self.w8 = self.ws = self.w_up = None
+        self.w8 = self.ws = self.w_up = self.w_hi = self.w_lo = None
+        if split and kh == 3 and kw == 3 and tdt == torch.float32 and i % 64 == 0:
+            # the fp32s engine's 3x3 convolutions on the halo-tiled kernel: w = hi + lo in bf16 (include/founddiff_hip.h: weight_split_hi / _lo)
+            hi = wk.to(torch.bfloat16)
+            self.w_hi, self.w_lo = hi.contiguous().to(dev), (wk - hi.float()).to(torch.bfloat16).contiguous().to(dev)
         if (up2x and kh == 3 and kw == 3 and tdt == torch.bfloat16 and cin_pad is None
                 and not (fp8 and os.environ.get("FOUNDDIFF_FP8_UPCONV") == "1")):       # (development: e4m3 9-tap up-sampling convs again)
             self.w_up = pack_up2x(w).to(dev, tdt)          # the up-sampling convs as four 2x2 convs on the source grid
@@ -143,7 +147,7 @@ class DAEngine:
         return t.detach().float().contiguous().to(self.dev)
 
     def _convw(self, w, b=None, cin_pad=None, up2x=False):
-        return ConvW(w, b, self.dev, self.tdt, cin_pad, fp8=getattr(self, "fp8", False), up2x=up2x)
+        return ConvW(w, b, self.dev, self.tdt, cin_pad, fp8=getattr(self, "fp8", False), up2x=up2x, split=bool(getattr(self, "f32_split", 0)))
 
     def _pack_res(self, s):
         r = {"conv": self._convw(ws_standardize(s["block1.proj.weight"]), s["block1.proj.bias"]),
@@ -398,6 +402,8 @@ class DAEngine:
         # (the one-slice kernel set asks for one workgroup per (tile, parity class) -- `upsample` = 2: a low-resolution tile grid
         #  alone is 64..256 workgroups for a lone 512x512 slice, 150.8 against 146.3 ms per 50-step slice with the 9-tap form,
         #  profiles/r05/latency_b1_sweep.txt; any split gives the same bits)
+        if weight is None and cw is not None and getattr(cw, "w_hi", None) is not None:
+            p.weight_split_hi, p.weight_split_lo = cw.w_hi.data_ptr(), cw.w_lo.data_ptr()
         if upsample and weight is None and cw is not None and getattr(cw, "w_up", None) is not None:
             p.weight_up2x = cw.w_up.data_ptr()
             if getattr(self, "low_latency", False):

@@ -141,6 +141,11 @@ typedef struct fd_conv_params {
      * `upsample` = 2 (otherwise the same as 1) asks for one workgroup per (tile, parity class) instead of per tile: four times
      * the workgroups for a batch that does not fill the chip; the results are the same bits.                                 */
     const void *weight_up2x;
+    /* fp32 storage with f32_split = 1, 3x3 / stride 1 / pad 1 (round 5): the weight matrix pre-split into its bf16 halves,
+     * w = hi + lo with hi = bf16(w), lo = bf16(w - hi), each [Cout][9 * Cin] bf16.  With both set the convolution runs on the
+     * halo-tiled kernel (three bf16 MFMA units per 64-channel slab: x_hi.w_hi + x_hi.w_lo + x_lo.w_hi) instead of the generic
+     * split implicit GEMM; `weight` (fp32) stays the reference copy.  NULL: the generic form.                              */
+    const void *weight_split_hi, *weight_split_lo;
 } fd_conv_params;
 
 /* 1 if fd_conv2d would run `p` (weight_f8 / w_scale set) on the fp8 MFMA path.                        */

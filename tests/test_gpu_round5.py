@@ -196,3 +196,59 @@ def test_conv3x3_upsample_as_four_2x2(cfg):
     torch.cuda.synchronize()
     e.low_latency = False
     assert torch.equal(o1, first)
+
+
+@pytest.mark.parametrize("cfg", [dict(c0=64, c1=0, cout=64, hw=(64, 64), up=False),          # <64, 16, SPL>
+                                 dict(c0=64, c1=64, cout=64, hw=(72, 64), up=False),         # two sources, <64, 8, SPL>
+                                 dict(c0=128, c1=64, cout=128, hw=(64, 64), up=False),       # 192 -> 128: <128, 8, SPL>, three slabs
+                                 dict(c0=128, c1=0, cout=64, hw=(64, 64), up=True),          # through the up-sampling index map
+                                 dict(c0=64, c1=0, cout=200, hw=(64, 64), up=False)])        # a ragged channel tile
+def test_conv3x3_split_bf16_halo(cfg):
+    """The fp32s engine's 3x3 convolutions on the halo-tiled kernel (conv3x3_halo_kernel<..., SPL>, kernel id 15: fp32 storage,
+    x_hi.w_hi + x_hi.w_lo + x_lo.w_hi on the bf16 MFMA, fp32 out): against torch in fp64 at the split contraction's own
+    accuracy, against the generic split implicit GEMM (the same weights without the pre-split copies), with the GroupNorm
+    partial sums, and bit for bit repeatable."""
+    from founddiff_amd import _lib as L
+    from founddiff_amd.engine import ConvW
+    from test_gpu_e2e import bare_engine, nhwc, nchw
+    e = bare_engine("fp32s")
+    e.f32_split = 1
+    torch.manual_seed(41)
+    B, (OH, OW), up = 2, cfg["hw"], cfg["up"]
+    H, W = (OH // 2, OW // 2) if up else (OH, OW)
+    cin, cout = cfg["c0"] + cfg["c1"], cfg["cout"]
+    x = torch.randn(B, cin, H, W)
+    w = torch.randn(cout, cin, 3, 3) / (3 * cin ** 0.5)
+    bias = torch.randn(cout)
+    xin = F.interpolate(x, scale_factor=2, mode="nearest") if up else x
+    ref = F.conv2d(xin.double(), w.double(), bias.double(), padding=1)
+    cws = ConvW(w, bias, e.dev, e.tdt, split=True)
+    cwg = ConvW(w, bias, e.dev, e.tdt)
+    assert cws.w_hi is not None and cwg.w_hi is None
+    xa = nhwc(x[:, :cfg["c0"]], e.tdt)
+    kw = dict(c0=cfg["c0"], upsample=up)
+    if cfg["c1"]:
+        kw.update(in1=nhwc(x[:, cfg["c0"]:], e.tdt), c1=cfg["c1"])
+    mt = L.lib().fd_conv_mtiles(OH, OW)
+    outs, parts = {}, {}
+    for tag, cw, kid in (("halo", cws, 15), ("generic", cwg, None)):
+        out = torch.full((B, OH, OW, cout), float("nan"), device="cuda")
+        part = torch.full((B, mt, cout, 2), 7.0, device="cuda")
+        got = e.conv(cw, xa, B, H, W, out, probe="kid", stats=part, **kw)
+        assert (got == 15) if kid else (got != 15), (tag, got)
+        e.conv(cw, xa, B, H, W, out, stats=part, **kw)
+        torch.cuda.synchronize()
+        outs[tag], parts[tag] = out, part
+    eh, eg = rel_err(nchw(outs["halo"]).double(), ref), rel_err(nchw(outs["generic"]).double(), ref)
+    print(f"split-bf16 3x3 {cin} -> {cout} @ {OH}x{OW} up={int(up)}: halo-tiled max-rel {eh:.2e}, generic {eg:.2e}")
+    assert torch.isfinite(outs["halo"]).all()
+    assert eh < 2e-5 and eh < 3 * eg + 1e-6
+    s = parts["halo"].sum(1).cpu().double()
+    assert rel_err(s[..., 0], ref.sum((2, 3))) < 1e-4
+    assert rel_err(s[..., 1], (ref ** 2).sum((2, 3))) < 1e-4
+    first = outs["halo"].clone()
+    for _ in range(6):
+        outs["halo"].zero_()
+        e.conv(cws, xa, B, H, W, outs["halo"], stats=parts["halo"], **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(outs["halo"], first)
