@@ -418,6 +418,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
             const bool has_next = !last_slab || more_tiles;
             const int nslab_i = last_slab ? 0 : slab + 1;
             const int ncls_i = last_slab ? ncls : cls;
+            // SPL: the unit behind x_hi.w_hi (part 0) is x_hi.w_lo on the SAME halo image: nothing to load or store for it
+            const bool reload = !(SPL && !last_slab && slab % 3 == 0);
             if constexpr (F8) {
                 const unsigned char *sH = smem;
 #pragma unroll
@@ -487,7 +489,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
                         // pixel fragments of (t, 1), from the halo).  A bare s_barrier: __syncthreads() would drain those
                         // as well, an LDS round trip in front of every barrier.
                         const bool t2 = tap + 2 < NTAP || has_next;
-                        const bool halo_young = has_next && (tap == 1 || tap == 2);
+                        const bool halo_young = has_next && reload && (tap == 1 || tap == 2);
                         asm volatile("" ::: "memory");
                         // (the unit's last barrier drains them too: behind it the halo buffer is overwritten -- next slab / C staging)
                         if (tap == NTAP - 1) { if (t2) FD_WAIT_VM_LGKM(NB, 0); else FD_WAIT_VM_LGKM(0, 0); }
@@ -497,7 +499,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
                         asm volatile("" ::: "memory");
                         if (tap + 3 < NTAP || has_next)
                             w_dma(tap + 3 < NTAP ? cls : ncls_i, tap + 3 < NTAP ? slab : nslab_i, (tap + 3) % NTAP, slot(tap + 3));
-                        if (tap == 0 && has_next) {               // in flight during this unit's taps
+                        if (tap == 0 && has_next && reload) {     // in flight during this unit's taps
                             if (last_slab) halo_gload(0, nty0, ntx0); else halo_gload(slab + 1, ty0, tx0);
                         }
                     }
@@ -506,8 +508,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
                         __builtin_amdgcn_sched_barrier(0);
                         half_step(fb[1], true, tap + 1, 0);
                     } else if (!last_slab) {                      // every wave is done with this slab's halo
-                        halo_lstore();
-                        __syncthreads();
+                        if (reload) {
+                            halo_lstore();
+                            __syncthreads();
+                        }
                         load_b(NTAP, 0, fb[0]);                   // tap 0 of the next unit
                         __builtin_amdgcn_sched_barrier(0);
                         half_step(fb[1], true, 0, 0);
@@ -790,11 +794,11 @@ int fd_conv3x3_up2x_ok(const fd_conv_params &p) {
 int fd_conv3x3_launch(const fd_conv_params &p, hipStream_t s) {
     const bool wide = p.Cout > 64;
     if (fd_conv3x3_split_ok(p)) {
-        const int th = (!wide && p.OH % 16 == 0) ? 16 : 8;
-        const int tiles_xy = (p.OH / th) * (p.OW / TW), gy = cdiv(p.Cout, wide ? 128 : 64);
+        // 8-row tiles at every width: the fp32 halo registers of a 16-row tile spill (152 bytes of scratch; 64 -> 64 at 512^2
+        // 639 -> 535 us with <64, 8>)
+        const int tiles_xy = (p.OH / 8) * (p.OW / TW), gy = cdiv(p.Cout, wide ? 128 : 64);
         dim3 grid(tiles_xy, gy, p.B), block(256);
         if (wide) hipLaunchKernelGGL((conv3x3_halo_kernel<128, 8, false, false, true>), grid, block, 0, s, p, 1, tiles_xy);
-        else if (th == 16) hipLaunchKernelGGL((conv3x3_halo_kernel<64, 16, false, false, true>), grid, block, 0, s, p, 1, tiles_xy);
         else hipLaunchKernelGGL((conv3x3_halo_kernel<64, 8, false, false, true>), grid, block, 0, s, p, 1, tiles_xy);
         return 0;
     }
