@@ -81,11 +81,13 @@ __device__ __forceinline__ float fd_softplus(float x) { return x > 20.0f ? x : l
 // (truncation < 3e-8 absolute, ~1.5e-6 relative); else log(1 + e) with 1 + e >= 1.018 so the
 // rounding of the sum costs <= 3e-6 relative.  v_exp_f32 / v_log_f32 are the base-2 forms.
 __device__ __forceinline__ float fd_softplus_fast(float x) {
-    if (x > 20.0f) return x;
-    const float e = __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
+    // (branch-free: with an early return for x > 20 the unrolled scan steps became control flow the register allocator
+    //  could not keep inside an occupancy step: 450-820 bytes of scratch in the fp32 phase-A kernels)
+    const float e = __builtin_amdgcn_exp2f(x * 1.4426950408889634f);      // (x > 20: inf at worst, discarded below; NaN stays NaN)
     const float series = e * (1.0f + e * (-0.5f + e * 0.33333334f));
     const float lg = __builtin_amdgcn_logf(1.0f + e) * 0.6931471805599453f;
-    return x < -4.0f ? series : lg;
+    const float r = x < -4.0f ? series : lg;
+    return x > 20.0f ? x : r;
 }
 
 // 8 consecutive elements <-> 8 floats (16-byte aligned for bf16, 32-byte span for f32)

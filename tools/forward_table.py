@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Every launch of one batch-8 UNet forward (512x512, bf16), replayed alone between HIP events: C-ABI entry point, shape,
 time, algorithmic GFLOP (dense contractions) and the rate it reaches -- the per-launch view behind profiles/*stage_detail*
-and the kernel_stats summaries.  usage: python tools/forward_table.py [--batch 8] > profiles/rNN_forward_launches.md"""
+and the kernel_stats summaries.  usage: python tools/forward_table.py [--batch 8] [--precision fp32s] > profiles/rNN_forward_launches.md"""
 import argparse
 import os
 import sys
@@ -14,9 +14,10 @@ from founddiff_amd import _lib as L, synth  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=8)
+ap.add_argument("--precision", default="bf16", help="bf16 | fp32s | fp32 | fp8: the kernel mode of the forward")
 a = ap.parse_args()
 dev = torch.device("cuda")
-dif, _ = bench.build_model(dev)
+dif, _ = bench.build_model(dev, precision=a.precision)
 eng = dif._eng()
 B = a.batch
 _, ld = synth.ct_phantom(B, 512, seed=10)
@@ -30,7 +31,8 @@ eng.forward(img, x_in, tb)
 trace, L.TRACE = L.TRACE, None
 lib = L.lib()
 KID = {0: "igemm 128x128", 1: "igemm 128x64", 2: "igemm 64x128", 3: "igemm 64x64", 4: "igemm 128x256", 5: "igemm 256x256",
-       6: "igemm 128x32", 7: "pw_gemm 256x256 persistent", 10: "row-GEMM", 11: "halo 3x3", 12: "halo 3x3 fp8", 13: "3x3 weights in registers", 14: "halo 3x3, up-sampling as four 2x2 (GFLOP of the 9-tap form)"}
+       6: "igemm 128x32", 7: "pw_gemm 256x256 persistent", 10: "row-GEMM", 11: "halo 3x3", 12: "halo 3x3 fp8", 13: "3x3 weights in registers", 14: "halo 3x3, up-sampling as four 2x2 (GFLOP of the 9-tap form)",
+       15: "halo 3x3 split-bf16 (fp32 storage)"}
 rows, tot_ms, tot_fl = [], 0.0, 0.0
 for n, args in trace:
     ms = bench._time_launches(lib, [(n, args)], reps=3)
@@ -68,7 +70,7 @@ for n, args in trace:
     rows.append((n, desc, ms, fl))
     tot_ms += ms
     tot_fl += fl
-print(f"# One batch-{B} forward, launch by launch (each replayed alone; sum {tot_ms:.2f} ms = {tot_ms / B:.3f} ms per slice, "
+print(f"# One batch-{B} forward ({a.precision}), launch by launch (each replayed alone; sum {tot_ms:.2f} ms = {tot_ms / B:.3f} ms per slice, "
       f"{tot_fl / 1e9 / B:.1f} GFLOP per slice counted)\n")
 print("| # | entry point | what | us | GFLOP | TFLOP/s |")
 print("|---|---|---|---|---|---|")
