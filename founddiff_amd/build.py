@@ -1,6 +1,7 @@
 """Build founddiff_amd/lib/libfounddiff_hip.so from csrc/*.hip with hipcc for gfx950 (in-tree)."""
 import glob
 import os
+import re
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -11,6 +12,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libfounddiff_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function",
+         "-Rpass-analysis=kernel-resource-usage",       # -> lib/obj/<file>.resources.txt (resources() below)
          "-I" + os.path.join(HERE, "..", "include")]
 
 
@@ -36,7 +38,7 @@ def build(force=False, verbose=False):
     for s in srcs:
         o = os.path.join(objdir, os.path.basename(s) + ".o")
         objs.append(o)
-        if force or _stale(o, [s] + hdrs):
+        if force or _stale(o, [s] + hdrs) or not os.path.exists(o[:-2] + ".resources.txt"):
             flags = [f for f in FLAGS if not (f == "-fno-slp-vectorize" and os.path.basename(s) in SLP_OK)]
             jobs.append([HIPCC] + flags + ["-c", s, "-o", o])
 
@@ -46,13 +48,41 @@ def build(force=False, verbose=False):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
-        if verbose and r.stderr.strip():
-            print(r.stderr)
+        err = r.stderr
+        if "-c" in cmd:          # the per-kernel register / scratch / occupancy remarks of this object, kept beside it
+            rem = [ln for ln in err.splitlines() if "remark:" in ln]
+            err = "\n".join(ln for ln in err.splitlines() if "remark:" not in ln)
+            with open(cmd[cmd.index("-o") + 1][:-2] + ".resources.txt", "w") as f:
+                f.write("\n".join(rem) + "\n")
+        if verbose and err.strip():
+            print(err)
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
     if jobs or force or _stale(LIB, objs):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
     return LIB
+
+
+def resources():
+    """{source file: {mangled kernel name: {"vgpr", "agpr", "scratch", "occupancy", "lds"}}} of the objects build() compiled
+    (hipcc's kernel-resource-usage remarks): tests/test_host_cpu.py holds the hot kernels to a scratch ledger, so that a
+    register-allocation accident (round 5: an early return in fd_softplus_fast cost the fp32 scans 450-820 bytes of scratch and a
+    factor 3-5) fails a test instead of waiting for a profile."""
+    out = {}
+    for f in sorted(glob.glob(os.path.join(LIBDIR, "obj", "*.resources.txt"))):
+        cur, tab = None, {}
+        for ln in open(f):
+            m = re.search(r"Function Name: (\S+)", ln)
+            if m:
+                cur = tab.setdefault(m.group(1), {})
+                continue
+            for key, pat in (("vgpr", r" VGPRs: (\d+)"), ("agpr", r"AGPRs: (\d+)"), ("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"),
+                             ("occupancy", r"Occupancy \[waves/SIMD\]: (\d+)"), ("lds", r"LDS Size \[bytes/block\]: (\d+)")):
+                m = re.search(pat, ln)
+                if m and cur is not None:
+                    cur[key] = int(m.group(1))
+        out[os.path.basename(f)[:-len(".resources.txt")]] = tab
+    return out
 
 
 if __name__ == "__main__":

@@ -238,3 +238,40 @@ def test_inline_asm_mfma_drains_in_the_isa():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kres.py"), "--check-drain"] + files, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert r.stdout.count("0 early read(s)") == 4, r.stdout
+
+
+def test_kernel_scratch_ledger():
+    """Register-allocation accidents fail here instead of waiting for a profile: every kernel of the library is held to a
+    scratch ledger read from hipcc's kernel-resource-usage remarks of the objects build() compiled
+    (founddiff_amd.build.resources()).  Round 5: an early return in fd_softplus_fast turned the unrolled steps of the fp32
+    scan's phase A into control flow the allocator could not fit in its occupancy step -- 450-820 bytes of scratch, 3-5 x the
+    time of the same kernel without it -- and nothing but a launch table of the fp32s mode showed it."""
+    import re
+    import shutil
+    if not shutil.which("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    from founddiff_amd import build
+    build.build()
+    res = build.resources()
+    assert res.get("fd_scan.hip") and res.get("fd_conv3x3.hip"), "no resource remarks beside the objects: rebuild with build(force=True)"
+    model_nr = {(4, 4), (8, 4), (16, 8), (32, 16), (32, 32), (16, 16), (8, 8)}     # (d_state, dt_rank) of the shipped architecture
+    ledger = [          # (file, pattern of the mangled name, bytes of scratch per lane it may use)
+        ("fd_conv.hip", r"conv_igemm_kernelI\w+Li256ELi256E", 192),        # the 256 x 256 tile sits at its 256-register cap
+        ("fd_conv3x3.hip", r"conv3x3_halo_kernelILi128ELi8ELb0ELb0ELb1E", 32),     # split-bf16 form: fp32 halo registers
+        ("fd_pwdw.hip", r"pwdw_gram_kernel|dwconv_gram_kernel|pwdw_kernelILi64ELb1E", 32),
+    ]
+    bad = []
+    for f, tab in res.items():
+        for name, r in tab.items():
+            limit = 0
+            m = re.search(r"scan_chunk_kernelI(DF16b|f)Li(\d+)ELi(\d+)E", name)
+            if f == "fd_scan.hip" and m:
+                # combinations the architecture uses: a few spilled values at the 96-register occupancy step; the others
+                # (dt_rank 32 at d_state 8 / 16) only have to build
+                limit = 256 if (int(m.group(2)), int(m.group(3))) in model_nr else 512
+            for lf, pat, lim in ledger:
+                if lf == f and re.search(pat, name):
+                    limit = lim
+            if r.get("scratch", 0) > limit:
+                bad.append((f, name, r["scratch"], limit))
+    assert not bad, bad
