@@ -29,6 +29,8 @@ PMC_ROWS=32 python3 tools/pmc_table.py $OUT/sq1 $OUT/sq2 > $OUT/pmc_table.md 2> 
 python3 tools/pmc_two_stream.py $OUT/sq1 $OUT/sq2 $OUT/traffic.json $OUT/bench.json $OUT/bench_one_stream_b8.json 6 > $OUT/pmc_two_stream.md 2> $OUT/pmc_two_stream.err
 # 4b. the forward launch by launch (each launch replayed alone between events)
 python3 tools/forward_table.py > $OUT/forward_launches.md 2> /dev/null
+python3 tools/forward_table.py --precision fp32s > $OUT/forward_launches_fp32s.md 2> /dev/null
+python3 tools/tail_table.py > $OUT/tail_launches.md 2> /dev/null
 # 5. per-stage times of one forward
 python3 tools/stage_times.py --batches 8 --detail > $OUT/stage_detail_b8.md 2> /dev/null
 # keep only the summaries (the raw traces are large)
