@@ -195,7 +195,8 @@ def roofline_leg(dif, x, noise, t_measured_ms=None, clock_replay=True):
     # the two instantiations of the halo 3x3 kernel separately (separate symbols in the rocprof summary: <128,8> serves
     # Cout > 64, <64,16> / <64,8> Cout <= 64)
     halo = [(n, a) for n, a in trace if n == "fd_conv2d" and lib.fd_conv_kernel_id(a[0]) == 11]
-    for name, sel in (("conv3x3_halo_kernel<128,8,false>", lambda q: q.Cout > 64), ("conv3x3_halo_kernel<64,16|8,false>", lambda q: q.Cout <= 64)):
+    for name, sel, tkey in (("conv3x3_halo_kernel<128,8,false>", lambda q: q.Cout > 64, "conv3x3_halo128_hbm_bytes_per_launch"),
+                            ("conv3x3_halo_kernel<64,16|8,false>", lambda q: q.Cout <= 64, "conv3x3_halo64_hbm_bytes_per_launch")):
         part = [(n, a) for n, a in halo if sel(a[0]._obj)]
         if not part:
             continue
@@ -204,7 +205,7 @@ def roofline_leg(dif, x, noise, t_measured_ms=None, clock_replay=True):
         tf = fl / (ms * 1e-3) / 1e12
         cands.append({"bound": "mfma", "kernel": name, "achieved": round(tf, 1),
                       "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4),
-                      "traffic": traffic.get("conv3x3_halo_hbm_bytes_per_launch"),
+                      "traffic": traffic.get(tkey, traffic.get("conv3x3_halo_hbm_bytes_per_launch")),     # (per symbol; the family figure as fallback)
                       "launches_per_forward": len(part), "avg_launch_us": round(ms * 1e3 / len(part), 2),
                       "alg_gflop_per_launch": round(fl / 1e9 / len(part), 2),
                       "kernel_ms_per_forward": round(ms, 3)})

@@ -48,7 +48,9 @@ __device__ __forceinline__ void scan_pos(const ScanGeom &g, int k, int l, int &l
 // instructions too, the cross-half add of the y pair disappears, u / y move as one dword per lane and step, and a
 // wave's LDS row broadcasts serve 128 channels: ~26.5 instead of ~31 issue slots per (channel, position).
 template <typename T, int N, int R, bool FINAL, bool ODD, int CPL = 1>
-__global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 8 ? (CPL == 2 ? 4 : 5) : 1))) void scan_chunk_kernel(const T *__restrict__ xc, const float *__restrict__ xdbl,
+// (occupancy steps: N = 16 with dt_rank >= 16 wants 100-114 registers -- at 5 waves per SIMD it spilled 16-20 bytes: 4 waves measured
+//  418-427 -> 406-412 us for d_inner 512 at 128x128; with dt_rank 8 the 5-wave form is the faster one, 202 vs 212 us)
+__global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 16 && R >= 16 ? 4 : (N >= 8 ? (CPL == 2 ? 4 : 5) : 1)))) void scan_chunk_kernel(const T *__restrict__ xc, const float *__restrict__ xdbl,
                                                         const float *__restrict__ dtw, const float *__restrict__ dtb,
                                                         const float *__restrict__ A, const float *__restrict__ Ds,
                                                         T *__restrict__ y, float *__restrict__ wsH,
