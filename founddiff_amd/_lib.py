@@ -47,6 +47,7 @@ class ConvParams(C.Structure):
         ("zre_eps", f32),
         ("weight_up2x", vp),
         ("weight_split_hi", vp), ("weight_split_lo", vp),
+        ("weight_up2x_split_hi", vp), ("weight_up2x_split_lo", vp),
     ]
 
 

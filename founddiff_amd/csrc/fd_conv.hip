@@ -639,13 +639,14 @@ int fd_conv3x3_fp8_ok(const fd_conv_params &p);
 int fd_conv3x3_launch(const fd_conv_params &p, hipStream_t s);
 int fd_conv3x3_up2x_ok(const fd_conv_params &p);
 int fd_conv3x3_split_ok(const fd_conv_params &p);
+int fd_conv3x3_up2x_split_ok(const fd_conv_params &p);
 int fd_conv3x3_rw_ok(const fd_conv_params &p);
 int fd_conv3x3_rw_launch(const fd_conv_params &p, hipStream_t s);
 int fd_pwgemm_ok(const fd_conv_params &p);
 int fd_pwgemm_launch(const fd_conv_params &p, hipStream_t s);
 
 // Which kernel fd_conv2d dispatches `p` to: 10 streaming row-GEMM, 11 halo-tiled 3x3 (12: its fp8 form; 14: an up-sampling 3x3
-// as four 2x2 convolutions on the source grid, weight_up2x; 15: its split-bf16 form on fp32 storage), 13 the 64 -> 64 3x3 with
+// as four 2x2 convolutions on the source grid, weight_up2x; 15: its split-bf16 form on fp32 storage; 16: both at once), 13 the 64 -> 64 3x3 with
 // the weights resident in registers (fd_conv3x3_rw.hip), else the
 // implicit-GEMM tile variant 0 <128,128>, 1 <128,64>, 2 <64,128>, 3 <64,64>, 4 <128,256>, 5 <256,256>, 6 <128,32> (BM, BN);
 // 7: the persistent 256x256 pointwise GEMM with deferred stores (fd_pwgemm.hip) where 5 would run and it applies.
@@ -655,6 +656,7 @@ extern "C" int fd_conv_kernel_id(const fd_conv_params *pp) {
     if (fd_conv_prologue_ok(pp)) return 10;
     if (fd_conv3x3_rw_ok(*pp)) return 13;
     if (fd_conv3x3_ok(*pp)) return fd_conv3x3_fp8_ok(*pp) ? 12 : (fd_conv3x3_up2x_ok(*pp) ? 14 : 11);
+    if (fd_conv3x3_up2x_split_ok(*pp)) return 16;
     if (fd_conv3x3_split_ok(*pp)) return 15;
     const bool wide = pp->Cout > 64, tall = conv_bm((int64_t)pp->OH * pp->OW) == 128;
     static const int force = [] { const char *e = getenv("FD_CONV_KID"); return e ? atoi(e) : -1; }();   // development: tile experiments
@@ -714,7 +716,7 @@ extern "C" int fd_conv2d(const fd_conv_params *pp, void *stream) {
         FD_LAUNCH_OK("fd_conv2d(3x3, weights in registers)");
         return FD_OK;
     }
-    if (fd_conv3x3_ok(p) || fd_conv3x3_split_ok(p)) {
+    if (fd_conv3x3_ok(p) || fd_conv3x3_split_ok(p) || fd_conv3x3_up2x_split_ok(p)) {
         fd_conv3x3_launch(p, (hipStream_t)stream);
         FD_LAUNCH_OK("fd_conv2d(3x3 halo)");
         return FD_OK;

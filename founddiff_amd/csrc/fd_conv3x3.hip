@@ -93,7 +93,7 @@ __device__ __forceinline__ float row16_sum(float x) {
 template <int BN, int TH, bool F8, bool UP = false, bool SPL = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_params p, const int tpw, const int tiles_xy) {
     static_assert(!(UP && F8), "the up-sampling form is bf16 only");
-    static_assert(!(SPL && (F8 || UP)), "the split form: fp32 storage, 9 taps");
+    static_assert(!(SPL && F8), "the split form: fp32 storage, bf16 MFMAs");
     constexpr int NTAP = UP ? 4 : 9, NCLS = UP ? 4 : 1;
     constexpr int BM = TH * TW, HY = TH + 2, HP = HY * HX;
     constexpr int HL = (HP * 8 + 255) / 256;          // halo 16-byte LDS chunks per thread
@@ -127,8 +127,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
     constexpr int ISZ = SPL ? 2 : 1;                  // input elements are ISZ x 2 bytes
     const bf16 *in0 = (const bf16 *)p.in0 + ((int64_t)b * p.H * p.W * p.ld0 + p.off0) * ISZ;
     const bf16 *in1 = p.in1 ? (const bf16 *)p.in1 + ((int64_t)b * p.H * p.W * p.ld1 + p.off1) * ISZ : nullptr;
-    const unsigned char *wgt = (const unsigned char *)(SPL ? p.weight_split_hi : (UP ? p.weight_up2x : (F8 ? p.weight_f8 : p.weight)));
-    const unsigned char *wgt_lo = (const unsigned char *)(SPL ? p.weight_split_lo : nullptr);
+    // (UP && SPL: the sub-pixel matrix of an up-sampling convolution, split like the 9-tap one: weight_up2x_split_hi / _lo)
+    const unsigned char *wgt = (const unsigned char *)(SPL ? (UP ? p.weight_up2x_split_hi : p.weight_split_hi)
+                                                           : (UP ? p.weight_up2x : (F8 ? p.weight_f8 : p.weight)));
+    const unsigned char *wgt_lo = (const unsigned char *)(SPL ? (UP ? p.weight_up2x_split_lo : p.weight_split_lo) : nullptr);
 
     // ---- halo loader: chunk ids hid = tid + 256*i -> (halo pixel, 16-byte channel chunk)
     // Every load is issued (from a clamped in-image address, zeroed on the LDS store where it was
@@ -573,7 +575,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
                         val[e + 1] = v2.y;
                     }
                     if (n0 < p.Cout) {
-                        float *op = outp + ((int64_t)(ty0 + 4 * wm + i) * p.OW + tx0 + fr) * p.ldo + n0;
+                        // (UP: tile pixel (i, j) of class (a, b) = (cls >> 1, cls & 1) is output pixel (2 i + a, 2 j + b))
+                        float *op = UP ? outp + ((int64_t)(2 * (ty0 + 4 * wm + i) + (cls >> 1)) * p.OW + 2 * (tx0 + fr) + (cls & 1)) * p.ldo + n0
+                                       : outp + ((int64_t)(ty0 + 4 * wm + i) * p.OW + tx0 + fr) * p.ldo + n0;
                         *(f32x4 *)op = f32x4{val[0], val[1], val[2], val[3]};
                         *(f32x4 *)(op + 4) = f32x4{val[4], val[5], val[6], val[7]};
                     }
@@ -784,6 +788,19 @@ int fd_conv3x3_split_ok(const fd_conv_params &p) {
     return 1;
 }
 
+// 1 if `p` (fp32 storage, f32_split, an up-sampling 3x3 with its pre-split sub-pixel matrices) runs as four 2x2 convolutions on
+// the source grid in the split-bf16 form: both of the above at once (the fp32s engine's three Upsample convolutions)
+int fd_conv3x3_up2x_split_ok(const fd_conv_params &p) {
+    static const bool off = getenv("FD_NO_CONV3_UP2X") != nullptr || getenv("FD_NO_CONV3_SPLIT") != nullptr;
+    if (off || !p.weight_up2x_split_hi || !p.weight_up2x_split_lo || !p.upsample || p.stats_partial) return 0;
+    if (p.H % 8 || p.W % TW) return 0;
+    if ((int64_t)p.Cout * 16 * (p.c0 + p.c1) >= (1ll << 30)) return 0;
+    fd_conv_params q = p;                   // every other condition is the 9-tap split form's
+    q.weight_split_hi = p.weight_up2x_split_hi;
+    q.weight_split_lo = p.weight_up2x_split_lo;
+    return fd_conv3x3_split_ok(q);
+}
+
 // 1 if `p` (an up-sampling 3x3 with its sub-pixel weight matrix, weight_up2x) runs as four 2x2 convolutions on the source grid
 int fd_conv3x3_up2x_ok(const fd_conv_params &p) {
     static const bool off = getenv("FD_NO_CONV3_UP2X") != nullptr;    // development: the 9-tap form through the up-sampling index map
@@ -793,6 +810,15 @@ int fd_conv3x3_up2x_ok(const fd_conv_params &p) {
 
 int fd_conv3x3_launch(const fd_conv_params &p, hipStream_t s) {
     const bool wide = p.Cout > 64;
+    if (fd_conv3x3_up2x_split_ok(p)) {
+        static const int cpw_env = [] { const char *e = getenv("FD_CONV3_UP_CPW"); return e ? atoi(e) : 0; }();
+        const int cpw = (cpw_env == 1 || cpw_env == 2 || cpw_env == 4) ? cpw_env : (p.upsample == 2 ? 1 : 4);
+        const int tiles_xy = (p.H / 8) * (p.W / TW), gy = cdiv(p.Cout, wide ? 128 : 64);
+        dim3 grid(tiles_xy * (4 / cpw), gy, p.B), block(256);
+        if (wide) hipLaunchKernelGGL((conv3x3_halo_kernel<128, 8, false, true, true>), grid, block, 0, s, p, cpw, tiles_xy);
+        else hipLaunchKernelGGL((conv3x3_halo_kernel<64, 8, false, true, true>), grid, block, 0, s, p, cpw, tiles_xy);
+        return 0;
+    }
     if (fd_conv3x3_split_ok(p)) {
         // 8-row tiles at every width: the fp32 halo registers of a 16-row tile spill (152 bytes of scratch; 64 -> 64 at 512^2
         // 639 -> 535 us with <64, 8>)

@@ -47,11 +47,16 @@ class ConvW:
         wk = w.permute(0, 2, 3, 1).reshape(o, kh * kw * i).contiguous()
         self.w = wk.to(dev, tdt)
         self.b = bias.detach().float().contiguous().to(dev) if bias is not None else None
-        self.w8 = self.ws = self.w_up = self.w_hi = self.w_lo = None
+        self.w8 = self.ws = self.w_up = self.w_hi = self.w_lo = self.w_up_hi = self.w_up_lo = None
         if split and kh == 3 and kw == 3 and tdt == torch.float32 and i % 64 == 0:
             # the fp32s engine's 3x3 convolutions on the halo-tiled kernel: w = hi + lo in bf16 (include/founddiff_hip.h: weight_split_hi / _lo)
             hi = wk.to(torch.bfloat16)
             self.w_hi, self.w_lo = hi.contiguous().to(dev), (wk - hi.float()).to(torch.bfloat16).contiguous().to(dev)
+            if up2x and cin_pad is None:
+                # ... and the up-sampling ones as four split 2x2 convolutions: the fp32 sub-pixel matrix, split the same way
+                wu = pack_up2x(w)
+                uh = wu.to(torch.bfloat16)
+                self.w_up_hi, self.w_up_lo = uh.contiguous().to(dev), (wu - uh.float()).to(torch.bfloat16).contiguous().to(dev)
         if (up2x and kh == 3 and kw == 3 and tdt == torch.bfloat16 and cin_pad is None
                 and not (fp8 and os.environ.get("FOUNDDIFF_FP8_UPCONV") == "1")):       # (development: e4m3 9-tap up-sampling convs again)
             self.w_up = pack_up2x(w).to(dev, tdt)          # the up-sampling convs as four 2x2 convs on the source grid
@@ -404,6 +409,10 @@ class DAEngine:
         #  profiles/r05/latency_b1_sweep.txt; any split gives the same bits)
         if weight is None and cw is not None and getattr(cw, "w_hi", None) is not None:
             p.weight_split_hi, p.weight_split_lo = cw.w_hi.data_ptr(), cw.w_lo.data_ptr()
+        if upsample and weight is None and cw is not None and getattr(cw, "w_up_hi", None) is not None:
+            p.weight_up2x_split_hi, p.weight_up2x_split_lo = cw.w_up_hi.data_ptr(), cw.w_up_lo.data_ptr()
+            if getattr(self, "low_latency", False):
+                p.upsample = 2
         if upsample and weight is None and cw is not None and getattr(cw, "w_up", None) is not None:
             p.weight_up2x = cw.w_up.data_ptr()
             if getattr(self, "low_latency", False):

@@ -146,6 +146,10 @@ typedef struct fd_conv_params {
      * halo-tiled kernel (three bf16 MFMA units per 64-channel slab: x_hi.w_hi + x_hi.w_lo + x_lo.w_hi) instead of the generic
      * split implicit GEMM; `weight` (fp32) stays the reference copy.  NULL: the generic form.                              */
     const void *weight_split_hi, *weight_split_lo;
+    /* Both of the above at once (fp32 storage, f32_split = 1, `upsample` != 0, 3x3): the sub-pixel matrix of weight_up2x, built
+     * from the fp32 weights and pre-split into bf16 halves, [Cout][16 * Cin] each: four 2x2 split-bf16 convolutions on the
+     * source grid.  NULL: the 9-tap split form through the up-sampling index map.                                        */
+    const void *weight_up2x_split_hi, *weight_up2x_split_lo;
 } fd_conv_params;
 
 /* 1 if fd_conv2d would run `p` (weight_f8 / w_scale set) on the fp8 MFMA path.                        */

@@ -252,3 +252,53 @@ def test_conv3x3_split_bf16_halo(cfg):
         e.conv(cws, xa, B, H, W, outs["halo"], stats=parts["halo"], **kw)
         torch.cuda.synchronize()
         assert torch.equal(outs["halo"], first)
+
+
+@pytest.mark.parametrize("cfg", [dict(cin=128, cout=64, hw=(64, 64)), dict(cin=256, cout=128, hw=(64, 96)),
+                                 dict(cin=128, cout=200, hw=(64, 64)), dict(cin=64, cout=64, hw=(128, 128))])
+def test_conv3x3_upsample_four_2x2_split_bf16(cfg):
+    """The fp32s engine's Upsample convolutions (src/DADiff.py:121-127) as four 2x2 SPLIT-bf16 convolutions on the source grid
+    (conv3x3_halo_kernel<..., UP, SPL>, kernel id 16: the sub-pixel matrix of the fp32 weights pre-split into bf16 halves,
+    fd_conv_params.weight_up2x_split_hi / _lo): against torch in fp64 on the up-sampled image at the split contraction's accuracy,
+    against the 9-tap split form through the up-sampling index map, with the class-parallel grid (`upsample` = 2) bit for bit
+    the same, and repeatable."""
+    from founddiff_amd.engine import ConvW
+    from test_gpu_e2e import bare_engine, nhwc, nchw
+    e = bare_engine("fp32s")
+    e.f32_split = 1
+    torch.manual_seed(43)
+    B, (OH, OW) = 2, cfg["hw"]
+    H, W, cin, cout = OH // 2, OW // 2, cfg["cin"], cfg["cout"]
+    x = torch.randn(B, cin, H, W)
+    w = torch.randn(cout, cin, 3, 3) / (3 * cin ** 0.5)
+    bias = torch.randn(cout)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest").double(), w.double(), bias.double(), padding=1)
+    cwu = ConvW(w, bias, e.dev, e.tdt, split=True, up2x=True)
+    cw9 = ConvW(w, bias, e.dev, e.tdt, split=True)
+    assert cwu.w_up_hi is not None and cwu.w_up_hi.shape == (cout, 16 * cin) and cw9.w_up_hi is None
+    xa = nhwc(x, e.tdt)
+    outs = {}
+    for tag, cw, kid in (("four2x2", cwu, 16), ("ninetap", cw9, 15)):
+        out = torch.full((B, OH, OW, cout), float("nan"), device="cuda")
+        assert e.conv(cw, xa, B, H, W, out, probe="kid", c0=cin, upsample=True) == kid, tag
+        e.conv(cw, xa, B, H, W, out, c0=cin, upsample=True)
+        torch.cuda.synchronize()
+        outs[tag] = out
+    e4, e9 = rel_err(nchw(outs["four2x2"]).double(), ref), rel_err(nchw(outs["ninetap"]).double(), ref)
+    print(f"split-bf16 up-sampling 3x3 {cin} -> {cout} to {OH}x{OW}: four 2x2 max-rel {e4:.2e}, nine taps {e9:.2e}")
+    assert torch.isfinite(outs["four2x2"]).all()
+    assert e4 < 2e-5 and e4 < 3 * e9 + 1e-6
+    first = outs["four2x2"].clone()
+    e.low_latency = True                       # one workgroup per (tile, parity class): the same bits
+    try:
+        par = torch.full_like(first, float("nan"))
+        e.conv(cwu, xa, B, H, W, par, c0=cin, upsample=True)
+        torch.cuda.synchronize()
+        assert torch.equal(par, first)
+    finally:
+        e.low_latency = False
+    for _ in range(4):
+        outs["four2x2"].zero_()
+        e.conv(cwu, xa, B, H, W, outs["four2x2"], c0=cin, upsample=True)
+        torch.cuda.synchronize()
+        assert torch.equal(outs["four2x2"], first)
