@@ -4,6 +4,7 @@ Gate (BASELINE.json north_star): <= 1e-3 relative, fp32 parity mode.  bf16 mode 
 drift vs fp32 (L2-relative <= 2e-2, see SURVEY 'Hard parts': reference autocast(bf16) itself
 drifts 7.4e-3 L2 / 1.8e-2 max)."""
 import json
+import os
 
 import pytest
 import torch
