@@ -21,11 +21,9 @@
 
 namespace {
 
-constexpr int PG_T = 256;                      // tile: 256 pixels x 256 channels
+constexpr int PG_T = 256;                      // tile: 256 pixels x TNC channels (TNC = 256: one 8-wave workgroup per CU;
+                                               //   TNC = 128: two 4-wave workgroups per CU, one's epilogue under the other's MFMAs)
 constexpr int PG_RB = 64;                      // bytes of K per LDS row: one K32 step of bf16
-constexpr int PG_NS = 4;                       // ring slots
-constexpr int PG_SLOT = 2 * PG_T * PG_RB;      // 32 KB: 256 pixel rows, then 256 weight rows
-constexpr int PG_NTHR = 512;
 
 // 16-byte chunk c of 64-byte row r: conflict-free for the 16-row x 4-chunk fragment reads (round-3 ring experiment)
 __device__ __forceinline__ int pg_swz(int row, int chunk) { return (chunk ^ ((-(row >> 2)) & 3)) << 4; }
@@ -40,25 +38,32 @@ __device__ __forceinline__ void pg_wait_vm(int n) {
     case 4: PG_WAIT_VM(4); break;
     case 5: PG_WAIT_VM(5); break;
     case 6: PG_WAIT_VM(6); break;
+    case 7: PG_WAIT_VM(7); break;
     case 8: PG_WAIT_VM(8); break;
     case 9: PG_WAIT_VM(9); break;
     case 10: PG_WAIT_VM(10); break;
     case 12: PG_WAIT_VM(12); break;
     case 13: PG_WAIT_VM(13); break;
     case 14: PG_WAIT_VM(14); break;
+    case 15: PG_WAIT_VM(15); break;
     case 16: PG_WAIT_VM(16); break;
     case 17: PG_WAIT_VM(17); break;
     case 18: PG_WAIT_VM(18); break;
-    default: PG_WAIT_VM(0); break;               // (not reached: 4 (dA + dB) + (sA + sB) + 8 [e3 > 0])
+    default: PG_WAIT_VM(0); break;               // (not reached: DST x requests + stores + 8 [end-of-tile stores still younger])
     }
 }
 
-__global__ __launch_bounds__(PG_NTHR, 2) void pw_gemm_kernel(const fd_conv_params p, const int TM, const int TN, const int nst) {
+template <int TNC>
+__global__ __launch_bounds__(TNC * 2, 2) void pw_gemm_kernel(const fd_conv_params p, const int TM, const int TN, const int nst) {
+    constexpr int NWV = TNC / 32, WNW = TNC / 128;                        // waves (8 | 4) as 4 x WNW of 64 pixels x 128 channels
+    constexpr int PG_NS = TNC == 256 ? 4 : 3, LOOK = PG_NS - 1;           // ring slots; stages requested ahead of the one in the MFMAs
+    constexpr int PG_SLOT = (PG_T + TNC) * PG_RB;                         // 32 | 24 KB: 256 pixel rows, then TNC weight rows
+    constexpr int DPX = PG_T / 16 / NWV, DST = DPX + 2;                   // DMA instructions per wave and stage: pixel rows | all
     __shared__ __attribute__((aligned(1024))) unsigned char ring[PG_NS * PG_SLOT];
-    __shared__ __attribute__((aligned(16))) float s_ep[2][2][PG_T];      // [tile parity][bias | gate][channel of the tile]
+    __shared__ __attribute__((aligned(16))) float s_ep[2][2][TNC];       // [tile parity][bias | gate][channel of the tile]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;                              // 4 x 2 waves of 64 pixels x 128 channels
+    const int wm = wave / WNW, wn = wave % WNW;
     const int fr = lane & 15, fg = lane >> 4;
     const int K = p.c0, OHW = p.OH * p.OW, mpi = OHW / PG_T;              // row blocks per image
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
@@ -69,20 +74,26 @@ __global__ __launch_bounds__(PG_NTHR, 2) void pw_gemm_kernel(const fd_conv_param
     bf16 *O = (bf16 *)p.out;
 
     // ---- DMA roles.  A wave instruction fills 1 KiB = 16 rows x 64 B: lane -> (row lane / 4, physical chunk lane % 4),
-    // and fetches the LOGICAL chunk that belongs there.  Wave w fills rows [32 w, 32 w + 32) of both halves.
+    // and fetches the LOGICAL chunk that belongs there.  Wave w fills pixel rows [16 DPX w, 16 DPX (w + 1)) and weight rows
+    // [32 w, 32 w + 32).
     const int drow = lane >> 2;
-    const int dchunk = (lane & 3) ^ ((-(lane >> 4)) & 3);                 // (row >> 2) & 3 == lane >> 4 (32 w = 0 mod 4)
-    unsigned voff_px[2], voff_w[2];
+    const int dchunk = (lane & 3) ^ ((-(lane >> 4)) & 3);                 // (row >> 2) & 3 == lane >> 4 (row bases are 0 mod 16)
+    unsigned voff_px[DPX], voff_w[2];
+#pragma unroll
+    for (int h = 0; h < DPX; ++h) {
+        const int r = 16 * DPX * wave + 16 * h + drow;                    // tile row
+        voff_px[h] = (unsigned)((r * p.ld0 + 8 * dchunk) * 2);
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        const int r = 32 * wave + 16 * h + drow;                          // tile row
-        voff_px[h] = (unsigned)((r * p.ld0 + 8 * dchunk) * 2);
+        const int r = 32 * wave + 16 * h + drow;                          // weight row of the tile
         // weight row R of a 32-row group holds output channel ((R >> 2) & 3) * 8 + ((R >> 4) & 1) * 4 + (R & 3): the
         // transposed MFMA then leaves 8 CONSECUTIVE channels of one pixel in a lane (fd_conv.hip, PWE)
         const int R = r & 31, n = (r & ~31) | (((R >> 2) & 3) << 3) | (((R >> 4) & 1) << 2) | (R & 3);
         voff_w[h] = (unsigned)((n * K + 8 * dchunk) * 2);
     }
-    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)ring + wave * 2048;
+    const unsigned lds_px = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)ring + wave * (DPX * 1024);
+    const unsigned lds_wt = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)ring + PG_T * PG_RB + wave * 2048;
     auto dma = [&](const char *base, unsigned voff, unsigned dst) {       // dst: wave-uniform LDS byte address (M0)
         unsigned m0_saved;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
@@ -90,18 +101,24 @@ __global__ __launch_bounds__(PG_NTHR, 2) void pw_gemm_kernel(const fd_conv_param
     };
     // producer cursor: the stage that is requested next (tile pq of this XCD's list, K32 step pks)
     int pq = idx, pks = 0, pslot = 0;
+    const char *pa = nullptr, *pw = nullptr;                              // operand rows of the stage requested next (wave-uniform)
     auto produce = [&]() -> bool {                                        // request one stage; false when there is none left
         if (pq >= ntile_x) return false;
-        const int tm = (pq / TN) * 8 + xcd, tn = (pq - (pq / TN) * TN + (pq / TN) / rot_every) % TN;      // (column tiles rotate, see below)
-        const int b = tm / mpi, m0 = (tm - b * mpi) * PG_T;
-        const char *pa = (const char *)(A + ((int64_t)b * OHW + m0) * p.ld0 + p.off0 + 32 * pks);
-        const char *pw = (const char *)(Wt + (int64_t)b * p.w_batch_stride + (int64_t)tn * PG_T * K + 32 * pks);
-        const unsigned dst = lds0 + pslot * PG_SLOT;
+        if (pks == 0) {
+            // the tile's coordinates once per tile, not per stage: four integer divisions by runtime values are ~150 instructions,
+            // issued by every wave in front of the stage's MFMAs while -- one barrier per stage -- no other wave has matrix work either
+            const int tm = (pq / TN) * 8 + xcd, tn = (pq - (pq / TN) * TN + (pq / TN) / rot_every) % TN;      // (column tiles rotate, see below)
+            const int b = tm / mpi, m0 = (tm - b * mpi) * PG_T;
+            pa = (const char *)(A + ((int64_t)b * OHW + m0) * p.ld0 + p.off0);
+            pw = (const char *)(Wt + (int64_t)b * p.w_batch_stride + (int64_t)tn * TNC * K);
+        }
 #pragma unroll
-        for (int h = 0; h < 2; ++h) dma(pa, voff_px[h], dst + 1024 * h);
+        for (int h = 0; h < DPX; ++h) dma(pa, voff_px[h], lds_px + pslot * PG_SLOT + 1024 * h);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) dma(pw, voff_w[h], dst + PG_T * PG_RB + 1024 * h);
-        pslot = (pslot + 1) & (PG_NS - 1);
+        for (int h = 0; h < 2; ++h) dma(pw, voff_w[h], lds_wt + pslot * PG_SLOT + 1024 * h);
+        pslot = pslot + 1 == PG_NS ? 0 : pslot + 1;
+        pa += 2 * 32;                                                     // the next K32 step
+        pw += 2 * 32;
         if (++pks == nst) { pks = 0; pq += per_xcd; }
         return true;
     };
@@ -120,7 +137,7 @@ __global__ __launch_bounds__(PG_NTHR, 2) void pw_gemm_kernel(const fd_conv_param
     // operation that the counted waits below would have to account for.)
     auto store_q = [&](int u) {                                           // deferred store u of 8 (u: compile-time)
         const int jp = 2 + (u >> 2), i = u & 3;
-        const int m = sm0 + 64 * wm + 16 * i + fr, n0 = stn * PG_T + 128 * wn + 32 * jp + 8 * fg;
+        const int m = sm0 + 64 * wm + 16 * i + fr, n0 = stn * TNC + 128 * wn + 32 * jp + 8 * fg;
         *(u32x4 *)(O + ((int64_t)sb * OHW + m) * p.ldo + p.offo + n0) = outq[u];
     };
 
@@ -130,12 +147,14 @@ __global__ __launch_bounds__(PG_NTHR, 2) void pw_gemm_kernel(const fd_conv_param
     for (int i = 0; i < 4; ++i) { const int r = 64 * wm + 16 * i + fr; poff[i] = r * PG_RB + pg_swz(r, fg); }
     { const int r = 128 * wn + fr; woff0 = PG_T * PG_RB + r * PG_RB + pg_swz(r, fg); }     // + 16 j rows: (r + 16 j) >> 2 = same mod 4
 
-    bool d1 = produce(), d2, d0;                                          // stages 0, 1, 2 in flight before the first step
-    d0 = d1; d1 = produce(); d2 = produce();
+    // stages 0 .. LOOK - 1 in flight before the first step
     // history for the counted waits: dA / dB = was stage gs + 1 / gs + 2 requested, sA / sB = stores issued 2 / 1 steps ago
-    bool dA = d1, dB = d2, sA = false, sB = false;
+    // (LOOK = 2: one step of history -- dA and sA stay false, dB / sB are the step before)
+    bool dA = false, dB = false, sA = false, sB = false;
+    produce();
+    if constexpr (LOOK == 3) { dA = produce(); dB = produce(); }
+    else dB = produce();
     int e3 = 0;                                                           // steps for which the 8 stores of a tile's end are still younger than the awaited stage
-    (void)d0;
     int slot = 0, tcount = 0;
     for (int q = idx; q < ntile_x; q += per_xcd, ++tcount) {
         // the column tile of a row block's siblings rotates by one every `rot_every` row blocks (about once per round;
@@ -145,8 +164,8 @@ __global__ __launch_bounds__(PG_NTHR, 2) void pw_gemm_kernel(const fd_conv_param
         const int tm = (q / TN) * 8 + xcd, tn = (q - (q / TN) * TN + (q / TN) / rot_every) % TN;
         const int b = tm / mpi, m0 = (tm - b * mpi) * PG_T;
         const int par = tcount & 1;
-        if (tid < PG_T) {
-            const int n = tn * PG_T + tid;
+        if (tid < TNC) {
+            const int n = tn * TNC + tid;
             s_ep[par][0][tid] = p.bias ? p.bias[n] : 0.f;
             s_ep[par][1][tid] = p.epilogue == FD_EPI_GATE_RES ? p.gate[(int64_t)b * p.gate_ld + n] : 0.f;
         }
@@ -154,20 +173,24 @@ __global__ __launch_bounds__(PG_NTHR, 2) void pw_gemm_kernel(const fd_conv_param
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 // stage `slot` has landed once at most the operations issued after its request are outstanding
-                pg_wait_vm(4 * ((int)dA + (int)dB) + ((int)sA + (int)sB) + (e3 > 0 ? 8 : 0));
+                pg_wait_vm(DST * ((int)dA + (int)dB) + ((int)sA + (int)sB) + (e3 > 0 ? 8 : 0));
                 e3 = e3 > 0 ? e3 - 1 : 0;
                 __builtin_amdgcn_s_barrier();
-                const bool st = pending && g8 == 0;
-                if (st) store_q(u);
-                const bool dn = produce();                                // stage gs + 3 into the slot stage gs - 1 was read from
-                dA = dB; dB = dn; sA = sB; sB = st;
                 const unsigned char *sl = ring + slot * PG_SLOT;
                 {
+                    // the stage's first fragments are requested right behind the barrier: their LDS round trip runs under the
+                    // scalar work of the DMA requests below (every wave of the workgroup is at this point together -- one
+                    // barrier per stage -- so nothing else would cover it)
                     bf16x8 pf[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) pf[i] = *(const bf16x8 *)(sl + poff[i]);
                     // weight fragments one ahead of their MFMAs, never all eight at once
                     bf16x8 wn_ = *(const bf16x8 *)(sl + woff0);
+                    const bool st = pending && g8 == 0;
+                    if (st) store_q(u);
+                    const bool dn = produce();                            // stage gs + LOOK into the slot stage gs - 1 was read from
+                    if constexpr (LOOK == 3) { dA = dB; sA = sB; }
+                    dB = dn; sB = st;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const bf16x8 wf = wn_;
@@ -183,7 +206,7 @@ __global__ __launch_bounds__(PG_NTHR, 2) void pw_gemm_kernel(const fd_conv_param
                             asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(wf), "v"(pf[i]));
                     }
                 }
-                slot = (slot + 1) & (PG_NS - 1);
+                slot = slot + 1 == PG_NS ? 0 : slot + 1;
             }
             if (g8 == 0) pending = false;
         }
@@ -195,7 +218,7 @@ __global__ __launch_bounds__(PG_NTHR, 2) void pw_gemm_kernel(const fd_conv_param
         // pair of permuted 16-channel tiles), stored during the next tile's first eight stages
 #pragma unroll
         for (int jp = 0; jp < 4; ++jp) {
-            const int cl = 128 * wn + 32 * jp + 8 * fg, n0 = tn * PG_T + cl;
+            const int cl = 128 * wn + 32 * jp + 8 * fg, n0 = tn * TNC + cl;
             float bias8[8], gate8[8];
             load8(&s_ep[par][0][cl], bias8);
             if (p.epilogue == FD_EPI_GATE_RES) load8(&s_ep[par][1][cl], gate8);
@@ -231,7 +254,7 @@ __global__ __launch_bounds__(PG_NTHR, 2) void pw_gemm_kernel(const fd_conv_param
         }
         sb = b; sm0 = m0; stn = tn;
         pending = true;
-        e3 = 3;
+        e3 = LOOK;
     }
     if (pending) {
 #pragma unroll
@@ -265,7 +288,9 @@ int fd_pwgemm_ok(const fd_conv_params &p) {
 }
 
 int fd_pwgemm_launch(const fd_conv_params &p, hipStream_t s) {
-    const int TM = p.B * (int)((int64_t)p.OH * p.OW / 256), TN = p.Cout / 256;
-    hipLaunchKernelGGL(pw_gemm_kernel, dim3(256), dim3(PG_NTHR), 0, s, p, TM, TN, p.c0 / 32);
+    static const int tnc = [] { const char *e = getenv("FD_PWGEMM_TNC"); return e ? atoi(e) : 256; }();     // development
+    const int TM = p.B * (int)((int64_t)p.OH * p.OW / 256);
+    if (tnc == 128) hipLaunchKernelGGL(pw_gemm_kernel<128>, dim3(512), dim3(256), 0, s, p, TM, p.Cout / 128, p.c0 / 32);
+    else hipLaunchKernelGGL(pw_gemm_kernel<256>, dim3(256), dim3(512), 0, s, p, TM, p.Cout / 256, p.c0 / 32);
     return 0;
 }
