@@ -53,14 +53,23 @@ __device__ __forceinline__ void pg_wait_vm(int n) {
     }
 }
 
-template <int TNC>
+constexpr int PG_MAXC = 2048, PG_MAXG = 4096;     // bias: Cout floats; gate (GATE_RES): B x Cout floats (fd_pwgemm_ok)
+
+// EPI: the epilogue as a template parameter (FD_EPI_NONE / _SILU_SPLIT / _GATE_RES): as a runtime value it was ~60 scalar
+// branches per tile.  Only TNC = 256 is instantiated: two 4-wave workgroups per CU on 256 x 128 tiles (one's epilogue under
+// the other's MFMAs) measured 0-8 % slower at every shape of the forward.
+template <int TNC, int EPI>
 __global__ __launch_bounds__(TNC * 2, 2) void pw_gemm_kernel(const fd_conv_params p, const int TM, const int TN, const int nst) {
     constexpr int NWV = TNC / 32, WNW = TNC / 128;                        // waves (8 | 4) as 4 x WNW of 64 pixels x 128 channels
     constexpr int PG_NS = TNC == 256 ? 4 : 3, LOOK = PG_NS - 1;           // ring slots; stages requested ahead of the one in the MFMAs
     constexpr int PG_SLOT = (PG_T + TNC) * PG_RB;                         // 32 | 24 KB: 256 pixel rows, then TNC weight rows
     constexpr int DPX = PG_T / 16 / NWV, DST = DPX + 2;                   // DMA instructions per wave and stage: pixel rows | all
     __shared__ __attribute__((aligned(1024))) unsigned char ring[PG_NS * PG_SLOT];
-    __shared__ __attribute__((aligned(16))) float s_ep[2][2][TNC];       // [tile parity][bias | gate][channel of the tile]
+    // bias and gate of the WHOLE layer, staged once: staged per tile they were a global load in front of an LDS store, whose
+    // s_waitcnt vmcnt(0) -- the compiler does not know the DMAs in flight -- drained the three requested stages at the start
+    // of every tile
+    __shared__ __attribute__((aligned(16))) float s_bias[PG_MAXC];
+    __shared__ __attribute__((aligned(16))) float s_gate[EPI == FD_EPI_GATE_RES ? PG_MAXG : 4];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WNW, wn = wave % WNW;
@@ -147,6 +156,10 @@ __global__ __launch_bounds__(TNC * 2, 2) void pw_gemm_kernel(const fd_conv_param
     for (int i = 0; i < 4; ++i) { const int r = 64 * wm + 16 * i + fr; poff[i] = r * PG_RB + pg_swz(r, fg); }
     { const int r = 128 * wn + fr; woff0 = PG_T * PG_RB + r * PG_RB + pg_swz(r, fg); }     // + 16 j rows: (r + 16 j) >> 2 = same mod 4
 
+    for (int n = tid; n < p.Cout; n += TNC * 2) s_bias[n] = p.bias ? p.bias[n] : 0.f;
+    if constexpr (EPI == FD_EPI_GATE_RES)
+        for (int i = tid; i < p.B * p.Cout; i += TNC * 2) s_gate[i] = p.gate[(int64_t)(i / p.Cout) * p.gate_ld + i % p.Cout];
+    __syncthreads();
     // stages 0 .. LOOK - 1 in flight before the first step
     // history for the counted waits: dA / dB = was stage gs + 1 / gs + 2 requested, sA / sB = stores issued 2 / 1 steps ago
     // (LOOK = 2: one step of history -- dA and sA stay false, dB / sB are the step before)
@@ -155,25 +168,26 @@ __global__ __launch_bounds__(TNC * 2, 2) void pw_gemm_kernel(const fd_conv_param
     if constexpr (LOOK == 3) { dA = produce(); dB = produce(); }
     else dB = produce();
     int e3 = 0;                                                           // steps for which the 8 stores of a tile's end are still younger than the awaited stage
-    int slot = 0, tcount = 0;
-    for (int q = idx; q < ntile_x; q += per_xcd, ++tcount) {
+    int slot = 0;
+    for (int q = idx; q < ntile_x; q += per_xcd) {
         // the column tile of a row block's siblings rotates by one every `rot_every` row blocks (about once per round;
         // constant inside a sibling group, so the tile map stays a bijection): with TN a divisor of the workgroups per XCD
         // a workgroup would otherwise keep ONE column tile for all its rounds, and the column tiles are not equally
         // expensive (SILU_SPLIT applies the SiLU to the upper half of the channels only)
         const int tm = (q / TN) * 8 + xcd, tn = (q - (q / TN) * TN + (q / TN) / rot_every) % TN;
         const int b = tm / mpi, m0 = (tm - b * mpi) * PG_T;
-        const int par = tcount & 1;
-        if (tid < TNC) {
-            const int n = tn * TNC + tid;
-            s_ep[par][0][tid] = p.bias ? p.bias[n] : 0.f;
-            s_ep[par][1][tid] = p.epilogue == FD_EPI_GATE_RES ? p.gate[(int64_t)b * p.gate_ld + n] : 0.f;
-        }
         for (int g8 = 0; g8 < nst; g8 += 8) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 // stage `slot` has landed once at most the operations issued after its request are outstanding
-                pg_wait_vm(DST * ((int)dA + (int)dB) + ((int)sA + (int)sB) + (e3 > 0 ? 8 : 0));
+                {
+                    // (the two values of a tile's steady state first: as one switch the wait was a tree of ~10 scalar branches
+                    //  per stage, 14 % of the K loop's time)
+                    const int wv = DST * ((int)dA + (int)dB) + ((int)sA + (int)sB) + (e3 > 0 ? 8 : 0);
+                    if (wv == (LOOK - 1) * DST) PG_WAIT_VM((LOOK - 1) * DST);
+                    else if (wv == (LOOK - 1) * DST + (LOOK - 1)) PG_WAIT_VM((LOOK - 1) * DST + (LOOK - 1));
+                    else pg_wait_vm(wv);
+                }
                 e3 = e3 > 0 ? e3 - 1 : 0;
                 __builtin_amdgcn_s_barrier();
                 const unsigned char *sl = ring + slot * PG_SLOT;
@@ -184,8 +198,10 @@ __global__ __launch_bounds__(TNC * 2, 2) void pw_gemm_kernel(const fd_conv_param
                     bf16x8 pf[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) pf[i] = *(const bf16x8 *)(sl + poff[i]);
-                    // weight fragments one ahead of their MFMAs, never all eight at once
-                    bf16x8 wn_ = *(const bf16x8 *)(sl + woff0);
+                    // weight fragments TWO ahead of their MFMAs (an LDS round trip under load is ~200 cycles: one group of four
+                    // MFMAs per wave, 2 x 64 cycles with the SIMD's other wave, did not cover it -- the K loop alone ran at 0.48
+                    // of the peak), never all eight at once
+                    bf16x8 wn_ = *(const bf16x8 *)(sl + woff0), wn2_ = *(const bf16x8 *)(sl + woff0 + 16 * PG_RB);
                     const bool st = pending && g8 == 0;
                     if (st) store_q(u);
                     const bool dn = produce();                            // stage gs + LOOK into the slot stage gs - 1 was read from
@@ -194,7 +210,8 @@ __global__ __launch_bounds__(TNC * 2, 2) void pw_gemm_kernel(const fd_conv_param
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const bf16x8 wf = wn_;
-                        if (j + 1 < 8) wn_ = *(const bf16x8 *)(sl + woff0 + 16 * (j + 1) * PG_RB);
+                        wn_ = wn2_;
+                        if (j + 2 < 8) wn2_ = *(const bf16x8 *)(sl + woff0 + 16 * (j + 2) * PG_RB);
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
@@ -220,8 +237,8 @@ __global__ __launch_bounds__(TNC * 2, 2) void pw_gemm_kernel(const fd_conv_param
         for (int jp = 0; jp < 4; ++jp) {
             const int cl = 128 * wn + 32 * jp + 8 * fg, n0 = tn * TNC + cl;
             float bias8[8], gate8[8];
-            load8(&s_ep[par][0][cl], bias8);
-            if (p.epilogue == FD_EPI_GATE_RES) load8(&s_ep[par][1][cl], gate8);
+            load8(&s_bias[n0], bias8);
+            if constexpr (EPI == FD_EPI_GATE_RES) load8(&s_gate[b * p.Cout + n0], gate8);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float val[8];
@@ -232,9 +249,9 @@ __global__ __launch_bounds__(TNC * 2, 2) void pw_gemm_kernel(const fd_conv_param
                     acc[i][2 * jp][e] = 0.f;
                     acc[i][2 * jp + 1][e] = 0.f;
                 }
-                if (p.epilogue == FD_EPI_SILU_SPLIT) {
+                if constexpr (EPI == FD_EPI_SILU_SPLIT) {
                     if (n0 >= p.epi_split) fd_silu8(val);
-                } else if (p.epilogue == FD_EPI_GATE_RES) {
+                } else if constexpr (EPI == FD_EPI_GATE_RES) {
                     const int m = m0 + 64 * wm + 16 * i + fr;
                     float rs[8];
                     load8((const bf16 *)p.res + ((int64_t)b * OHW + m) * p.ld_res + p.off_res + n0, rs);
@@ -277,7 +294,7 @@ int fd_pwgemm_ok(const fd_conv_params &p) {
     if (p.epilogue == FD_EPI_SILU_SPLIT && p.epi_split % 8) return 0;
     if (p.ld0 % 8 || p.off0 % 8 || p.ldo % 8 || p.offo % 8) return 0;
     if (p.epilogue == FD_EPI_GATE_RES && (!p.res || !p.gate || p.ld_res % 8 || p.off_res % 8)) return 0;
-    if (p.bias && ((uintptr_t)p.bias & 15)) return 0;
+    if (p.Cout > PG_MAXC || (p.epilogue == FD_EPI_GATE_RES && (int64_t)p.B * p.Cout > PG_MAXG)) return 0;     // the LDS tables
     if ((int64_t)p.OH * p.OW * p.ld0 * 2 >= (1ll << 31) || (int64_t)p.Cout * p.c0 * 2 >= (1ll << 31)) return 0;   // 32-bit DMA offsets
     const int64_t tiles = (int64_t)p.B * ((int64_t)p.OH * p.OW / 256) * (p.Cout / 256);
     // K = 256 tiles with the SiLU epilogue are epilogue-bound (8 stages of MFMA against ~1000 VALU instructions per lane):
@@ -288,9 +305,9 @@ int fd_pwgemm_ok(const fd_conv_params &p) {
 }
 
 int fd_pwgemm_launch(const fd_conv_params &p, hipStream_t s) {
-    static const int tnc = [] { const char *e = getenv("FD_PWGEMM_TNC"); return e ? atoi(e) : 256; }();     // development
-    const int TM = p.B * (int)((int64_t)p.OH * p.OW / 256);
-    if (tnc == 128) hipLaunchKernelGGL(pw_gemm_kernel<128>, dim3(512), dim3(256), 0, s, p, TM, p.Cout / 128, p.c0 / 32);
-    else hipLaunchKernelGGL(pw_gemm_kernel<256>, dim3(256), dim3(512), 0, s, p, TM, p.Cout / 256, p.c0 / 32);
+    const int TM = p.B * (int)((int64_t)p.OH * p.OW / 256), TN = p.Cout / 256, nst = p.c0 / 32;
+    if (p.epilogue == FD_EPI_SILU_SPLIT) hipLaunchKernelGGL((pw_gemm_kernel<256, FD_EPI_SILU_SPLIT>), dim3(256), dim3(512), 0, s, p, TM, TN, nst);
+    else if (p.epilogue == FD_EPI_GATE_RES) hipLaunchKernelGGL((pw_gemm_kernel<256, FD_EPI_GATE_RES>), dim3(256), dim3(512), 0, s, p, TM, TN, nst);
+    else hipLaunchKernelGGL((pw_gemm_kernel<256, FD_EPI_NONE>), dim3(256), dim3(512), 0, s, p, TM, TN, nst);
     return 0;
 }
