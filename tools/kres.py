@@ -55,7 +55,10 @@ def check_drain(src):
         parts = ops[1].split(",", 1)
         is_store = ops[0].startswith(("ds_write", "global_store", "buffer_store", "scratch_store", "flat_store"))
         return ops[0], (set() if is_store else regs(parts[0])), regs(ops[1] if is_store else (parts[1] if len(parts) > 1 else ""))
-    is_ins = lambda t: t and not t.startswith((";", ".")) and not t.endswith(":") and ":" not in t.split()[0]
+    # (a label may carry a comment: ".LBB1_30:      ; in Loop: Header=BB1_32 Depth=1")
+    is_label = lambda t: re.match(r"^[.\w$@]+:(\s*;.*)?$", t) is not None
+    label_of = lambda t: t.split(":")[0]
+    is_ins = lambda t: t and not t.startswith((";", ".")) and not is_label(t) and ":" not in t.split()[0]
     # per function (register numbers mean nothing across kernels): [start, end) line ranges and their MFMA destinations
     bounds = [k for k, t in enumerate(lines) if t.startswith(".type") and "@function" in t] + [len(lines)]
     fn_of = lambda k: max(b for b in bounds[:-1] if b <= k) if any(b <= k for b in bounds[:-1]) else 0
@@ -72,19 +75,23 @@ def check_drain(src):
         no VALU instruction in it may read an MFMA destination that the run itself has not redefined"""
         j = end - 1
         run = []
-        while j >= 0 and not lines[j].startswith("v_mfma") and not lines[j].endswith(":"):
+        while j >= 0 and not lines[j].startswith("v_mfma") and not is_label(lines[j]):
             if is_ins(lines[j]):
                 run.append(lines[j])
             j -= 1
         redef, n = set(), 0
         mfma_dst = fn_dst.get(fn_of(end), set())
+        if j >= 0 and is_label(lines[j]) and not lines[j].startswith(".L"):
+            # the run is the function's ENTRY block (its label is the kernel symbol, e.g. the path on which a K loop with a
+            # runtime trip count is skipped): no MFMA of this kernel has been issued on it, whatever its registers hold
+            return 0, None
         for ins in reversed(run):
             op, d, sr = dst_src(ins)
             if op.startswith("v_") and (sr & mfma_dst) - redef:
                 n += 1
                 print(f"{src}: `{ins}` reads an MFMA result in front of {what}")
             redef |= d
-        return n, (lines[j][:-1] if j >= 0 and lines[j].endswith(":") else None)
+        return n, (label_of(lines[j]) if j >= 0 and is_label(lines[j]) else None)
 
     blocks = bad = 0
     for i, ln in enumerate(lines):
