@@ -190,7 +190,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
                 const int ho = halo_geom(tl, i, hq, ty0, tx0, interior, v);
                 if (v) hvalid |= 1u << i;
 #pragma unroll
-                for (int h = 0; h < HG; ++h) rh[i][h] = *(const u32x4 *)(src + (int64_t)ho * ld + cc + 8 * h);
+                for (int h = 0; h < HG; ++h) {
+                    const bf16 *ap = src + (int64_t)ho * ld + cc + 8 * h;
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rh[i][h]) : "v"(ap));      // (see below: hidden from the compiler's waits)
+                }
             }
         } else {
             // a 64-channel slab lies in ONE source (c0 % 64 == 0): wave-uniform base + a 32-bit byte offset per load
@@ -204,8 +207,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
                 bool v;
                 const unsigned h = (unsigned)halo_geom(tl, i, hq, ty0, tx0, interior, v);
                 if (v) hvalid |= 1u << i;
-                rh[i][0] = *(const u32x4 *)(src + (h * ld2 + cc2));
-                if constexpr (SPL) rh[i][1] = *(const u32x4 *)(src + (h * ld2 + cc2 + 16));       // 8 fp32 channels = 32 bytes
+                // The loads are issued through inline asm so that the compiler's s_waitcnt pass does not know them: it counted
+                // only ITS outstanding operations, i.e. its wait in front of halo_lstore's first ds_write was vmcnt(HL - 1) ..
+                // vmcnt(0) -- a drain of every weight DMA in flight (the tiles of the next unit's taps 1 and 2, requested a tap
+                // or two earlier) at EVERY unit boundary; the ring's two-tap lead ended there.  The counted waits of the tap loop
+                // already guarantee more than is needed: the last tap's barrier allows NB operations in flight, all of them
+                // younger than these loads (issued at tap 0).
+                // (not where the kernel spills -- the 128-channel split form, 20 bytes --: a register parked in scratch before its
+                //  load has landed would park garbage)
+                const unsigned go = h * ld2 + cc2;
+                if constexpr (SPL && BN == 128) {
+                    rh[i][0] = *(const u32x4 *)(src + go);
+                    rh[i][1] = *(const u32x4 *)(src + (go + 16));
+                } else {
+                    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rh[i][0]) : "v"(go), "s"(src));
+                    if constexpr (SPL) asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(rh[i][1]) : "v"(go), "s"(src));       // 8 fp32 channels = 32 bytes
+                }
             }
         }
     };
@@ -389,7 +406,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
     w_dma(cls_begin, 0, 1, WT_B);
     if constexpr (!F8) w_dma(cls_begin, 0, 2, 2 * WT_B);
     halo_gload(0, ty0, tx0);
-    halo_lstore();                                   // consumes the youngest loads: everything above has landed
+    FD_WAIT_VM(0);                                   // (the halo loads are asm: no compiler wait in front of their first use)
+    halo_lstore();
     FD_WAIT_VM(0);
     __syncthreads();
     if constexpr (!F8) {
