@@ -645,7 +645,7 @@ int fd_conv3x3_rw_launch(const fd_conv_params &p, hipStream_t s);
 int fd_pwgemm_ok(const fd_conv_params &p);
 int fd_pwgemm_launch(const fd_conv_params &p, hipStream_t s);
 
-// Which kernel fd_conv2d dispatches `p` to: 10 streaming row-GEMM, 11 halo-tiled 3x3 (12: its fp8 form; 14: an up-sampling 3x3
+// Which kernel fd_conv2d dispatches `p` to: 10 streaming row-GEMM (17: its fp32-storage split-bf16 form, fd_gemm_rows32.hip), 11 halo-tiled 3x3 (12: its fp8 form; 14: an up-sampling 3x3
 // as four 2x2 convolutions on the source grid, weight_up2x; 15: its split-bf16 form on fp32 storage; 16: both at once), 13 the 64 -> 64 3x3 with
 // the weights resident in registers (fd_conv3x3_rw.hip), else the
 // implicit-GEMM tile variant 0 <128,128>, 1 <128,64>, 2 <64,128>, 3 <64,64>, 4 <128,256>, 5 <256,256>, 6 <128,32> (BM, BN);
@@ -653,7 +653,7 @@ int fd_pwgemm_launch(const fd_conv_params &p, hipStream_t s);
 extern "C" int fd_conv_fp8_ok(const fd_conv_params *pp) { return pp && !fd_conv_prologue_ok(pp) && fd_conv3x3_fp8_ok(*pp); }
 
 extern "C" int fd_conv_kernel_id(const fd_conv_params *pp) {
-    if (fd_conv_prologue_ok(pp)) return 10;
+    if (fd_conv_prologue_ok(pp)) return pp->dtype == FD_F32 ? 17 : 10;
     if (fd_conv3x3_rw_ok(*pp)) return 13;
     if (fd_conv3x3_ok(*pp)) return fd_conv3x3_fp8_ok(*pp) ? 12 : (fd_conv3x3_up2x_ok(*pp) ? 14 : 11);
     if (fd_conv3x3_up2x_split_ok(*pp)) return 16;
@@ -700,7 +700,7 @@ extern "C" int fd_conv2d(const fd_conv_params *pp, void *stream) {
     FD_REQUIRE(p.ndir == 1 || p.ndir == 4, "fd_conv2d: ndir must be 1 or 4");
     FD_REQUIRE(p.epilogue >= FD_EPI_NONE && p.epilogue <= FD_EPI_GNSILU_ADD_FINAL, "fd_conv2d: bad epilogue %d", p.epilogue);
     FD_REQUIRE(p.epilogue != FD_EPI_GNSILU_ADD_FINAL || fd_conv_prologue_ok(pp),
-               "fd_conv2d: GNSILU_ADD_FINAL runs on the streaming row-GEMM only (bf16, 1x1, >= 16384 px, fin_* set)");
+               "fd_conv2d: GNSILU_ADD_FINAL runs on the streaming row-GEMM only (bf16 or fp32s, 1x1, >= 16384 px, fin_* set)");
     if (p.epilogue == FD_EPI_GATE_RES) FD_REQUIRE(p.res && p.gate, "fd_conv2d: GATE_RES needs res and gate");
     if (p.epilogue == FD_EPI_RES_RELU) FD_REQUIRE(p.res, "fd_conv2d: RES_RELU needs res");
     if (p.epilogue == FD_EPI_GNSILU_ADD || p.epilogue == FD_EPI_GNSILU_ADD_FINAL)

@@ -509,10 +509,14 @@ void launch_rows(const fd_conv_params &p, int nt, dim3 grid, size_t lds, int wti
 
 }  // namespace
 
+int fd_rows32_ok(const fd_conv_params &p);                          // fd_gemm_rows32.hip: fp32 storage, split-bf16 contractions
+int fd_gemm_rows32_launch(const fd_conv_params &p, hipStream_t s);
+
 // 1 if `p` can run on the streaming row-GEMM (and therefore may carry a fused LN prologue).
 extern "C" int fd_conv_prologue_ok(const fd_conv_params *pp) {
     const fd_conv_params &p = *pp;
     const int K = p.c0 + p.c1;
+    if (p.dtype == FD_F32) return fd_rows32_ok(p);
     if (p.dtype != FD_BF16 || p.out_f32) return 0;
     if (p.KH != 1 || p.KW != 1 || p.stride != 1 || p.pad_h != 0 || p.pad_w != 0 || p.upsample || p.ndir != 1) return 0;
     if (p.OH != p.H || p.OW != p.W) return 0;
@@ -547,6 +551,7 @@ extern "C" int fd_conv_prologue_ok(const fd_conv_params *pp) {
 constexpr int ZRE8_NT = 512;
 
 int fd_gemm_rows_launch(const fd_conv_params &p, hipStream_t s) {
+    if (p.dtype == FD_F32) return fd_gemm_rows32_launch(p, s);
     const int K = p.c0 + p.c1, KS = K / 32, RS = row_stride(K);
     const int64_t hw = (int64_t)p.H * p.W;
     const int px = KS <= 2 ? 32 : 16;      // pixels per wave iteration (see template parameter S)

@@ -372,7 +372,7 @@ class DAEngine:
         p.OW = OW if OW is not None else (Ws + 2 * pad - KW) // stride + 1
         p.ndir = ndir
         wt = weight if weight is not None else cw.w
-        p.weight, p.w_batch_stride, p.w_dir_stride = wt.data_ptr(), w_batch_stride, w_dir_stride
+        p.weight, p.w_batch_stride, p.w_dir_stride = ptr(wt), w_batch_stride, w_dir_stride
         bt = (cw.b if cw is not None else None) if isinstance(bias, str) else bias
         p.bias = bt.data_ptr() if bt is not None else None
         p.Cout = Cout
@@ -423,6 +423,28 @@ class DAEngine:
             return bool(L.lib().fd_conv_prologue_ok(C.byref(p)))
         L.call("fd_conv2d", C.byref(p), self.stream)
         return p.OH, p.OW
+
+    def conv_cols(self, cw, x, B, H, W, out, ldo, nchunks, *, split=None, **kw):
+        """A bias-free 1x1 convolution as `nchunks` launches over equal column (output channel) ranges of its weight matrix, each
+        writing its channels of `out` (row stride `ldo`): the fp32s row-GEMM keeps TWO bf16 images of its weights in LDS
+        (fd_gemm_rows32.hip), and the widest layers (in_proj 128 -> 512, qkv 128 -> 384) only fit in halves / thirds.  Every
+        launch reads the (narrow) input again and runs the fused LayerNorm prologue again; the wide output is written once.
+        `split`: SiLU on output channels >= split (EPI_SILU_SPLIT over the whole matrix).  Returns False -- nothing launched --
+        when a chunk does not fit either."""
+        assert cw.KH == 1 and cw.KW == 1 and cw.b is None and cw.Cout % nchunks == 0
+        n = cw.Cout // nchunks
+        es = cw.w.element_size()
+        calls = []
+        for j in range(nchunks):
+            k2 = dict(kw, weight=C.c_void_p(cw.w.data_ptr() + j * n * cw.Cin * es), bias=None, Cout=n, ldo=ldo, offo=j * n)
+            if split is not None:
+                k2.update(epi=L.EPI_SILU_SPLIT, split=min(max(split - j * n, 0), n))
+            if not self.conv(cw, x, B, H, W, out, probe=True, **k2):
+                return False
+            calls.append(k2)
+        for k2 in calls:
+            self.conv(cw, x, B, H, W, out, **k2)
+        return True
 
     def linear(self, x, w, b, out, act=L.ACT_NONE, pre_silu=False):
         M, K = x.shape
@@ -504,6 +526,8 @@ class DAEngine:
             self.conv(m["in_proj"], x, B, H, W, xz, epi=L.EPI_SILU_SPLIT, split=D, **ln1, **xonly)
         elif self.conv(m["in_proj"], x, B, H, W, xz, epi=L.EPI_SILU_SPLIT, split=D, probe=True, **ln1):
             self.conv(m["in_proj"], x, B, H, W, xz, epi=L.EPI_SILU_SPLIT, split=D, **ln1)
+        elif getattr(self, "f32_split", 0) and self.conv_cols(m["in_proj"], x, B, H, W, xz, 2 * D, 2, split=D, **ln1):
+            pass                                          # fp32s, C = 128: the x half and the z half as two row-GEMM launches
         else:
             xm = self._b("xm", (B, H, W, Cc))
             L.call("fd_ln_modulate", self.dt, _p(x), _p(m["n1w"]), _p(m["n1b"]), 1e-5, mp(0), mp(1), ml, _p(xm),
@@ -584,6 +608,8 @@ class DAEngine:
             qkv = self._b("qkv", (B, H, W, 3 * Cc))
             if self.conv(m["qkv"], x1, B, H, W, qkv, probe=True, **ln2):
                 self.conv(m["qkv"], x1, B, H, W, qkv, **ln2)
+            elif getattr(self, "f32_split", 0) and self.conv_cols(m["qkv"], x1, B, H, W, qkv, 3 * Cc, 3, **ln2):
+                pass                                      # fp32s, C = 128: q, k, v as three row-GEMM launches
             else:
                 xm2 = self._b("xm", (B, H, W, Cc))
                 L.call("fd_ln_modulate", self.dt, _p(x1), None, None, 1e-6, mp(3), mp(4), ml, _p(xm2), B, hw, Cc, s)
@@ -908,7 +934,8 @@ class DAEngine:
         if sched is not None:
             fin.update(mode=1, alpha=sched[0], last=int(bool(sched[1])), img=x_t, xin=x_in)
         kw = dict(c0=c0, in1=r, c1=c1)
-        if fr["res"] is not None and self.tdt == torch.bfloat16 and not self.probe and not os.environ.get("FOUNDDIFF_NO_FINAL_FOLD"):
+        if (fr["res"] is not None and (self.tdt == torch.bfloat16 or getattr(self, "f32_split", 0)) and not self.probe
+                and not os.environ.get("FOUNDDIFF_NO_FINAL_FOLD")):
             mt = L.lib().fd_conv_mtiles(H, W)
             hraw = self._b("res_h", (B, H, W, cw.Cout))
             part = self._b("gn_part", (B, mt, cw.Cout, 2), torch.float32)

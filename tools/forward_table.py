@@ -32,7 +32,7 @@ trace, L.TRACE = L.TRACE, None
 lib = L.lib()
 KID = {0: "igemm 128x128", 1: "igemm 128x64", 2: "igemm 64x128", 3: "igemm 64x64", 4: "igemm 128x256", 5: "igemm 256x256",
        6: "igemm 128x32", 7: "pw_gemm 256x256 persistent", 10: "row-GEMM", 11: "halo 3x3", 12: "halo 3x3 fp8", 13: "3x3 weights in registers", 14: "halo 3x3, up-sampling as four 2x2 (GFLOP of the 9-tap form)",
-       15: "halo 3x3 split-bf16 (fp32 storage)", 16: "halo 3x3 split-bf16, up-sampling as four 2x2 (GFLOP of the 9-tap form)"}
+       15: "halo 3x3 split-bf16 (fp32 storage)", 16: "halo 3x3 split-bf16, up-sampling as four 2x2 (GFLOP of the 9-tap form)", 17: "row-GEMM fp32 storage split-bf16"}
 rows, tot_ms, tot_fl = [], 0.0, 0.0
 for n, args in trace:
     ms = bench._time_launches(lib, [(n, args)], reps=3)
