@@ -10,6 +10,7 @@ LIB_PATH = os.environ.get("FOUNDDIFF_LIB") or os.path.join(HERE, "lib", "libfoun
 
 FD_F32, FD_BF16 = 0, 1
 FD_OPT_LOW_LATENCY = 0x100
+FD_OPT_F32_SPLIT = 0x200
 EPI_NONE, EPI_SILU_SPLIT, EPI_RELU, EPI_GATE_RES, EPI_RES_RELU, EPI_GNSILU_ADD, EPI_GNSILU_ADD_FINAL = range(7)
 ACT_NONE, ACT_SILU, ACT_GELU, ACT_RELU = range(4)
 PRO_NONE, PRO_LN_MOD, PRO_LN_GATE, PRO_LN_GATE_ZRE = range(4)
@@ -76,6 +77,13 @@ SIGNATURES = {
     "fd_pw_dw3x3_gram": (i32, [i32, vp, i32, i32, i32, vp, vp, f32, vp, vp, i32, vp, vp, vp, i32, i32, vp, i32, i32, i32, vp]),
     "fd_pw_dw3x3_proj_ok": (i32, [i32, i32, i32, i32]),
     "fd_pw_dw3x3_proj": (i32, [i32, vp, i32, i32, i32, vp, vp, f32, vp, vp, i32, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp]),
+    "fd_pw_dw3x3_f32_ok": (i32, [i32, i32, i32, i32, i32]),
+    "fd_pw_dw3x3_f32": (i32, [vp, i32, i32, i32, vp, vp, f32, vp, vp, i32, vp, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp]),
+    "fd_pw_dw3x3_gram_f32_ok": (i32, [i32, i32, i32, i32]),
+    "fd_pw_dw3x3_gram_f32_nblk": (i32, [i32, i32]),
+    "fd_pw_dw3x3_gram_f32": (i32, [vp, i32, i32, i32, vp, vp, f32, vp, vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, vp]),
+    "fd_pw_dw3x3_proj_f32_ok": (i32, [i32, i32, i32, i32]),
+    "fd_pw_dw3x3_proj_f32": (i32, [vp, i32, i32, i32, vp, vp, f32, vp, vp, i32, vp, vp, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp]),
     "fd_dwconv_gram_ok": (i32, [i32, i32, i32, i32]),
     "fd_dwconv_gram_nblk": (i32, [i32, i32]),
     "fd_dwconv_gram": (i32, [i32, vp, i32, i32, vp, vp, i32, i32, i32, vp]),

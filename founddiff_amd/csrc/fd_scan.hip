@@ -161,8 +161,71 @@ __global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 16 && R >= 16 ? 4 : (N >=
             }
         }
     }
+    // ---- the same on fp32 storage (the fp32s engine, FD_OPT_F32_SPLIT): fp32 pixels and fp32 x_proj weights, every product as
+    // three bf16 MFMAs on hi / lo operand halves (x_hi.w_hi + x_lo.w_hi + x_hi.w_lo, ~2^-16: the arithmetic of that engine's
+    // other contractions).  Round 6: until then the fp32 modes ran x_proj as its own launch (4 stride-2 sub-grid GEMMs over xc).
+    if constexpr (!FINAL && sizeof(T) == 4) {
+        if (g.xw) {
+            const float *Wk = (const float *)g.xw + (int64_t)k * CD * g.D;
+            const float *ubx = (const float *)xc + (int64_t)b * g.H * g.W * g.D;
+            float *xo = g.xdbl_out + ((int64_t)k * g.B + b) * g.L * g.CD;
+            constexpr int MB = (CD + 15) / 16, KSM = 8;               // d_inner <= 256 (launcher)
+            const int fr = lane & 15, fg = lane >> 4;
+            const int nblk = (l1 - l0 + 15) >> 4;
+            const int nks = g.D >> 5;
+            for (int nb = wave; nb < nblk; nb += nw) {
+                const int l = l0 + nb * 16 + fr;
+                int h2, w2;
+                if (odd) { w2 = l / g.H2; h2 = l - w2 * g.H2; }
+                else { h2 = l / g.W2; w2 = l - h2 * g.W2; }
+                const int hh = 2 * h2 + ph, ww = 2 * w2 + pw;
+                const bool inimg = l < l1 && hh < g.H && ww < g.W;      // odd sizes: padded positions are zero rows
+                const float *px = ubx + ((int64_t)hh * g.W + ww) * g.D + 8 * fg;
+                const int lrow = h2 * g.W2 + w2;
+                bf16x8 bh[KSM], bl[KSM];
+#pragma unroll
+                for (int ks = 0; ks < KSM; ++ks) {
+                    float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    if (ks < nks && inimg) load8(px + 32 * ks, f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const bf16 hv = (bf16)f[e];
+                        bh[ks][e] = hv;
+                        bl[ks][e] = (bf16)(f[e] - (float)hv);
+                    }
+                }
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    const int e = mb * 16 + fr;
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < KSM; ++ks) {
+                        if (ks < nks) {
+                            float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                            if (e < CD) load8(Wk + (int64_t)e * g.D + 32 * ks + 8 * fg, f);
+                            bf16x8 ah, al;
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) {
+                                const bf16 hv = (bf16)f[q];
+                                ah[q] = hv;
+                                al[q] = (bf16)(f[q] - (float)hv);
+                            }
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[ks], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[ks], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[ks], acc, 0, 0, 0);
+                        }
+                    }
+                    const int e0 = mb * 16 + 4 * fg;                    // CD % 4 == 0 (launcher): all four or none
+                    if (l < l1 && e0 < CD) {
+                        *(f32x4 *)&sx[(nb * 16 + fr) * CDP + e0] = acc;
+                        *(f32x4 *)&xo[(int64_t)lrow * CD + e0] = acc;
+                    }
+                }
+            }
+        }
+    }
     // ---- stage the chunk's rows (phase A with the fused x_proj writes them itself)
-    if (FINAL || sizeof(T) != 2 || !g.xw)
+    if (FINAL || !g.xw)
     for (int idx = threadIdx.x; idx < (l1 - l0) * CD; idx += blockDim.x) {
         const int row = idx / CD, e = idx - row * CD;
         const int l = l0 + row;
@@ -980,8 +1043,8 @@ static int scan_entry(int dtype_opts, const void *xc, const void *x_proj_w, floa
     FD_REQUIRE((int64_t)H * W * D * 4 < (1ll << 31), "fd_selective_scan: one image must stay below 2^31 bytes");
     ScanGeom g = make_geom(B, H, W, D, N, R, (dtype_opts & FD_OPT_LOW_LATENCY) != 0);
     if (x_proj_w) {
-        FD_REQUIRE(fd_selective_scan_fuses_xproj(dtype, D, N, R), "fd_selective_scan_xproj: not available for this shape "
-                   "(bf16, d_inner <= 256, (R + 2N) %% 4 == 0): D=%d N=%d R=%d", D, N, R);
+        FD_REQUIRE(fd_selective_scan_fuses_xproj(dtype_opts & (0xff | FD_OPT_F32_SPLIT), D, N, R), "fd_selective_scan_xproj: not available for this shape "
+                   "(bf16 or fp32 | FD_OPT_F32_SPLIT, d_inner <= 256, (R + 2N) %% 4 == 0): D=%d N=%d R=%d", D, N, R);
         FD_REQUIRE(((uintptr_t)x_proj_w & 15) == 0 && ((uintptr_t)xc & 15) == 0, "fd_selective_scan_xproj: 16-byte alignment");
         g.xw = x_proj_w;
         g.xdbl_out = xdbl;
@@ -1002,8 +1065,15 @@ extern "C" int fd_selective_scan(int dtype, const void *xc, const float *xdbl, c
 
 // 1 if fd_selective_scan_xproj can compute the x_proj rows inside its first phase for this shape: bf16, one
 // workgroup per chunk (d_inner <= 256, so no workgroup repeats another's rows), rows of whole 16-byte groups.
-extern "C" int fd_selective_scan_fuses_xproj(int dtype, int D, int N, int R) {
-    return dtype == FD_BF16 && D % 64 == 0 && D <= 256 && (R + 2 * N) % 4 == 0;
+extern "C" int fd_selective_scan_fuses_xproj(int dtype_opts, int D, int N, int R) {
+    const int dtype = dtype_opts & 0xff;
+    // (fp32 storage: only with FD_OPT_F32_SPLIT -- the x_proj rows then come from three bf16 MFMAs per product, which the exact
+    //  fp32 parity mode does not use anywhere)
+    // (measured, batch-8 launches of the fp32s forward, profiles/r06: d_inner 128 / N 4 at 512x512 1008 -> 953 us, d_inner 256 / N 8
+    //  at 256x256 649 -> 630, d_inner 128 / N 8 at 256x256 355 -> 358; d_inner 256 / N 16 at 128x128 245 -> 267: the split costs
+    //  VALU and registers in the phase that holds the widest state -- fused for N <= 8 only)
+    const bool dt_ok = dtype == FD_BF16 || (dtype == FD_F32 && (dtype_opts & FD_OPT_F32_SPLIT) && N <= 8);
+    return dt_ok && D % 64 == 0 && D <= 256 && (R + 2 * N) % 4 == 0;
 }
 
 // 1 if the engine should call fd_selective_scan_xproj for this block (x_proj inside the chunked scan's first phase),
@@ -1011,7 +1081,7 @@ extern "C" int fd_selective_scan_fuses_xproj(int dtype, int D, int N, int R) {
 // state takes its x_dbl rows from the workspace.  A function of the shape only.
 extern "C" int fd_selective_scan_plan(int dtype_opts, int D, int N, int R, int H, int W) {
     const bool seq = !(dtype_opts & FD_OPT_LOW_LATENCY) && scan_seq_ok(H, W, D, N, R);
-    return fd_selective_scan_fuses_xproj(dtype_opts & 0xff, D, N, R) && !seq;
+    return fd_selective_scan_fuses_xproj(dtype_opts & (0xff | FD_OPT_F32_SPLIT), D, N, R) && !seq;
 }
 
 extern "C" int fd_selective_scan_xproj(int dtype, const void *xc, const void *x_proj_w, float *xdbl, const float *dtw,

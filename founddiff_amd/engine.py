@@ -48,6 +48,10 @@ class ConvW:
         self.w = wk.to(dev, tdt)
         self.b = bias.detach().float().contiguous().to(dev) if bias is not None else None
         self.w8 = self.ws = self.w_up = self.w_hi = self.w_lo = self.w_up_hi = self.w_up_lo = None
+        if split and kh == 1 and kw == 1 and tdt == torch.float32 and i == 64:
+            # fp32s, the 64-channel Mamba blocks: in_proj / qkv pre-split for the fused LN -> 1x1 -> depthwise kernels (fd_pwdw32.hip)
+            hi = wk.to(torch.bfloat16)
+            self.w_hi, self.w_lo = hi.contiguous().to(dev), (wk - hi.float()).to(torch.bfloat16).contiguous().to(dev)
         if split and kh == 3 and kw == 3 and tdt == torch.float32 and i % 64 == 0:
             # the fp32s engine's 3x3 convolutions on the halo-tiled kernel: w = hi + lo in bf16 (include/founddiff_hip.h: weight_split_hi / _lo)
             hi = wk.to(torch.bfloat16)
@@ -131,7 +135,7 @@ class DAEngine:
         # low_latency: the kernel set for ONE slice at a time (the reference's Trainer.test loop).  The default set is
         # chosen for throughput at a batch that fills the chip; both are functions of the image size only.
         self.low_latency = bool(low_latency)
-        self.scan_dt = self.dt | (L.FD_OPT_LOW_LATENCY if low_latency else 0)
+        self.scan_dt = self.dt | (L.FD_OPT_LOW_LATENCY if low_latency else 0) | (L.FD_OPT_F32_SPLIT if mode == "fp32s" else 0)
         # z gate of SS2D recomputed inside out_proj instead of written by in_proj and read back (mamba_block); 0 = round-3 dataflow
         # (development: 64 = only in the 64-channel blocks)
         self.z_recompute = int(os.environ.get("FOUNDDIFF_Z_RECOMPUTE", "1"))
@@ -407,7 +411,7 @@ class DAEngine:
         # (the one-slice kernel set asks for one workgroup per (tile, parity class) -- `upsample` = 2: a low-resolution tile grid
         #  alone is 64..256 workgroups for a lone 512x512 slice, 150.8 against 146.3 ms per 50-step slice with the 9-tap form,
         #  profiles/r05/latency_b1_sweep.txt; any split gives the same bits)
-        if weight is None and cw is not None and getattr(cw, "w_hi", None) is not None:
+        if weight is None and cw is not None and getattr(cw, "w_hi", None) is not None and KH == 3:
             p.weight_split_hi, p.weight_split_lo = cw.w_hi.data_ptr(), cw.w_lo.data_ptr()
         if upsample and weight is None and cw is not None and getattr(cw, "w_up_hi", None) is not None:
             p.weight_up2x_split_hi, p.weight_up2x_split_lo = cw.w_up_hi.data_ptr(), cw.w_up_lo.data_ptr()
@@ -513,10 +517,17 @@ class DAEngine:
                     zre=dict(w=C.c_void_p(m["in_proj"].w.data_ptr() + D * Cc * m["in_proj"].w.element_size()),
                              gamma=m["n1w"], beta=m["n1b"], shift=mp(0), scale=mp(1), ld=ml, eps=1e-5))
         xonly = dict(Cout=D, ldo=2 * D)                  # in_proj restricted to its x half (rows 0 .. D-1), z columns of xz untouched
+        # fp32s engine (fp32 storage, split-bf16 contractions): its own fused LN -> in_proj -> conv2d kernel (fd_pwdw32.hip)
+        f32s = bool(getattr(self, "f32_split", 0))
+        fused32 = f32s and m["in_proj"].w_hi is not None and bool(L.lib().fd_pw_dw3x3_f32_ok(self.dt, Cc, D, H, W))
         zre = (getattr(self, "z_recompute", 0) in (1, Cc) and self.conv(m["out_proj"], y, B, H, W, x1, probe=True, **ep1, **lngz)
-               and (bool(L.lib().fd_pw_dw3x3_ok(getattr(self, 'scan_dt', self.dt), Cc, D, 0, H, W)) if fused else
-                    self.conv(m["in_proj"], x, B, H, W, xz, epi=L.EPI_SILU_SPLIT, split=D, probe=True, **ln1, **xonly)))
-        if fused:
+               and (fused32 or (bool(L.lib().fd_pw_dw3x3_ok(getattr(self, 'scan_dt', self.dt), Cc, D, 0, H, W)) if fused else
+                                self.conv(m["in_proj"], x, B, H, W, xz, epi=L.EPI_SILU_SPLIT, split=D, probe=True, **ln1, **xonly))))
+        fused32 = fused32 and zre            # (the fp32 kernel writes the depthwise half only: z has to be recomputed)
+        if fused32:
+            L.call("fd_pw_dw3x3_f32", _p(x), Cc, 0, Cc, _p(m["n1w"]), _p(m["n1b"]), 1e-5, mp(0), mp(1), ml, _p(m["in_proj"].w_hi), _p(m["in_proj"].w_lo), D,
+                   _p(m["dw_w"]), _p(m["dw_b"]), 1, _p(xc), D, 0, B, H, W, s)
+        elif fused:
             # LN+modulate -> in_proj -> conv2d+SiLU (x half) / SiLU (z half) in one pass: the x half of
             # in_proj's output never exists in HBM (xz[..., :D] stays unwritten, z lands in xz[..., D:])
             L.call("fd_pw_dw3x3", self.dt, _p(x), Cc, 0, Cc, _p(m["n1w"]), _p(m["n1b"]), 1e-5, mp(0), mp(1), ml,
@@ -533,7 +544,7 @@ class DAEngine:
             L.call("fd_ln_modulate", self.dt, _p(x), _p(m["n1w"]), _p(m["n1b"]), 1e-5, mp(0), mp(1), ml, _p(xm),
                    B, hw, Cc, s)
             self.conv(m["in_proj"], xm, B, H, W, xz, epi=L.EPI_SILU_SPLIT, split=D)
-        if not fused:
+        if not fused and not fused32:
             L.call("fd_dwconv3x3", self.dt, _p(xz), 2 * D, 0, _p(m["dw_w"]), _p(m["dw_b"]), 1, _p(xc), D, 0,
                    B, H, W, D, s)
         self._pr(tag + ".xc", xc)
@@ -571,6 +582,23 @@ class DAEngine:
         self._pr(tag + ".x1", x1)
         # --- channel attention branch
         ln2 = dict(prologue=L.PRO_LN_MOD, ln_eps=1e-6, ln_shift=mp(3), ln_scale=mp(4), ln_ld=ml)
+        if (f32s and m["qkv"].w_hi is not None and L.lib().fd_pw_dw3x3_gram_f32_ok(self.dt, Cc, H, W)
+                and L.lib().fd_pw_dw3x3_proj_f32_ok(self.dt, Cc, H, W)):
+            # fp32s: q, k -> depthwise -> Gram + norms in one pass over x1, then v -> depthwise -> Weff -> gated residual in
+            # another: q, k, v and the attention output never reach HBM (fd_pwdw32.hip)
+            nblk = L.lib().fd_pw_dw3x3_gram_f32_nblk(H, W)
+            part = self._b("gram", (B, m["heads"], nblk, 1024 + 64), torch.float32)
+            L.call("fd_pw_dw3x3_gram_f32", _p(x1), Cc, 0, Cc, None, None, 1e-6, mp(3), mp(4), ml, _p(m["qkv"].w_hi), _p(m["qkv"].w_lo), _p(m["qdw_w"]),
+                   3 * Cc, _p(part), B, H, W, s)
+            weff = self._b("weff", (B, Cc, Cc))
+            L.call("fd_chan_attn_weff", self.dt, _p(part), nblk, _p(m["temp"]), _p(m["wproj"]), _p(weff), B, Cc, s)
+            self._pr(tag + ".weff", weff)
+            x2 = self._b(tag + ".x2", (B, H, W, Cc))
+            wvh, wvl = (C.c_void_p(t.data_ptr() + 2 * Cc * Cc * t.element_size()) for t in (m["qkv"].w_hi, m["qkv"].w_lo))
+            L.call("fd_pw_dw3x3_proj_f32", _p(x1), Cc, 0, Cc, None, None, 1e-6, mp(3), mp(4), ml, wvh, wvl, _p(m["qdw_w_v"]), Cc,
+                   _p(weff), mp(5), ml, _p(x2), Cc, 0, B, H, W, s)
+            self._pr(tag, x2)
+            return x2
         if L.lib().fd_pw_dw3x3_gram_ok(self.dt, Cc, H, W):
             # qkv -> qkv_dwconv -> L2 norms + q k^T in one pass: q and k never reach HBM, only v and one Gram
             # partial per workgroup do (fd_pwdw.hip: pwdw_gram_kernel)

@@ -259,6 +259,31 @@ int fd_pw_dw3x3_proj(int dtype, const void *x, int ld_x, int off_x, int Cin, con
                      int ln_ld, const void *w_pw, const uint32_t *w_dw, const void *w2, const float *gate,
                      int gate_ld, void *out, int ld_o, int off_o, int B, int H, int W, void *stream);
 
+/* ---- the three fused kernels above on FP32 STORAGE with split-bf16 contractions (round 6, fd_pwdw32.hip): the 64-channel
+ * Mamba blocks of the `fp32s` engine (fp32 activations, every dense product as three bf16 MFMAs on hi / lo operand halves,
+ * fp32 LayerNorm / depthwise / accumulation; the exact-f32 MFMA for the Gram).  Weights come as the checkpoint's fp32 values:
+ *   w_pw_hi / w_pw_lo  bf16 [rows][64]: the checkpoint's fp32 1x1 weights split by the caller, hi = bf16(w), lo = bf16(w - hi);
+ *   w_dw fp32 [9][ld_wdw] tap-major, column = w_pw row; b_dw fp32 [rows] or NULL
+ * Same reference lines as the bf16 forms: src/emamba2.py:716-722 (in_proj x half + conv2d + SiLU; Cdw rows, z is recomputed by
+ * fd_conv2d's FD_PRO_LN_GATE_ZRE), src/DADiff.py:266-276 (q, k rows 0..127 of qkv.weight -> qkv_dwconv -> per-head Gram and L2
+ * norms; partial [B][2][nblk][1024 + 64] in fd_chan_attn_gram's layout, nblk = fd_pw_dw3x3_gram_f32_nblk(H, W)),
+ * src/DADiff.py:266-285, 483-488 (v rows -> qkv_dwconv -> w2[b] = fd_chan_attn_weff's fp32 output -> x + gate . ()).
+ * Cin = 64, H % 8 == 0, W % 16 == 0 (W % 8 for the Gram / project_out forms), >= 16384 px per image.               */
+int fd_pw_dw3x3_f32_ok(int dtype, int Cin, int Cdw, int H, int W);
+int fd_pw_dw3x3_f32(const void *x, int ld_x, int off_x, int Cin, const float *ln_gamma, const float *ln_beta, float ln_eps,
+                    const float *ln_shift, const float *ln_scale, int ln_ld, const void *w_pw_hi, const void *w_pw_lo, int Cdw,
+                    const float *w_dw, const float *b_dw, int dw_silu, void *out_dw, int ld_dw, int off_dw, int B, int H, int W, void *stream);
+int fd_pw_dw3x3_gram_f32_ok(int dtype, int Cin, int H, int W);
+int fd_pw_dw3x3_gram_f32_nblk(int H, int W);
+int fd_pw_dw3x3_gram_f32(const void *x, int ld_x, int off_x, int Cin, const float *ln_gamma, const float *ln_beta, float ln_eps,
+                         const float *ln_shift, const float *ln_scale, int ln_ld, const void *w_pw_hi, const void *w_pw_lo,
+                         const float *w_dw, int ld_wdw, float *partial, int B, int H, int W, void *stream);
+int fd_pw_dw3x3_proj_f32_ok(int dtype, int Cin, int H, int W);
+int fd_pw_dw3x3_proj_f32(const void *x, int ld_x, int off_x, int Cin, const float *ln_gamma, const float *ln_beta, float ln_eps,
+                         const float *ln_shift, const float *ln_scale, int ln_ld, const void *w_pw_hi, const void *w_pw_lo,
+                         const float *w_dw, int ld_wdw, const float *w2, const float *gate, int gate_ld, void *out, int ld_o, int off_o, int B,
+                         int H, int W, void *stream);
+
 /* ---- qkv_dwconv + L2 norms + q k^T for the wider blocks (C >= 128, src/DADiff.py:267-276): the depthwise 3x3 of the q
  * and k channels of a qkv tensor [B,H,W,ld] (q at channel 0, k at channel C) feeding the per-head Gram directly -- q and k
  * after the depthwise conv never reach HBM.  v keeps fd_dwconv3x3.  w_dw [9][3C/2] in fd_pw_dw3x3's fp16 layout;
@@ -287,6 +312,11 @@ int fd_dwconv_gram(int dtype, const void *qkv, int ld, int C, const uint32_t *w_
  * 512x512) but walks its 1024 positions with one wave per channel group: a lone slice takes 2-3x longer in it.  An
  * engine uses ONE of the two for all its calls (DAEngine low_latency), so results stay batch-invariant within it.  */
 #define FD_OPT_LOW_LATENCY 0x100
+/* OR-ed into the `dtype` argument of fd_selective_scan_plan / fd_selective_scan_fuses_xproj / fd_selective_scan_xproj with
+ * FD_F32 (round 6): the caller's fp32-storage engine runs its contractions split-bf16 (fd_conv_params.f32_split), so the
+ * x_proj einsum (src/emamba2.py:332) may run inside the scan's first phase as three bf16 MFMAs per product, x_proj_w fp32
+ * [4][R + 2N][d_inner].  Without it an FD_F32 scan takes its x_dbl rows from the workspace (exact parity mode).          */
+#define FD_OPT_F32_SPLIT 0x200
 int64_t fd_scan_ws_floats(int B, int H, int W, int D, int N);
 int fd_selective_scan(int dtype, const void *xc, const float *xdbl, const float *dtw,
                       const float *dtb, const float *A, const float *Ds, void *y, float *ws,

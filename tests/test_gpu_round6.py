@@ -175,3 +175,86 @@ def test_row_gemm_fp32_storage_split_bf16(eng_factory):  # noqa: F811
     torch.cuda.synchronize()
     err = rel_err(out.cpu().reshape(B, hw, 512), ref)
     assert err < TOL, err
+
+
+def _ln_mod(x, mod, C_, g=None, b=None, eps=1e-5, sh=0, sc=1):
+    return F.layer_norm(_d(x), (C_,), None if g is None else _d(g), None if b is None else _d(b), eps) * \
+        (1 + _d(mod)[:, None, None, sc * C_:(sc + 1) * C_]) + _d(mod)[:, None, None, sh * C_:(sh + 1) * C_]
+
+
+@pytest.mark.parametrize("hw", [(128, 128), (136, 144)])
+def test_pw_dw3x3_fp32_storage(hw):
+    """fd_pwdw32.hip: the three fused LN -> 1x1 -> depthwise 3x3 forms of the fp32s engine against fp64 torch on the same
+    fp32 operands (image borders, a non-square image whose tile counts are not powers of two)."""
+    from founddiff_amd import _lib as L
+    lib = L.lib()
+    torch.manual_seed(21)
+    H, W = hw
+    B, Cc, D = 2, 64, 128
+    TOL = 3e-5
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    po = lambda t, off: C.c_void_p(t.data_ptr() + 4 * off)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    x = torch.randn(B, H, W, Cc) * 1.5 + 0.3
+    mod = torch.randn(B, 6 * Cc) * 0.5
+    g, b_ = torch.randn(Cc), torch.randn(Cc)
+    xd, md, gd, bd = x.cuda(), mod.cuda(), g.cuda(), b_.cuda()
+    # (a) DW: in_proj x half -> conv2d + bias + SiLU
+    assert lib.fd_pw_dw3x3_f32_ok(L.FD_F32, Cc, D, H, W)
+    w_in = torch.randn(2 * D, Cc) / 8
+    w_dw, b_dw = torch.randn(D, 3, 3) / 3, torch.randn(D)
+    xn = _ln_mod(x, mod, Cc, g, b_, 1e-5, sh=0, sc=1)
+    t = F.linear(xn, _d(w_in)[:D]).permute(0, 3, 1, 2)
+    ref = F.silu(F.conv2d(t, _d(w_dw)[:, None], _d(b_dw), padding=1, groups=D)).permute(0, 2, 3, 1)
+    wdw9 = w_dw.reshape(D, 9).t().contiguous().cuda()
+    out = torch.zeros(B, H, W, D, device="cuda")
+    b_dw_d = b_dw.cuda()
+    split = lambda w: (w.to(torch.bfloat16).cuda(), (w - w.to(torch.bfloat16).float()).to(torch.bfloat16).cuda())
+    pb = lambda t, off: C.c_void_p(t.data_ptr() + 2 * off)
+    w_in_h, w_in_l = split(w_in)
+    L.call("fd_pw_dw3x3_f32", p(xd), Cc, 0, Cc, p(gd), p(bd), 1e-5, p(md), po(md, Cc), 6 * Cc, p(w_in_h), p(w_in_l), D, p(wdw9), p(b_dw_d), 1,
+           p(out), D, 0, B, H, W, st)
+    torch.cuda.synchronize()
+    err = rel_err(out.cpu(), ref)
+    assert err < TOL, err
+    # (b) GRAM: q, k -> depthwise -> per-head Gram + norms -> Weff, against the unfused fp64 arithmetic
+    assert lib.fd_pw_dw3x3_gram_f32_ok(L.FD_F32, Cc, H, W) and lib.fd_pw_dw3x3_proj_f32_ok(L.FD_F32, Cc, H, W)
+    w_qkv = torch.randn(3 * Cc, Cc) / 8
+    w_qdw = torch.randn(3 * Cc, 3, 3) / 3
+    temp, wproj = torch.rand(2) + 0.5, torch.randn(Cc, Cc) / 8
+    xn2 = _ln_mod(x, mod, Cc, None, None, 1e-6, sh=3, sc=4)
+    qkv = F.conv2d(F.linear(xn2, _d(w_qkv)).permute(0, 3, 1, 2), _d(w_qdw)[:, None], None, padding=1, groups=3 * Cc)
+    q, k, v = qkv.reshape(B, 3, 2, 32, H * W).unbind(1)
+    G = torch.einsum("bhip,bhjp->bhij", q, k)
+    nq, nk = (q * q).sum(-1), (k * k).sum(-1)
+    nblk = lib.fd_pw_dw3x3_gram_f32_nblk(H, W)
+    part = torch.zeros(B, 2, nblk, 1024 + 64, device="cuda")
+    qdw9 = w_qdw.reshape(3 * Cc, 9).t().contiguous().cuda()
+    w_qkv_h, w_qkv_l = split(w_qkv)
+    L.call("fd_pw_dw3x3_gram_f32", p(xd), Cc, 0, Cc, None, None, 1e-6, po(md, 3 * Cc), po(md, 4 * Cc), 6 * Cc, p(w_qkv_h), p(w_qkv_l), p(qdw9),
+           3 * Cc, p(part), B, H, W, st)
+    torch.cuda.synchronize()
+    ps = part.cpu().double().sum(2)
+    assert rel_err(ps[..., :1024].reshape(B, 2, 32, 32), G) < TOL
+    assert rel_err(ps[..., 1024:1056], nq) < TOL and rel_err(ps[..., 1056:], nk) < TOL
+    # (c) PROJ: v -> depthwise -> Weff[b] -> x + gate . ()
+    attn = torch.softmax(G / (nq.sqrt().clamp(min=1e-12)[..., :, None] * nk.sqrt().clamp(min=1e-12)[..., None, :]) * _d(temp)[None, :, None, None], -1)
+    ao = torch.einsum("bhij,bhjp->bhip", attn, v).reshape(B, Cc, H * W)
+    ref2 = _d(x) + _d(mod)[:, None, None, 5 * Cc:] * torch.einsum("oc,bcp->bpo", _d(wproj), ao).reshape(B, H, W, Cc)
+    weff = torch.empty(B, Cc, Cc, device="cuda")
+    tempd, wpd = temp.cuda(), wproj.cuda()
+    L.call("fd_chan_attn_weff", L.FD_F32, p(part), nblk, p(tempd), p(wpd), p(weff), B, Cc, st)
+    qdw9v = qdw9[:, 2 * Cc:].contiguous()
+    out2 = torch.zeros(B, H, W, Cc, device="cuda")
+    L.call("fd_pw_dw3x3_proj_f32", p(xd), Cc, 0, Cc, None, None, 1e-6, po(md, 3 * Cc), po(md, 4 * Cc), 6 * Cc, pb(w_qkv_h, 2 * Cc * Cc),
+           pb(w_qkv_l, 2 * Cc * Cc), p(qdw9v), Cc, p(weff), po(md, 5 * Cc), 6 * Cc, p(out2), Cc, 0, B, H, W, st)
+    torch.cuda.synchronize()
+    err = rel_err(out2.cpu(), ref2)
+    assert err < TOL, err
+    # bitwise repeatable (fixed-order partial sums, no atomics)
+    part2 = torch.zeros_like(part)
+    L.call("fd_pw_dw3x3_gram_f32", p(xd), Cc, 0, Cc, None, None, 1e-6, po(md, 3 * Cc), po(md, 4 * Cc), 6 * Cc, p(w_qkv_h), p(w_qkv_l), p(qdw9),
+           3 * Cc, p(part2), B, H, W, st)
+    torch.cuda.synchronize()
+    # (fd_chan_attn_weff reduced `part` in place into slot 0: compare the untouched slots)
+    assert torch.equal(part2[:, :, 1:], part[:, :, 1:])
