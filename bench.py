@@ -280,13 +280,20 @@ def roofline_leg(dif, x, noise, t_measured_ms=None, clock_replay=True):
         scan_entries.append(ent)
     # (~1.5 s of halo-conv launches next to a rocm-smi call; skipped under rocprofv3, whose --stats would count them)
     box = clocks_under_load(lib, halo) if clock_replay else None
-    cands.sort(key=lambda c: -c["kernel_ms_per_forward"])
-    res = cands[0]
-    res["box_under_halo_replay"] = box
-    # the scan groups ride in `others` (largest first): the headline `roofline` stays a single SYMBOL with a plain HBM / MFMA
-    # bound; a scan "group" at level 0 is three launches of two symbols
+    # the headline `roofline` = the entry with the largest time per forward over symbol GROUPS (round 6): a scan group (two
+    # chunked phases + the carry kernel, or the single-pass kernel) competes with the convolution / fused-kernel symbols, so the
+    # scan is the headline while it is the largest consumer.  Its `frac` is taken against the tighter of its two bounds (`bound`
+    # names it; `frac_hbm` / `frac_transcendental` carry both).
     scan_entries.sort(key=lambda c: -c["kernel_ms_per_forward"])
-    res.update({"all_kernels_ms_per_forward": round(all_ms, 3), "batch": B, "others": scan_entries + cands[1:],
+    allc = sorted(cands + scan_entries, key=lambda c: -c["kernel_ms_per_forward"])
+    res = dict(allc[0])
+    res["box_under_halo_replay"] = box
+    short = {"level 0": "scan_level0", "levels 1-2": "scan_levels12", "single pass": "scan_seq"}
+    for c in scan_entries:          # ... and every scan group at the top level of `roofline`, next to `forward`
+        for pat, key in short.items():
+            if pat in c["kernel"]:
+                res[key] = c
+    res.update({"all_kernels_ms_per_forward": round(all_ms, 3), "batch": B, "others": allc[1:],
                 "scan_family_ms_per_forward": round(sum(c["kernel_ms_per_forward"] for c in scan_entries), 3),
                 "forward": forward_bounds(eng, x.shape[2], x.shape[3], traffic, t_measured_ms if t_measured_ms else all_ms / B),
                 "note": "every kernel replayed ALONE on the launch stream at the sub-batch the timed region launches (8): the "
@@ -605,6 +612,27 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert vol.shape[0] == world * B and torch.isfinite(vol).all()
+    # SURVEY section 8(d) defines the metric from the H2D copy of the LDCT batch on: the same K steps once more with the batch
+    # copied from PINNED host memory inside the timed region (1 MiB per slice).  Reported beside `value`, which keeps the
+    # bench contract's definition (inputs resident in HBM when the timed region starts).
+    h2d = None
+    if world == 1 and a.sampler == "ddim":
+        x_host = x.cpu().pin_memory()
+        x_dev = torch.empty_like(x)
+
+        def step_h2d():
+            x_dev.copy_(x_host, non_blocking=True)
+            return dif.sample([x_dev], batch_size=B, noise=noise, slice_seeds=seeds)[-1]
+        step_h2d()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            vol2 = step_h2d()
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t1
+        h2d = {"value": round(B * a.steps / dt2, 4), "unit": "slices/s", "ms_per_step": round(dt2 / a.steps * 1e3, 2),
+               "h2d_bytes_per_step": int(x_host.numel() * x_host.element_size()), "host_memory": "pinned",
+               "same_output_as_resident_run": bool(torch.equal(vol2, vol))}
 
     if rank == 0:
         slices = world * B * a.steps
@@ -626,6 +654,9 @@ def main():
                        "collective; 1 all-gather of the output volume"},
             "ms_per_unet_forward_per_slice": round(dt / a.steps / a.ddim_steps / B * 1e3, 3),
             "alg_tflops_sustained": round(ALG_GFLOP_PER_FORWARD * a.ddim_steps * slices / dt / 1e3, 1),
+            "inputs": "resident in HBM when the timed region starts (bench contract); `h2d_inclusive` repeats the region with the "
+                      "pinned-host -> device copy of the LDCT batch inside it (SURVEY section 8d)",
+            "h2d_inclusive": h2d,
             "box_during_untimed_replay": smi.summary() if smi else None,
             "box_sampler_active_in_timed_region": False,
         }

@@ -104,6 +104,7 @@ SIGNATURES = {
     "fd_pack_planes": (i32, [i32, vp, vp, vp, i32, i64, i32, vp]),
     "fd_init_conv7_ok": (i32, [i32, i32, i32, i32]),
     "fd_init_conv7": (i32, [i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "fd_init_conv7_f32s": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "fd_pack_planes3": (i32, [i32, vp, vp, vp, vp, i32, i64, i32, vp]),
     "fd_cast": (i32, [i32, vp, i32, vp, i64, vp]),
     "fd_final_conv1": (i32, [i32, vp, vp, vp, vp, i64, i32, vp]),

@@ -108,7 +108,104 @@ __global__ __launch_bounds__(256, 2) void initconv7_kernel(const float *__restri
     }
 }
 
+// The same layer for the fp32s engine (fp32 storage, split-bf16 contractions), two input planes: the LDS image is the one
+// above -- slots (x0_hi, x1_hi, x0_lo, x1_lo) -- and the weights come as TWO packed sets: `wk` = bf16(w) in all four slots
+// (w_hi . x_hi + w_hi . x_lo) and `wl` = bf16(w - bf16(w)) in slots 0, 1, zero in 2, 3 (w_lo . x_hi): the three terms of
+// every other fp32s product, two MFMAs per filter row.  Output channels in groups of 32 with that group's 28 fragments in
+// registers; fp32 stores.  The generic split implicit GEMM took 610-670 us per batch-8 launch at 512 x 512 for this layer
+// (K = 49 taps x 8 zero-padded channels, an NHWC copy of the planes in front of it).
+template <int NG>
+__global__ __launch_bounds__(256, 2) void initconv7_f32s_kernel(const float *__restrict__ p0, const float *__restrict__ p1,
+                                                               const bf16 *__restrict__ wk, const bf16 *__restrict__ wl,
+                                                               const float *__restrict__ bias, float *__restrict__ out,
+                                                               int H, int W) {
+    __shared__ __attribute__((aligned(16))) uint2 sx[IHY * IHX];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int tiles_x = W / IT;
+    const int ty0 = (blockIdx.x / tiles_x) * IT, tx0 = (blockIdx.x % tiles_x) * IT;
+    const int64_t img = blockIdx.y, plane = (int64_t)H * W;
+    const int rperm = 8 * (fr >> 2) + (fr & 3);
+    for (int i = tid; i < IHY * IHX; i += 256) {
+        const int hy = i / IHX, hx = i - hy * IHX;
+        const int y = ty0 + hy - 3, x = tx0 + hx - 3;
+        float v0 = 0.f, v1 = 0.f;
+        if (y >= 0 && y < H && x >= 0 && x < W) {
+            const int64_t o = img * plane + (int64_t)y * W + x;
+            v0 = p0[o];
+            v1 = p1[o];
+        }
+        const bf16 b0 = (bf16)v0, b1 = (bf16)v1;
+        const bf16 l0 = (bf16)(v0 - (float)b0), l1 = (bf16)(v1 - (float)b1);
+        uint2 wv;
+        wv.x = (uint32_t)__builtin_bit_cast(uint16_t, b0) | ((uint32_t)__builtin_bit_cast(uint16_t, b1) << 16);
+        wv.y = (uint32_t)__builtin_bit_cast(uint16_t, l0) | ((uint32_t)__builtin_bit_cast(uint16_t, l1) << 16);
+        sx[i] = wv;
+    }
+    __syncthreads();
+    constexpr int CO = 32 * NG;
+#pragma unroll 1
+    for (int g = 0; g < NG; ++g) {
+        bf16x8 wa[7], wb[7], la[7], lb[7];
+#pragma unroll
+        for (int kh = 0; kh < 7; ++kh) {
+            const int64_t oa = (int64_t)(32 * g + rperm) * 224 + kh * 32 + fg * 8, ob = oa + 4 * 224;
+            wa[kh] = *(const bf16x8 *)(wk + oa);
+            wb[kh] = *(const bf16x8 *)(wk + ob);
+            la[kh] = *(const bf16x8 *)(wl + oa);
+            lb[kh] = *(const bf16x8 *)(wl + ob);
+        }
+        float bs[8];
+        if (bias) load8(bias + 32 * g + 8 * fg, bs);
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bs[e] = 0.f;
+        }
+#pragma unroll 1
+        for (int i = 0; i < 4; ++i) {
+            const int ty = 4 * wave + i;
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kh = 0; kh < 7; ++kh) {
+                const uint2 *src = sx + (ty + kh) * IHX + fr + 2 * fg;
+                const uint2 q0 = src[0], q1 = src[1];
+                const u32x4 xv = {q0.x, q0.y, q1.x, q1.y};
+                const bf16x8 xb = __builtin_bit_cast(bf16x8, xv);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(la[kh], xb, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lb[kh], xb, a1, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[kh], xb, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[kh], xb, a1, 0, 0, 0);
+            }
+            const int y = ty0 + ty, x = tx0 + fr;
+            float *op = out + ((img * H + y) * W + x) * CO + 32 * g + 8 * fg;
+            float val[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { val[e] = a0[e] + bs[e]; val[4 + e] = a1[e] + bs[4 + e]; }
+            store8(op, val);
+        }
+    }
+}
+
 }  // namespace
+
+// fp32s form (fp32 storage, split-bf16 contraction), two input planes: w_hi_packed / w_lo_packed are fd_init_conv7's packing of
+// bf16(w) (all four channel slots: the planes and their rounding residuals) and of bf16(w - bf16(w)) (slots 0, 1 only).
+extern "C" int fd_init_conv7_f32s(const float *p0, const float *p1, const void *w_hi_packed, const void *w_lo_packed,
+                                  const float *bias, void *out, int B, int H, int W, int Cout, void *stream) {
+    FD_REQUIRE((Cout == 32 || Cout == 64) && H % IT == 0 && W % IT == 0, "fd_init_conv7_f32s: needs Cout in {32, 64}, H, W multiples "
+               "of 16 (Cout=%d H=%d W=%d)", Cout, H, W);
+    FD_REQUIRE(p0 && p1 && w_hi_packed && w_lo_packed && out, "fd_init_conv7_f32s: null pointer");
+    FD_REQUIRE((((uintptr_t)bias | (uintptr_t)out | (uintptr_t)w_hi_packed | (uintptr_t)w_lo_packed) & 15) == 0, "fd_init_conv7_f32s: 16-byte alignment");
+    dim3 grid((H / IT) * (W / IT), B), block(256);
+    if (Cout == 64)
+        hipLaunchKernelGGL(initconv7_f32s_kernel<2>, grid, block, 0, (hipStream_t)stream, p0, p1, (const bf16 *)w_hi_packed,
+                           (const bf16 *)w_lo_packed, bias, (float *)out, H, W);
+    else
+        hipLaunchKernelGGL(initconv7_f32s_kernel<1>, grid, block, 0, (hipStream_t)stream, p0, p1, (const bf16 *)w_hi_packed,
+                           (const bf16 *)w_lo_packed, bias, (float *)out, H, W);
+    FD_LAUNCH_OK("fd_init_conv7_f32s");
+    return FD_OK;
+}
 
 extern "C" int fd_init_conv7_ok(int dtype, int Cout, int H, int W) {
     return dtype == FD_BF16 && (Cout == 32 || Cout == 64) && H % IT == 0 && W % IT == 0;

@@ -170,6 +170,17 @@ class DAEngine:
         """init_conv weight (Cout, C<=3, 7, 7) -> bf16 [Cout][7 kh][8 kw][4 c] (include/founddiff_hip.h:
         fd_init_conv7): one filter row = one K32 MFMA step."""
         co, c = w.shape[0], w.shape[1]
+        if getattr(self, "f32_split", 0) and c == 2 and tuple(w.shape[2:]) == (7, 7):
+            # fp32s engine (fd_init_conv7_f32s): bf16(w) in all four slots (planes + their rounding residuals) and the
+            # weights' own residual bf16(w - bf16(w)) in slots 0, 1 -- the three terms of a split-bf16 product
+            wf = w.detach().float().permute(0, 2, 3, 1)
+            hi = wf.to(torch.bfloat16)
+            ph, pl = torch.zeros(co, 7, 8, 4), torch.zeros(co, 7, 8, 4)
+            ph[:, :, :7, 0:2] = hi.float()
+            ph[:, :, :7, 2:4] = hi.float()
+            pl[:, :, :7, 0:2] = wf - hi.float()
+            return (ph.reshape(co, 224).contiguous().to(self.dev, torch.bfloat16),
+                    pl.reshape(co, 224).contiguous().to(self.dev, torch.bfloat16))
         if self.tdt != torch.bfloat16 or c > 3 or tuple(w.shape[2:]) != (7, 7):
             return None
         p = torch.zeros(co, 7, 8, 4, dtype=torch.float32)
@@ -890,7 +901,10 @@ class DAEngine:
         B, _, H, W = x_t.shape
         s = self.stream
         r = self._b("r", (B, H, W, self.dim))
-        if self.init_w7 is not None and L.lib().fd_init_conv7_ok(self.dt, self.dim, H, W):
+        if isinstance(self.init_w7, tuple) and x_cond2 is None and self.dim in (32, 64) and H % 16 == 0 and W % 16 == 0:
+            L.call("fd_init_conv7_f32s", _p(x_t), _p(x_in), _p(self.init_w7[0]), _p(self.init_w7[1]), _p(self.init_conv.b), _p(r),
+                   B, H, W, self.dim, s)
+        elif self.init_w7 is not None and not isinstance(self.init_w7, tuple) and L.lib().fd_init_conv7_ok(self.dt, self.dim, H, W):
             L.call("fd_init_conv7", self.dt, _p(x_t), _p(x_in), _p(x_cond2), _p(self.init_w7), _p(self.init_conv.b),
                    _p(r), B, H, W, self.dim, s)
         else:

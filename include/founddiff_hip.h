@@ -392,6 +392,11 @@ int fd_pack_planes(int dtype, const float *p0, const float *p1, void *out, int B
 int fd_init_conv7_ok(int dtype, int Cout, int H, int W);
 int fd_init_conv7(int dtype, const float *p0, const float *p1, const float *p2, const void *w_packed,
                   const float *bias, void *out, int B, int H, int W, int Cout, void *stream);
+/* The same layer on fp32 storage with the split-bf16 contraction of the `fp32s` engine (round 6), two input planes, fp32 out:
+ * w_hi_packed = fd_init_conv7's packing of bf16(w) (all four channel slots: planes and their bf16 rounding residuals),
+ * w_lo_packed = the same packing of bf16(w - bf16(w)) with slots 2, 3 zero: w_hi.x_hi + w_hi.x_lo + w_lo.x_hi.         */
+int fd_init_conv7_f32s(const float *p0, const float *p1, const void *w_hi_packed, const void *w_lo_packed, const float *bias,
+                       void *out, int B, int H, int W, int Cout, void *stream);
 /* same with a third plane: torch.cat((x, x_input, x_input_condition), 1)  src/DADiff.py:1157-1158
  * (p1, p2 may be NULL)                                                                        */
 int fd_pack_planes3(int dtype, const float *p0, const float *p1, const float *p2, void *out, int B,

@@ -10,7 +10,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import rel_err
+from conftest import gate2x, rel_err
 
 pytestmark = pytest.mark.gpu
 TINY_CLIP = dict(layers=(2, 1, 1, 1), width=16, embed_dim=1024)
@@ -62,7 +62,7 @@ def test_resnet_block(golden, mode, tol, name):
     else:
         out = e.res_block(r, xd, Cin, None, 0, B, H, W, "t")
     torch.cuda.synchronize()
-    assert rel_err(nchw(out), g[name + ".out"]) < tol
+    gate2x(f"resnet_block[{name}-{mode}]", rel_err(nchw(out), g[name + ".out"]), tol)
 
 
 @pytest.mark.parametrize("mode,tol", [("fp32", 1e-4), ("bf16", 3e-2)])
@@ -73,7 +73,7 @@ def test_mamba_block(golden, mode, tol, tag):
     from founddiff_amd import _lib as L
     from founddiff_amd.engine import _Sub
     g = golden("modules_odd" if tag.startswith("odd:") else "modules")
-    tag = tag.split(":")[-1]
+    tag0, tag = tag, tag.split(":")[-1]
     p = f"mamba_{tag}."
     e = bare_engine(mode)
     m = e._pack_mamba(_Sub(g.weights(p), p))
@@ -87,7 +87,7 @@ def test_mamba_block(golden, mode, tol, tag):
     e.linear(c.reshape(B, 256).cuda(), m.pop("local_w").cuda(), None, e.local_all, L.ACT_SILU)
     out = e.mamba_block(m, nhwc(x, e.tdt), B, H, W, "t")
     torch.cuda.synchronize()
-    assert rel_err(nchw(out), g[p + "out"]) < tol
+    gate2x(f"mamba_block[{tag0}-{mode}]", rel_err(nchw(out), g[p + "out"]), tol)
 
 
 @pytest.mark.parametrize("C_,H,W", [(64, 128, 256), (128, 32, 32)])

@@ -8,7 +8,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import rel_err
+from conftest import gate2x, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -373,7 +373,7 @@ def test_selective_scan(eng_factory, mode, tol, cfg):
     L.call("fd_selective_scan", e.dt, xcd.data_ptr(), t[0].data_ptr(), t[1].data_ptr(),
            t[2].data_ptr(), t[3].data_ptr(), t[4].data_ptr(), y.data_ptr(), ws.data_ptr(), B, H, W, D, N, R, e.stream)
     torch.cuda.synchronize()
-    assert rel_err(nchw(y), ref) < (1e-4 if mode == "fp32" else 1e-2)
+    gate2x(f"selective_scan[{'-'.join(map(str, cfg))}-{mode}]", rel_err(nchw(y), ref), 1e-4 if mode == "fp32" else 1e-2)
 
 
 def _scan_inputs(b, KD, K, N, L, seed):
