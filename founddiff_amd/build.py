@@ -11,7 +11,16 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libfounddiff_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function",
+# No packed-fp32 VALU instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) anywhere in the library (round 6).  With them the
+# library was NOT run-to-run repeatable once two kernels of different kinds shared the chip -- the default two-stream sample():
+# the element in the EVEN register of a packed result came out wrong in lanes 48..63 of a wave, sporadically (a level-0 scan
+# output in ~1 of 10 concurrent forwards; up to 0.14 on a [0, 1] image over a 50-step loop; one stream: always bit-stable).  Found
+# with tools/probes/determinism_matrix.py + race_hunt.py, isolated by this flag: every configuration repeatable with it, none
+# without (profiles/r06/packed_fp32_nondeterminism.md).  Cost: 14.20 -> 14.07 slices/s alternated.  The f32x2 vector types in the
+# sources stay; the compiler splits them into scalar instructions.  (-fno-slp-vectorize, round 2, was the first sighting of the
+# same thing: SLP-packed v_pk_add_f32 feeding ds_bpermute gave run-to-run differences.)
+NO_PACKED_F32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function", *NO_PACKED_F32,
          "-Rpass-analysis=kernel-resource-usage",       # -> lib/obj/<file>.resources.txt (resources() below)
          "-I" + os.path.join(HERE, "..", "include")]
 

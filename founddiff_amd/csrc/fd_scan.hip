@@ -659,14 +659,12 @@ __global__ __launch_bounds__(64 * SEG) void scan_carry_kernel(float *__restrict_
 // flight during the current block's steps); each lane reads its own slices of a row: 4 distinct addresses per
 // ds_read.  Which path runs is a function of (H, W, N, R) only -- never of the batch -- so a slice's result does not
 // depend on what else is in the batch (scan_seq_ok).
+// (Round 6, measured and not kept: 8 lanes per channel at N = 32 -- half the states per lane, twice the waves, each lane of the octet
+// computing the dt of one of 8 steps, the cross-quad broadcast through the half-row mirror DPP.  VERDICT r5 expected the one-wave-
+// per-SIMD d_inner 512 launch (VALU 46 % busy) to gain; batch-8 launches, alternated in one call: d_inner 512 201 -> 204-207 us,
+// d_inner 1024 289 -> 376-380 us.  The per-step work that does NOT shrink with the state slice -- u conversion, the y all-reduce
+// (3 instead of 2 DPP adds), broadcast moves, the store, row reads -- is paid by twice as many lanes: issue-bound, not latency-bound.)
 constexpr int SEQ_LPC = 4, SEQ_SP = 32, SEQ_MAXL = 1024;
-
-// lane J of every quad -> all lanes of the quads selected by BANK (the quads of a 16-lane row); the others keep `old`
-template <int J, int BANK>
-__device__ __forceinline__ int seq_qp(int old, int src) {
-    constexpr int CTRL = J == 0 ? 0x00 : (J == 1 ? 0x55 : (J == 2 ? 0xAA : 0xFF));
-    return __builtin_amdgcn_update_dpp(old, src, CTRL, 0xF, BANK, false);
-}
 
 __device__ __forceinline__ float quad_sum(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // lane ^ 1
@@ -674,18 +672,14 @@ __device__ __forceinline__ float quad_sum(float v) {
     return v;
 }
 
-// LPC = lanes per channel: 4, or (round 6) 8 for N = 32.  With 4 lanes the 64x64 level of a batch of 8 slices is 1024 waves at
-// d_inner 512 -- ONE wave per SIMD, VALU 46 % busy (PMC, round 5): a lone wave cannot cover the latency of its own LDS reads,
-// DPP exchanges and transcendentals -- and 1.7 waves at d_inner 1024.  8 lanes per channel halve a lane's states (N / 8 = 4),
-// double the waves, and each lane of the octet computes the whole dt of ONE of the group's 8 steps.
-template <typename T, int N, int R, bool ODD, int LPC_ = SEQ_LPC>
+template <typename T, int N, int R, bool ODD>
 __global__ __launch_bounds__(256) void scan_seq_kernel(const T *__restrict__ xc, const float *__restrict__ xdbl,
                                                       const float *__restrict__ dtw, const float *__restrict__ dtb,
                                                       const float *__restrict__ A, const float *__restrict__ Ds,
                                                       T *__restrict__ y, const ScanGeom g) {
-    constexpr int LPC = LPC_, NS = N / LPC, SP = SEQ_SP;
+    constexpr int LPC = SEQ_LPC, NS = N / LPC, RS = R / LPC, SP = SEQ_SP;
     constexpr int CD = R + 2 * N, CD4 = CD / 4;
-    static_assert((LPC == 4 || LPC == 8) && NS % 2 == 0 && R % 8 == 0 && CD % 4 == 0 && (R + N) % 4 == 0, "scan_seq_kernel: slice shapes");
+    static_assert(NS % 2 == 0 && RS % 2 == 0 && CD % 4 == 0 && (R + N) % 4 == 0, "scan_seq_kernel: slice shapes");
     constexpr bool LOG2U = sizeof(T) == 2;                           // see scan_chunk_kernel: dt in base-2 units
     constexpr float WS = LOG2U ? 1.4426950408889634f : 1.f;
     constexpr float AS = LOG2U ? 1.f : 1.4426950408889634f;
@@ -695,9 +689,9 @@ __global__ __launch_bounds__(256) void scan_seq_kernel(const T *__restrict__ xc,
     __shared__ __attribute__((aligned(16))) float sx[2][SP * CDS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int sub = lane & (LPC - 1);
+    const int sub = lane & 3;
     const int bk = blockIdx.y, b = bk >> 2, k = bk & 3;
-    const int d = blockIdx.x * (256 / LPC) + wave * (64 / LPC) + lane / LPC;
+    const int d = blockIdx.x * 64 + wave * 16 + (lane >> 2);
     const int kd = k * g.D + d;
     const int odd = k & 1, ph = k & 1, pw = k >> 1;
     const float *xb = xdbl + ((int64_t)k * g.B + b) * g.L * CD;       // [4][B][L][CD], row = h2 * W2 + w2
@@ -845,8 +839,7 @@ __global__ __launch_bounds__(256) void scan_seq_kernel(const T *__restrict__ xc,
             if (n & 1) acc3 = h[n] * q.cr[n] + acc3;
             else acc2 = h[n] * q.cr[n] + acc2;
         }
-        const float part = (acc2.x + acc3.x) + (acc2.y + acc3.y);
-        st_y(soff, (LPC == 8 ? fd_group_sum<8>(part) : quad_sum(part)) + o.du);
+        st_y(soff, quad_sum((acc2.x + acc3.x) + (acc2.y + acc3.y)) + o.du);
     };
 
     constexpr int U = 8;                                 // steps per prefetch group; SP / U groups per staged block
@@ -869,48 +862,21 @@ __global__ __launch_bounds__(256) void scan_seq_kernel(const T *__restrict__ xc,
         else r = __builtin_amdgcn_update_dpp(0, x, 0xFF, 0xF, 0xF, true);
         return __builtin_bit_cast(float, r);
     };
-    // 8 lanes per channel: lane `sub` of the octet holds the dt of step `sub` of the group.  A DPP quad_perm reaches inside a
-    // quad only: the other quad's values come through the half-row mirror (lane j <- lane 7 - j), and the bank mask of the two
-    // moves picks which quad of the octet each writes (banks = quads of a 16-lane row: 0b0101 = the lower, 0b1010 = the upper)
-    auto oct_bcast = [&](float v, float vm, int i) -> float {
-        const int x = __builtin_bit_cast(int, v), xm = __builtin_bit_cast(int, vm);
-        int r = 0;
-        switch (i) {                                     // (i is a constant of the unrolled step loop; the builtin wants literals)
-        case 0: r = seq_qp<0, 0x5>(0, x); r = seq_qp<3, 0xA>(r, xm); break;     // lower quad holds it; upper reads the mirror
-        case 1: r = seq_qp<1, 0x5>(0, x); r = seq_qp<2, 0xA>(r, xm); break;
-        case 2: r = seq_qp<2, 0x5>(0, x); r = seq_qp<1, 0xA>(r, xm); break;
-        case 3: r = seq_qp<3, 0x5>(0, x); r = seq_qp<0, 0xA>(r, xm); break;
-        case 4: r = seq_qp<0, 0xA>(0, x); r = seq_qp<3, 0x5>(r, xm); break;     // upper quad holds it; lower reads the mirror
-        case 5: r = seq_qp<1, 0xA>(0, x); r = seq_qp<2, 0x5>(r, xm); break;
-        case 6: r = seq_qp<2, 0xA>(0, x); r = seq_qp<1, 0x5>(r, xm); break;
-        default: r = seq_qp<3, 0xA>(0, x); r = seq_qp<0, 0x5>(r, xm); break;
-        }
-        return __builtin_bit_cast(float, r);
-    };
     auto run = [&](int gi, const int (&pix)[U], const uint32_t (&u)[U]) {
         const float *rows = &sx[(gi >> 2) & 1][((gi & 3) * U) * CDS];
         RowRegs q[3];
         PreOut o[2];
-        float dtq[U / LPC];                              // dt of step LPC b + sub of block b, in lane `sub`
-        float dtm = 0.f;                                 // LPC == 8: dtq[0] through the half-row mirror
+        float dtq[U / 4];                                // dt of step 4 b + sub of block b, in lane `sub`
         load_row(rows, q[0]);
         load_row(rows + CDS, q[1]);
         dtq[0] = dt_of_row(rows + sub * CDS);
-        if constexpr (LPC == 8)
-            dtm = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, dtq[0]), 0x141, 0xF, 0xF, false));
-        auto dt_at = [&](int s_) -> float {
-            if constexpr (LPC == 8) return oct_bcast(dtq[0], dtm, s_);
-            else return quad_bcast(dtq[s_ / 4], s_ & 3);
-        };
-        pre(q[0], u[0], dt_at(0), o[0]);
+        pre(q[0], u[0], quad_bcast(dtq[0], 0), o[0]);
 #pragma unroll
         for (int s = 0; s < U; ++s) {
             if (s + 2 < U) load_row(rows + (s + 2) * CDS, q[(s + 2) % 3]);
             __builtin_amdgcn_sched_barrier(0);           // the reads stay two steps ahead of their use
-            if constexpr (LPC == 4) {
-                if ((s & 3) == 0 && s + 4 < U) dtq[s / 4 + 1] = dt_of_row(rows + (s + 4 + sub) * CDS);    // next block's dt
-            }
-            if (s + 1 < U) pre(q[(s + 1) % 3], u[s + 1], dt_at(s + 1), o[(s + 1) & 1]);
+            if ((s & 3) == 0 && s + 4 < U) dtq[s / 4 + 1] = dt_of_row(rows + (s + 4 + sub) * CDS);    // next block's dt
+            if (s + 1 < U) pre(q[(s + 1) % 3], u[s + 1], quad_bcast(dtq[(s + 1) / 4], (s + 1) & 3), o[(s + 1) & 1]);
             post(q[s % 3], o[s & 1], pix[s]);
         }
     };
@@ -953,23 +919,10 @@ bool scan_seq_ok(int H, int W, int D, int N, int R) {
     return L <= SEQ_MAXL && N >= 16 && N % (2 * SEQ_LPC) == 0 && R % (2 * SEQ_LPC) == 0 && D % 64 == 0;
 }
 
-static bool scan_seq8_on() {
-    static const bool off = getenv("FD_SCAN_SEQ_LPC4") != nullptr;   // development switch: 4 lanes per channel at N = 32 too
-    return !off;
-}
-
 template <typename T, int N, int R, bool ODD>
 void launch_scan_seq(const T *xc, const float *xdbl, const float *dtw, const float *dtb, const float *A,
                      const float *Ds, T *y, const ScanGeom &g, hipStream_t s) {
     if constexpr (N >= 16 && N % (2 * SEQ_LPC) == 0 && R % (2 * SEQ_LPC) == 0) {
-        // 8 lanes per channel for the widest state (N = 32: the 64x64 level of a 512x512 slice): a function of N only
-        if constexpr (N == 32) {
-            if (g.D % 32 == 0 && scan_seq8_on()) {
-                dim3 grid(g.D / 32, g.B * 4), block(256);
-                hipLaunchKernelGGL((scan_seq_kernel<T, N, R, ODD, 8>), grid, block, 0, s, xc, xdbl, dtw, dtb, A, Ds, y, g);
-                return;
-            }
-        }
         dim3 grid(g.D / 64, g.B * 4), block(256);
         hipLaunchKernelGGL((scan_seq_kernel<T, N, R, ODD>), grid, block, 0, s, xc, xdbl, dtw, dtb, A, Ds, y, g);
     }

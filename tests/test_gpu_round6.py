@@ -375,3 +375,27 @@ def test_init_conv7_fp32_storage_split_bf16(cfg):
     torch.cuda.synchronize()
     err = rel_err(out.cpu(), ref)
     assert err < 2e-5, err
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp32s"])
+def test_two_stream_sample_repeatable_at_bench_size(prec):
+    """sample() at the BENCHMARKED shape -- 512x512, batch 8 as two concurrent sub-batches on two HIP streams -- is bitwise
+    repeatable run to run and equal to the one-stream run.  Until round 6 this was only tested on the tiny model at 64x64
+    (test_concurrent_half_batches_bitwise), where the two streams barely overlap; at 512x512 the library built WITH packed-fp32
+    VALU instructions differed from run to run by up to 0.14 on a [0, 1] image (founddiff_amd/build.py: NO_PACKED_F32)."""
+    import bench
+    from founddiff_amd import synth
+    dev = torch.device("cuda")
+    S = 50 if prec == "bf16" else 20
+    dif, _ = bench.build_model(dev, steps=S, precision=prec)
+    B = 8
+    _, ld = synth.ct_phantom(B, 512, seed=10)
+    x = torch.from_numpy(ld).to(dev)
+    noise = torch.stack([torch.randn(1, 512, 512, generator=torch.Generator().manual_seed(1000 + i)) for i in range(B)]).to(dev)
+    dif.streams = 2
+    outs = [dif.sample([x], batch_size=B, noise=noise)[-1].clone() for _ in range(3)]
+    dif.streams = 1
+    one = dif.sample([x], batch_size=B, noise=noise)[-1].clone()
+    torch.cuda.synchronize()
+    for i, o in enumerate(outs):
+        assert torch.equal(o, one), (prec, i, float((o - one).abs().max()))

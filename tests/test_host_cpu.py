@@ -258,7 +258,7 @@ def test_kernel_scratch_ledger():
     ledger = [          # (file, pattern of the mangled name, bytes of scratch per lane it may use)
         ("fd_conv.hip", r"conv_igemm_kernelI\w+Li256ELi256E", 192),        # the 256 x 256 tile sits at its 256-register cap
         ("fd_conv3x3.hip", r"conv3x3_halo_kernelILi128ELi8ELb0ELb0ELb1E", 32),     # split-bf16 form: fp32 halo registers
-        ("fd_pwdw.hip", r"pwdw_gram_kernel|dwconv_gram_kernel|pwdw_kernelILi64ELb1E", 32),
+        ("fd_pwdw.hip", r"pwdw_gram_kernel|dwconv_gram_kernel|pwdw_kernelILi64ELb1E", 48),    # (round 6: built without packed-fp32 instructions, build.NO_PACKED_F32: 36 bytes in the project_out form)
     ]
     bad = []
     for f, tab in res.items():
