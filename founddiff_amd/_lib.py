@@ -56,6 +56,7 @@ class ConvParams(C.Structure):
 SIGNATURES = {
     "fd_version": (i32, []),
     "fd_last_error": (C.c_char_p, []),
+    "fd_dev_options": (C.c_char_p, []),
     "fd_conv_mtiles": (i32, [i32, i32]),
     "fd_conv2d": (i32, [C.POINTER(ConvParams), vp]),
     "fd_conv_prologue_ok": (i32, [C.POINTER(ConvParams)]),

@@ -20,7 +20,10 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # sources stay; the compiler splits them into scalar instructions.  (-fno-slp-vectorize, round 2, was the first sighting of the
 # same thing: SLP-packed v_pk_add_f32 feeding ds_bpermute gave run-to-run differences.)
 NO_PACKED_F32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function", *NO_PACKED_F32,
+# -DFD_RELEASE: the development switches of csrc/fd_common.h (FD_DEV_SWITCHES) are compiled to their defaults -- the shipped library
+# reads no environment variable.  FOUNDDIFF_DEV_BUILD=1 builds the form that reads them (A/B experiments, tools/probes/).
+RELEASE = [] if os.environ.get("FOUNDDIFF_DEV_BUILD") == "1" else ["-DFD_RELEASE"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function", *NO_PACKED_F32, *RELEASE,
          "-Rpass-analysis=kernel-resource-usage",       # -> lib/obj/<file>.resources.txt (resources() below)
          "-I" + os.path.join(HERE, "..", "include")]
 

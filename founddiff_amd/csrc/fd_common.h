@@ -198,14 +198,59 @@ __device__ __forceinline__ u32x4 fd_ln_mod_chunk(u32x4 raw, const f32x2 (&g)[4],
 #define FD_TIE8(a) FD_TIE4(a), "+v"((a)[4]), "+v"((a)[5]), "+v"((a)[6]), "+v"((a)[7])
 #define FD_MFMA_ASM_DRAIN "s_nop 15\n\ts_nop 15\n\ts_nop 15"
 
-// Development switch FD_PAD_<NAME>=<KiB>: extra dynamic LDS requested per workgroup of kernel family NAME, i.e. a cap on
-// its workgroups per CU -- used to study how kernels of the two concurrent sub-batch streams share a CU
-// (tools/probes/corun.py).  0 (unset) in production.
-static inline size_t fd_occ_pad(const char *name) {
-    char key[64];
-    snprintf(key, sizeof key, "FD_PAD_%s", name);
-    const char *e = getenv(key);
-    return e ? (size_t)atoi(e) * 1024 : 0;
-}
+// ---- Development switches: ONE table, read from the environment ONCE, absent from the release build.
+// Until round 6 the dispatch code held 29 getenv() calls behind function-local statics: the behaviour of a library that
+// include/founddiff_hip.h calls stateless depended on the environment at first use.  Now: X(name, kind, default) below is the
+// whole list (environment variable FD_<name>); fd_dev(FD_DEV_<name>) is the only accessor; under -DFD_RELEASE (what founddiff_amd.build.build() ships) it is a
+// compile-time constant -- the default -- and no environment variable reaches the library.  A development build
+// (FOUNDDIFF_DEV_BUILD=1 python -m founddiff_amd.build) reads the variables once, in fd_dev_options() / the first fd_dev().
+// kind F: flag (set = 1); kind I: integer value.  What each one does is documented where it is used.
+#define FD_DEV_SWITCHES(X)                                                                            \
+    X(CONV_KID, I, -1)          /* fd_conv.hip: force an implicit-GEMM tile for stat-free 1x1 layers */ \
+    X(CONV_BIG_TILE, F, 0)      /* fd_conv.hip: the 128x256 tile below its workgroup-count threshold */ \
+    X(NO_CONV3_SPLIT, F, 0)     /* fd_conv3x3.hip: fp32s 3x3 on the generic split implicit GEMM */     \
+    X(NO_CONV3_UP2X, F, 0)      /* fd_conv3x3.hip: up-sampling 3x3 in its 9-tap form */                \
+    X(CONV3_UP_CPW, I, 0)       /* fd_conv3x3.hip: parity classes per workgroup of the four-2x2 form */ \
+    X(CONV3_TH8, F, 0)          /* fd_conv3x3.hip: 8-row tiles for Cout <= 64 too */                   \
+    X(CONV_TPW, I, 0)           /* fd_conv3x3.hip: tiles per workgroup */                              \
+    X(NO_CONV3_RW, F, 0)        /* fd_conv3x3_rw.hip: off */                                           \
+    X(CONV3_RW_TPW, I, 0)       /* fd_conv3x3_rw.hip: tiles per workgroup */                           \
+    X(NO_DOWNFUSE, F, 0)        /* fd_downfuse.hip: off */                                             \
+    X(DOWN_TPW, I, 0)           /* fd_downfuse.hip: tiles per workgroup */                             \
+    X(ROWS_PER_CU_MAX, I, 0)    /* fd_gemm_rows.hip: persistent workgroups per CU, upper limit */      \
+    X(ROWS_PER_CU, I, 0)        /* fd_gemm_rows.hip: persistent workgroups per CU, cap */              \
+    X(ZRE_NOPF, F, 0)           /* fd_gemm_rows.hip: z-recompute out_proj without the next-tile prefetch */ \
+    X(NO_PWDW128, F, 0)         /* fd_pwdw.hip: the C = 128 fused in_proj kernel off */                \
+    X(PWDW_MINPIX, I, 32768)    /* fd_pwdw.hip: smallest image the fused kernels take */               \
+    X(PWDW_TPW, I, 0)           /* fd_pwdw.hip: tiles per workgroup */                                 \
+    X(NO_PWDW_PROJ, F, 0)       /* fd_pwdw.hip: v-recompute project_out kernel off */                  \
+    X(GRAM_TPW, I, 0)           /* fd_pwdw.hip: tiles per workgroup of the Gram form (changes the partial-sum order) */ \
+    X(NO_GRAM_FUSE, F, 0)       /* fd_pwdw.hip: Gram-fused qkv kernel off */                           \
+    X(NO_DWGRAM, F, 0)          /* fd_pwdw.hip: dwconv_gram_kernel off */                              \
+    X(NO_PWGEMM, F, 0)          /* fd_pwgemm.hip: the generic 256x256 tile instead */                  \
+    X(SCAN_NO_SEQ, F, 0)        /* fd_scan.hip: chunked form for short sequences too */                \
+    X(SCAN_NO_CPL2, F, 0)       /* fd_scan.hip: one channel per lane at level 0 */                     \
+    X(SCAN_CL, I, 0)            /* fd_scan.hip: chunk length */                                        \
+    X(PAD_CONV3, I, 0)          /* extra dynamic LDS (KiB) per workgroup: a cap on workgroups per CU (tools/probes/corun.py) */ \
+    X(PAD_PWDW, I, 0)                                                                              \
+    X(PAD_SCAN, I, 0)
+enum fd_dev_id {
+#define FD_DEV_ENUM(name, kind, dflt) FD_DEV_##name,
+    FD_DEV_SWITCHES(FD_DEV_ENUM)
+#undef FD_DEV_ENUM
+    FD_DEV_COUNT
+};
+#ifdef FD_RELEASE
+static constexpr int fd_dev_defaults[FD_DEV_COUNT] = {
+#define FD_DEV_DFLT(name, kind, dflt) dflt,
+    FD_DEV_SWITCHES(FD_DEV_DFLT)
+#undef FD_DEV_DFLT
+};
+static constexpr int fd_dev(int id) { return fd_dev_defaults[id]; }
+#else
+int fd_dev(int id);            // fd_small.hip: the table, filled from the environment on first use
+#endif
+// extra dynamic LDS per workgroup of a kernel family (FD_PAD_<family>, KiB); 0 in the release build
+static inline size_t fd_occ_pad(int id) { return (size_t)fd_dev(id) * 1024; }
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -659,7 +659,7 @@ extern "C" int fd_conv_kernel_id(const fd_conv_params *pp) {
     if (fd_conv3x3_up2x_split_ok(*pp)) return 16;
     if (fd_conv3x3_split_ok(*pp)) return 15;
     const bool wide = pp->Cout > 64, tall = conv_bm((int64_t)pp->OH * pp->OW) == 128;
-    static const int force = [] { const char *e = getenv("FD_CONV_KID"); return e ? atoi(e) : -1; }();   // development: tile experiments
+    const int force = fd_dev(FD_DEV_CONV_KID);   // development: tile experiments
     if (force >= 0 && force <= 6 && !pp->stats_partial && pp->KH == 1 && pp->Cout >= 256) return force;
     // 8-wave 128x256 tile (id 4) for the dense layers of the 64x64 / 128x128 levels: it halves the operand
     // traffic from beyond L2 (+15..30 % at batch 8) but launches 4x fewer workgroups, so it is chosen only
@@ -678,7 +678,7 @@ extern "C" int fd_conv_kernel_id(const fd_conv_params *pp) {
         return fd_pwgemm_ok(*pp) ? 7 : 5;
     if (!tall && pp->Cout >= 256 && pp->Cout <= 512 && !pp->stats_partial && pp->KH * pp->KW * (pp->c0 + pp->c1) >= 256) {
         const int64_t wgs = (int64_t)pp->B * pp->ndir * cdiv((int64_t)pp->OH * pp->OW, 128) * cdiv(pp->Cout, 256);
-        if (wgs >= 192 || getenv("FD_CONV_BIG_TILE")) return 4;
+        if (wgs >= 192 || fd_dev(FD_DEV_CONV_BIG_TILE)) return 4;
     }
     // very narrow outputs (x_proj: Cout = dt_rank + 2 d_state = 12..40 at the high-resolution levels): a
     // 32-column tile halves the wasted B-side work of the 64-column one and fits more workgroups per CU

@@ -238,6 +238,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
         unsigned char *sH = smem;
         int tl = tid;
         asm volatile("" : "+v"(tl));
+        // the halo registers are written by inline-asm loads the compiler's waitcnt pass does not see; every call of
+        // this function sits behind a counted vmcnt wait (+ barrier) that covers them.  Tying each register to an (empty)
+        // volatile asm HERE makes every consumer below depend on a statement that stays behind those waits -- a register-only
+        // consumer (the hvalid select, the split / fp8 conversions) can no longer be scheduled above them.  What this cannot
+        // forbid is a COPY of such a register before the wait (live-range split, AGPR park): tests/test_host_cpu.py pins
+        // AGPRs = 0 and scratch = 0 for every instantiation that uses the asm loads.
+#pragma unroll
+        for (int i = 0; i < HL; ++i)
+#pragma unroll
+            for (int h = 0; h < HG; ++h) asm volatile("" : "+v"(rh[i][h]));
 #pragma unroll
         for (int i = 0; i < HL; ++i) {
             const int hid = tl + 256 * i, hp = hid >> 3;
@@ -791,7 +801,7 @@ int fd_conv3x3_fp8_ok(const fd_conv_params &p) {
 
 // 1 if `p` (fp32 storage, f32_split, the pre-split bf16 weight matrices set) runs on the split-bf16 form of the halo kernel
 int fd_conv3x3_split_ok(const fd_conv_params &p) {
-    static const bool off = getenv("FD_NO_CONV3_SPLIT") != nullptr;     // development: the generic split implicit GEMM
+    const bool off = fd_dev(FD_DEV_NO_CONV3_SPLIT);     // development: the generic split implicit GEMM
     const int Cin = p.c0 + p.c1;
     if (off || p.dtype != FD_F32 || !p.f32_split || !p.weight_split_hi || !p.weight_split_lo || p.ndir != 1) return 0;
     if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad_h != 1 || p.pad_w != 1) return 0;
@@ -809,7 +819,7 @@ int fd_conv3x3_split_ok(const fd_conv_params &p) {
 // 1 if `p` (fp32 storage, f32_split, an up-sampling 3x3 with its pre-split sub-pixel matrices) runs as four 2x2 convolutions on
 // the source grid in the split-bf16 form: both of the above at once (the fp32s engine's three Upsample convolutions)
 int fd_conv3x3_up2x_split_ok(const fd_conv_params &p) {
-    static const bool off = getenv("FD_NO_CONV3_UP2X") != nullptr || getenv("FD_NO_CONV3_SPLIT") != nullptr;
+    const bool off = (fd_dev(FD_DEV_NO_CONV3_UP2X) | fd_dev(FD_DEV_NO_CONV3_SPLIT)) != 0;
     if (off || !p.weight_up2x_split_hi || !p.weight_up2x_split_lo || !p.upsample || p.stats_partial) return 0;
     if (p.H % 8 || p.W % TW) return 0;
     if ((int64_t)p.Cout * 16 * (p.c0 + p.c1) >= (1ll << 30)) return 0;
@@ -821,7 +831,7 @@ int fd_conv3x3_up2x_split_ok(const fd_conv_params &p) {
 
 // 1 if `p` (an up-sampling 3x3 with its sub-pixel weight matrix, weight_up2x) runs as four 2x2 convolutions on the source grid
 int fd_conv3x3_up2x_ok(const fd_conv_params &p) {
-    static const bool off = getenv("FD_NO_CONV3_UP2X") != nullptr;    // development: the 9-tap form through the up-sampling index map
+    const bool off = fd_dev(FD_DEV_NO_CONV3_UP2X);    // development: the 9-tap form through the up-sampling index map
     return !off && p.weight_up2x && p.upsample && !p.weight_f8 && !p.stats_partial && p.epilogue == FD_EPI_NONE &&
            p.H % 8 == 0 && p.W % TW == 0 && fd_conv3x3_ok(p);
 }
@@ -829,7 +839,7 @@ int fd_conv3x3_up2x_ok(const fd_conv_params &p) {
 int fd_conv3x3_launch(const fd_conv_params &p, hipStream_t s) {
     const bool wide = p.Cout > 64;
     if (fd_conv3x3_up2x_split_ok(p)) {
-        static const int cpw_env = [] { const char *e = getenv("FD_CONV3_UP_CPW"); return e ? atoi(e) : 0; }();
+        const int cpw_env = fd_dev(FD_DEV_CONV3_UP_CPW);
         const int cpw = (cpw_env == 1 || cpw_env == 2 || cpw_env == 4) ? cpw_env : (p.upsample == 2 ? 1 : 4);
         const int tiles_xy = (p.H / 8) * (p.W / TW), gy = cdiv(p.Cout, wide ? 128 : 64);
         dim3 grid(tiles_xy * (4 / cpw), gy, p.B), block(256);
@@ -852,7 +862,7 @@ int fd_conv3x3_launch(const fd_conv_params &p, hipStream_t s) {
         const int tiles_xy = (p.H / th) * (p.W / TW), gy = cdiv(p.Cout, wide ? 128 : 64);
         // classes per workgroup: 4 (the four classes of a tile share its workgroup), or 1 when the caller asks for the
         // class-parallel grid (`upsample` = 2: the one-slice kernel set; any split gives the same bits)
-        static const int cpw_env = [] { const char *e = getenv("FD_CONV3_UP_CPW"); return e ? atoi(e) : 0; }();     // development
+        const int cpw_env = fd_dev(FD_DEV_CONV3_UP_CPW);     // development
         const int cpw = (cpw_env == 1 || cpw_env == 2 || cpw_env == 4) ? cpw_env : (p.upsample == 2 ? 1 : 4);
         dim3 grid(tiles_xy * (4 / cpw), gy, p.B), block(256);
         if (wide) hipLaunchKernelGGL((conv3x3_halo_kernel<128, 8, false, true>), grid, block, 0, s, p, cpw, tiles_xy);
@@ -860,21 +870,21 @@ int fd_conv3x3_launch(const fd_conv_params &p, hipStream_t s) {
         else hipLaunchKernelGGL((conv3x3_halo_kernel<64, 8, false, true>), grid, block, 0, s, p, cpw, tiles_xy);
         return 0;
     }
-    static const bool th8 = getenv("FD_CONV3_TH8") != nullptr;        // development: 8-row tiles for Cout <= 64 too
+    const bool th8 = fd_dev(FD_DEV_CONV3_TH8);        // development: 8-row tiles for Cout <= 64 too
     const int th = (!wide && p.OH % 16 == 0 && !th8) ? 16 : 8;
     const int tiles_xy = (p.OH / th) * (p.OW / TW), gy = cdiv(p.Cout, wide ? 128 : 64);
     // consecutive tiles per workgroup: the next tile's halo is in flight during the current tile's MFMAs (a workgroup
     // per tile has nothing in flight while it computes: the 64 -> 64 convolutions of level 0 ran at 2.1 TB/s of a
     // latency-bound load -> compute -> store sequence).  Chosen from the launch size only: any split gives the same
     // bits (a tile's result does not depend on which workgroup computes it).
-    static const int tpw_env = [] { const char *e = getenv("FD_CONV_TPW"); return e ? atoi(e) : 0; }();
+    const int tpw_env = fd_dev(FD_DEV_CONV_TPW);
     // Round 4: ONE tile per workgroup by default.  Alone on the chip several tiles per workgroup win (64 -> 64 at 512x512:
     // 265 -> 238 us at 4 tiles), inside the forward they lose: FD_CONV_TPW=1 / 2 / 4 for every layer gave 13.09 / 13.11 /
     // 13.37 ms per batch-8 forward against 13.13 with the launch-size rule (interleaved runs, one box).
     int tpw = tpw_env > 0 ? tpw_env : 1;
     tpw = tpw < 1 ? 1 : (tpw > 8 ? 8 : tpw);
     dim3 grid(cdiv(tiles_xy, tpw), gy, p.B), block(256);
-    static const size_t pad = fd_occ_pad("CONV3");
+    const size_t pad = fd_occ_pad(FD_DEV_PAD_CONV3);
     if (fd_conv3x3_fp8_ok(p)) {
         if (wide) hipLaunchKernelGGL((conv3x3_halo_kernel<128, 8, true>), grid, block, 0, s, p, tpw, tiles_xy);
         else if (th == 16) hipLaunchKernelGGL((conv3x3_halo_kernel<64, 16, true>), grid, block, 0, s, p, tpw, tiles_xy);

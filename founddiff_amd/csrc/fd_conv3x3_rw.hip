@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rw_kernel(const fd_conv_params
 }  // namespace
 
 int fd_conv3x3_rw_ok(const fd_conv_params &p) {
-    static const bool off = getenv("FD_NO_CONV3_RW") != nullptr;       // development switch
+    const bool off = fd_dev(FD_DEV_NO_CONV3_RW);       // development switch
     if (off || p.dtype != FD_BF16 || p.out_f32 || p.ndir != 1 || p.upsample || p.weight_f8) return 0;
     if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad_h != 1 || p.pad_w != 1) return 0;
     if (p.epilogue != FD_EPI_NONE || p.prologue != FD_PRO_NONE) return 0;
@@ -196,7 +196,7 @@ int fd_conv3x3_rw_launch(const fd_conv_params &p, hipStream_t s) {
     const int tiles_xy = (p.OH / RW_TH) * (p.OW / RW_TW);
     // persistent: one wave of resident workgroups (2 per CU), consecutive tiles each.  The partition does not touch the
     // results (every tile is computed by itself, one GroupNorm partial per tile)
-    static const int tpw_env = [] { const char *e = getenv("FD_CONV3_RW_TPW"); return e ? atoi(e) : 0; }();      // development
+    const int tpw_env = fd_dev(FD_DEV_CONV3_RW_TPW);      // development
     int tpw = tpw_env > 0 ? tpw_env : (int)(((int64_t)tiles_xy * p.B + 511) / 512);
     if (tpw < 1) tpw = 1;
     dim3 grid((tiles_xy + tpw - 1) / tpw, p.B);

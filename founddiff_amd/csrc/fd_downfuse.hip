@@ -181,7 +181,7 @@ __global__ __launch_bounds__(64 * NW, 2) void down_fused_kernel(const DownParams
 // `dtype | FD_OPT_LOW_LATENCY`: a lone slice has too few tiles per workgroup to amortise the 128 KB of weights a
 // workgroup loads; the one-slice kernel set keeps the apply pass + implicit GEMM.
 extern "C" int fd_gn_apply_down4x4_ok(int dtype_opts, int C, int Cout, int H, int W) {
-    static const bool off = getenv("FD_NO_DOWNFUSE") != nullptr;       // development switch
+    const bool off = fd_dev(FD_DEV_NO_DOWNFUSE);       // development switch
     const int dtype = dtype_opts & 0xff;
     return !off && !(dtype_opts & FD_OPT_LOW_LATENCY) && dtype == FD_BF16 && C == 64 && (Cout == 64 || Cout == 128) &&
            H % (2 * DT_OH) == 0 && W % (2 * DT_OW) == 0 && (int64_t)H * W >= 16384 && (int64_t)H * W * 128 < (1ll << 31);
@@ -203,7 +203,7 @@ extern "C" int fd_gn_apply_down4x4(int dtype, const void *h, const void *x, cons
     p.ntiles = p.tiles_x * ((H / 2) / DT_OH);
     // persistent: one wave of resident workgroups, consecutive tiles each (row-major: neighbours share halo columns in L2;
     // the partition does not touch the results: every tile is computed by itself)
-    static const int tpw_env = [] { const char *e = getenv("FD_DOWN_TPW"); return e ? atoi(e) : 0; }();      // development
+    const int tpw_env = fd_dev(FD_DEV_DOWN_TPW);      // development
     const int wgs = Cout == 64 ? 512 : 256;                 // resident workgroups of the chip (2 / 1 per CU)
     int tpw = tpw_env > 0 ? tpw_env : (int)(((int64_t)p.ntiles * B + wgs - 1) / wgs);
     if (tpw < 1) tpw = 1;

@@ -563,7 +563,7 @@ int fd_gemm_rows_launch(const fd_conv_params &p, hipStream_t s) {
     // (round 4: 3 persistent workgroups per CU instead of 4 once the batch fills the chip: -0.1..-0.3 % per batch-8 forward,
     //  2: +0.8 %; 4 for small batches: +0.7 ms per 50-step slice at batch 1 otherwise.  The grid size does not touch the
     //  results: every pixel row is computed by itself)
-    static const int pcmax = [] { const char *e = getenv("FD_ROWS_PER_CU_MAX"); return e ? atoi(e) : 0; }();    // development
+    const int pcmax = fd_dev(FD_DEV_ROWS_PER_CU_MAX);    // development
     const int pclim = pcmax > 0 ? pcmax : (p.B >= 4 ? 3 : 4);
     if (per_cu > pclim) per_cu = pclim;
     if (zre && per_cu > 3) per_cu = 3;       // 168 VGPRs with the next tile's rows in flight: 3 waves per SIMD
@@ -571,13 +571,13 @@ int fd_gemm_rows_launch(const fd_conv_params &p, hipStream_t s) {
     int nt = per_cu >= 3 ? 256 : ((per_cu == 2 || !fits_768(KS, p.prologue)) ? 512 : 768);
     if (nt == 512 && !fits_512(KS, p.prologue)) nt = 256;
     if (zre && K == 256) nt = ZRE8_NT;
-    static const int cap = [] { const char *e = getenv("FD_ROWS_PER_CU"); return e ? atoi(e) : 0; }();   // development: see fd_occ_pad
+    const int cap = fd_dev(FD_DEV_ROWS_PER_CU);   // development: see fd_occ_pad
     int gx = (256 * ((cap > 0 && per_cu > cap) ? cap : per_cu) + p.B - 1) / p.B;
     const int need = (wtiles + nt / 64 - 1) / (nt / 64);
     if (gx > need) gx = need;
     dim3 grid(gx, p.B);
     if (zre) {
-        static const bool nopf = getenv("FD_ZRE_NOPF") != nullptr;      // development
+        const bool nopf = fd_dev(FD_DEV_ZRE_NOPF);      // development
         if (K == 128 && nopf) hipLaunchKernelGGL((gemm_rows_zre_kernel<4, 256, false>), grid, dim3(256), lds, s, p, wtiles);
         else if (K == 128) hipLaunchKernelGGL((gemm_rows_zre_kernel<4, 256, true>), grid, dim3(256), lds, s, p, wtiles);
         else {

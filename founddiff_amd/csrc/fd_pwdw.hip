@@ -805,8 +805,8 @@ extern "C" int fd_pw_dw3x3_ok(int dtype_opts, int Cin, int Cdw, int Cz, int H, i
     // `dtype | FD_OPT_LOW_LATENCY`: the kernel set for ONE slice keeps the C = 128 block on row-GEMM + depthwise (the fused
     // 128-channel form has two workgroups per CU and too few tiles for a lone slice: 155 -> 153 ms per 50-step slice)
     const int dtype = dtype_opts & 0xff;
-    static const bool no128 = getenv("FD_NO_PWDW128") != nullptr;        // development switch
-    static const int minpix = [] { const char *e = getenv("FD_PWDW_MINPIX"); return e ? atoi(e) : 32768; }();    // development
+    const bool no128 = fd_dev(FD_DEV_NO_PWDW128);        // development switch
+    const int minpix = fd_dev(FD_DEV_PWDW_MINPIX);    // development
     const bool c64 = Cin == 64 && Cdw <= 192, c128 = Cin == 128 && Cdw <= 256 && Cz <= 256 && !no128 && !(dtype_opts & FD_OPT_LOW_LATENCY);
     return dtype == FD_BF16 && (c64 || c128) && Cdw > 0 && Cdw % 64 == 0 && Cz >= 0 && Cz % 32 == 0 && H % PT_H == 0 &&
            W % PT_W == 0 && (int64_t)H * W >= minpix && (int64_t)H * W * 256 < (1ll << 31);   // 32-bit element offsets
@@ -834,12 +834,12 @@ extern "C" int fd_pw_dw3x3(int dtype, const void *x, int ld_x, int off_x, int Ci
     p.Cz = Cz; p.out_z = (bf16 *)out_z; p.ld_z = ld_z; p.off_z = off_z;
     p.H = H; p.W = W;
     p.ntiles = (H / PT_H) * (W / PT_W);
-    static const int tpw_env = [] { const char *e = getenv("FD_PWDW_TPW"); return e ? atoi(e) : 0; }();
+    const int tpw_env = fd_dev(FD_DEV_PWDW_TPW);
     // (4 consecutive tiles per workgroup once the batch fills the chip; ONE for a lone slice: 154.6 -> 152.8 ms per 50-step
     //  slice at batch 1.  Tiles are independent: the split does not touch the results)
     p.tpw = tpw_env > 0 ? tpw_env : (B >= 4 ? 4 : 1);
     dim3 grid((p.ntiles + p.tpw - 1) / p.tpw, B), block(256);
-    static const size_t pad = fd_occ_pad("PWDW");
+    const size_t pad = fd_occ_pad(FD_DEV_PAD_PWDW);
     if (Cin == 64) hipLaunchKernelGGL(pwdw_kernel<64>, grid, block, pad, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(pwdw_kernel<128>, grid, block, pad, (hipStream_t)stream, p);
     FD_LAUNCH_OK("fd_pw_dw3x3");
@@ -851,7 +851,7 @@ extern "C" int fd_pw_dw3x3(int dtype, const void *x, int ld_x, int off_x, int Ci
 // w_pw [64][64] (the v rows of qkv.weight), w_dw [9][32] fp16 channel pairs (the v taps of qkv_dwconv), w2 [B][64][64]
 // (fd_chan_attn_weff's output).  With fd_pw_dw3x3_gram(out_v = NULL) in front, v never reaches HBM.
 extern "C" int fd_pw_dw3x3_proj_ok(int dtype_opts, int Cin, int H, int W) {
-    static const bool off = getenv("FD_NO_PWDW_PROJ") != nullptr;      // development switch
+    const bool off = fd_dev(FD_DEV_NO_PWDW_PROJ);      // development switch
     // (`dtype | FD_OPT_LOW_LATENCY`: for ONE slice the row-GEMM on the stored v is the shorter chain -- 151.7 against
     //  152.7 ms per 50-step slice at batch 1; the throughput set gains 0.8 % per batch-8 forward with this kernel)
     return !off && !(dtype_opts & FD_OPT_LOW_LATENCY) && Cin == 64 && fd_pw_dw3x3_ok(dtype_opts, Cin, 64, 0, H, W);
@@ -878,10 +878,10 @@ extern "C" int fd_pw_dw3x3_proj(int dtype, const void *x, int ld_x, int off_x, i
     p.out2 = (bf16 *)out; p.ld_o2 = ld_o; p.off_o2 = off_o;
     p.H = H; p.W = W;
     p.ntiles = (H / PT_H) * (W / PT_W);
-    static const int tpw_env = [] { const char *e = getenv("FD_PWDW_TPW"); return e ? atoi(e) : 0; }();
+    const int tpw_env = fd_dev(FD_DEV_PWDW_TPW);
     p.tpw = tpw_env > 0 ? tpw_env : (B >= 4 ? 4 : 1);
     dim3 grid((p.ntiles + p.tpw - 1) / p.tpw, B), block(256);
-    static const size_t pad = fd_occ_pad("PWDW");
+    const size_t pad = fd_occ_pad(FD_DEV_PAD_PWDW);
     hipLaunchKernelGGL((pwdw_kernel<64, true>), grid, block, pad, (hipStream_t)stream, p);
     FD_LAUNCH_OK("fd_pw_dw3x3_proj");
     return FD_OK;
@@ -892,12 +892,12 @@ extern "C" int fd_pw_dw3x3_proj(int dtype, const void *x, int ld_x, int off_x, i
 // 16: +0.6 %), 4 under FD_OPT_LOW_LATENCY (one slice: 8 leaves 256 workgroups for 256 CUs, +2.5 ms per 50-step slice);
 // FD_GRAM_TPW overrides both for experiments
 static int gram_tpw(int dtype_opts) {
-    static const int forced = [] { const char *e = getenv("FD_GRAM_TPW"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 64 ? v : 0; }();
+    const int gv = fd_dev(FD_DEV_GRAM_TPW), forced = gv >= 1 && gv <= 64 ? gv : 0;
     return forced ? forced : ((dtype_opts & FD_OPT_LOW_LATENCY) ? 4 : 8);
 }
 
 extern "C" int fd_pw_dw3x3_gram_ok(int dtype, int Cin, int H, int W) {
-    static const bool off = getenv("FD_NO_GRAM_FUSE") != nullptr;      // development switch
+    const bool off = fd_dev(FD_DEV_NO_GRAM_FUSE);      // development switch
     return !off && Cin == 64 && fd_pw_dw3x3_ok(dtype, Cin, 192, 0, H, W);      // pwdw_gram_kernel is the 64-channel form
 }
 
@@ -928,7 +928,7 @@ extern "C" int fd_pw_dw3x3_gram(int dtype, const void *x, int ld_x, int off_x, i
     p.part = partial; p.nblk = fd_pw_dw3x3_gram_nblk_opts(dtype_opts, H, W);
     p.H = H; p.W = W; p.tpw = gram_tpw(dtype_opts); p.ntiles = (H / PT_H) * (W / PT_W);
     dim3 grid(p.nblk, B), block(256);
-    static const size_t pad = fd_occ_pad("PWDW");
+    const size_t pad = fd_occ_pad(FD_DEV_PAD_PWDW);
     hipLaunchKernelGGL(pwdw_gram_kernel, grid, block, pad, (hipStream_t)stream, p);
     FD_LAUNCH_OK("fd_pw_dw3x3_gram");
     return FD_OK;
@@ -938,7 +938,7 @@ extern "C" int fd_pw_dw3x3_gram(int dtype, const void *x, int ld_x, int off_x, i
 static int dwgram_tpw(int ntiles) { return ntiles >= 256 ? 4 : (ntiles >= 64 ? 2 : 1); }
 
 extern "C" int fd_dwconv_gram_ok(int dtype, int C, int H, int W) {
-    static const bool off = getenv("FD_NO_DWGRAM") != nullptr;         // development switch
+    const bool off = fd_dev(FD_DEV_NO_DWGRAM);         // development switch
     return !off && dtype == FD_BF16 && C % 64 == 0 && C >= 64 && H % PT_H == 0 && W % PT_W == 0 &&
            (int64_t)H * W * 3 * C < (1ll << 31);
 }

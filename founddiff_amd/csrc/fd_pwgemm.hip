@@ -284,7 +284,7 @@ __global__ __launch_bounds__(TNC * 2, 2) void pw_gemm_kernel(const fd_conv_param
 // 1 if `p` runs on the persistent pointwise GEMM: bf16, 1x1 / stride 1 / one source, K and Cout multiples of 256, whole
 // 256-pixel row blocks per image, no GroupNorm sums, epilogue NONE / SILU_SPLIT / GATE_RES, enough tiles to fill the chip.
 int fd_pwgemm_ok(const fd_conv_params &p) {
-    static const bool off = getenv("FD_NO_PWGEMM") != nullptr;            // development switch: the generic 256x256 tile
+    const bool off = fd_dev(FD_DEV_NO_PWGEMM);            // development switch: the generic 256x256 tile
     if (off || p.dtype != FD_BF16 || p.out_f32 || p.ndir != 1 || p.prologue != FD_PRO_NONE) return 0;
     if (p.KH != 1 || p.KW != 1 || p.stride != 1 || p.pad_h != 0 || p.pad_w != 0 || p.upsample) return 0;
     if (p.OH != p.H || p.OW != p.W || p.c1 != 0 || p.in1) return 0;

@@ -913,7 +913,7 @@ __global__ __launch_bounds__(256) void scan_seq_kernel(const T *__restrict__ xc,
 
 // the single-pass form applies to (image size, state size, rank) only: batch-invariant by construction
 bool scan_seq_ok(int H, int W, int D, int N, int R) {
-    static const bool off = getenv("FD_SCAN_NO_SEQ") != nullptr;     // development switch: time the chunked form
+    const bool off = fd_dev(FD_DEV_SCAN_NO_SEQ);     // development switch: time the chunked form
     if (off) return false;
     const int L = ((H + 1) / 2) * ((W + 1) / 2);
     return L <= SEQ_MAXL && N >= 16 && N % (2 * SEQ_LPC) == 0 && R % (2 * SEQ_LPC) == 0 && D % 64 == 0;
@@ -929,7 +929,7 @@ void launch_scan_seq(const T *xc, const float *xdbl, const float *dtw, const flo
 }
 
 static bool scan_cpl2_on() {
-    static const bool off = getenv("FD_SCAN_NO_CPL2") != nullptr;    // development switch
+    const bool off = fd_dev(FD_DEV_SCAN_NO_CPL2);    // development switch
     return !off;
 }
 
@@ -952,7 +952,7 @@ void launch_scan(const T *xc, const float *xdbl, const float *dtw, const float *
     const int cw = two ? 128 : 64;                     // channels per wave
     const int nw = g.D >= 4 * cw ? 4 : g.D / cw;       // waves per workgroup
     dim3 grid(g.nch * (g.D / (cw * nw)), g.B * 4), block(64 * nw);
-    static const size_t pad = fd_occ_pad("SCAN");
+    const size_t pad = fd_occ_pad(FD_DEV_PAD_SCAN);
     // (+ 4 KB behind the rows: the u block of the two-channel phase A with the fused x_proj)
     const size_t lds = (size_t)g.CL * ((g.CD + 3) & ~3) * sizeof(float) + (two && g.xw ? 4096 : 0) + pad;
     if (two) hipLaunchKernelGGL((scan_chunk_kernel<T, N, R, false, ODD, CPL>), grid, block, lds, s, xc, xdbl, dtw, dtb, A, Ds, y, wsH, wsP, g);
@@ -1007,7 +1007,7 @@ int chunk_len(int L, int D, bool low_latency) {
     // Round 4: 32-step chunks only pay for ONE slice (low_latency); from batch 8 up the chip is full anyway and a chunk
     // start costs its constants, its x_dbl staging and a carry entry: 64-step chunks measured 316 -> 270 us (d_inner 128,
     // N = 8 at 256x256) and 472 -> 429 us (d_inner 512, N = 16 at 128x128) at batch 8, level 0 (128 steps) unchanged.
-    static const int force = [] { const char *e = getenv("FD_SCAN_CL"); return e ? atoi(e) : 0; }();     // development: chunk-length experiments
+    const int force = fd_dev(FD_DEV_SCAN_CL);     // development: chunk-length experiments
     if (force >= 32 && force <= 256 && (force & (force - 1)) == 0) return force;
     int64_t units = (int64_t)4 * (D / 64) * L;
     int cl = 256;

@@ -14,6 +14,37 @@ void fd_set_error(const char *fmt, ...) {
 }
 
 extern "C" const char *fd_last_error(void) { return g_err; }
+
+// ---- development switches (fd_common.h: FD_DEV_SWITCHES)
+#ifdef FD_RELEASE
+extern "C" const char *fd_dev_options(void) { return "release build: development switches compiled out (every one at its default)"; }
+#else
+namespace {
+struct DevTable {
+    int v[FD_DEV_COUNT];
+    char text[2048];
+    DevTable() {
+        static const struct { const char *name; char kind; int dflt; } tab[] = {
+#define FD_DEV_ROW(name, kind, dflt) {"FD_" #name, #kind[0], dflt},
+            FD_DEV_SWITCHES(FD_DEV_ROW)
+#undef FD_DEV_ROW
+        };
+        size_t n = (size_t)snprintf(text, sizeof text, "development build; switches set:");
+        for (int i = 0; i < FD_DEV_COUNT; ++i) {
+            const char *e = getenv(tab[i].name);
+            v[i] = e ? (tab[i].kind == 'F' ? 1 : atoi(e)) : tab[i].dflt;
+            if (e && n < sizeof text) n += (size_t)snprintf(text + n, sizeof text - n, " %s=%d", tab[i].name, v[i]);
+        }
+    }
+};
+const DevTable &dev_table() {
+    static const DevTable t;        // read once; thread-safe initialisation
+    return t;
+}
+}  // namespace
+int fd_dev(int id) { return dev_table().v[id]; }
+extern "C" const char *fd_dev_options(void) { return dev_table().text; }
+#endif
 extern "C" int fd_version(void) { return 100; }
 
 namespace {

@@ -32,6 +32,11 @@ extern "C" {
 #define FD_ERR_LAUNCH (-2)
 
 int fd_version(void);
+/* Development switches (round 6).  The release build (what founddiff_amd.build.build() ships: -DFD_RELEASE) reads NO environment
+ * variable: every tuning switch of the dispatch code is compiled to its default.  A development build (FOUNDDIFF_DEV_BUILD=1)
+ * reads the FD_* variables of founddiff_amd/csrc/fd_common.h (FD_DEV_SWITCHES) once, on the first call that needs one.  Returns a
+ * static string: "release build: ..." or the switches that are set.                                                    */
+const char *fd_dev_options(void);
 const char *fd_last_error(void);
 
 /* ---- implicit-GEMM convolution / GEMM on MFMA -------------------------------------------

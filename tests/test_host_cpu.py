@@ -275,3 +275,13 @@ def test_kernel_scratch_ledger():
             if r.get("scratch", 0) > limit:
                 bad.append((f, name, r["scratch"], limit))
     assert not bad, bad
+    # conv3x3_halo_kernel's halo registers are written by inline-asm loads (hidden from the compiler's waitcnt pass).
+    # A register parked in an AGPR or in scratch before its load has landed would park garbage: every instantiation that uses
+    # the asm loads must have neither -- the one that spills (the 128-channel split form) is compiled with plain loads instead.
+    for name, r in res["fd_conv3x3.hip"].items():
+        if "conv3x3_halo_kernel" not in name:
+            continue
+        plain = re.search(r"conv3x3_halo_kernelILi128ELi8ELb0ELb0ELb1E", name) is not None     # <128, 8, F8 = 0, UP = 0, SPL = 1>
+        if plain:
+            continue
+        assert r.get("agpr", 0) == 0 and r.get("scratch", 0) == 0, (name, r)

@@ -1,11 +1,15 @@
 #!/usr/bin/env python3
 """Kernel resource usage (VGPR / scratch / occupancy) of one csrc/*.hip file, compactly."""
-import re, subprocess, sys
+import os, re, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from founddiff_amd import build as _build          # the library's own compiler and flags (HIPCC from the environment, include path from __file__)
+HIPCC = _build.HIPCC
+CFLAGS = [f for f in _build.FLAGS if not f.startswith("-Rpass") and f != "-fPIC"]
 src = sys.argv[1]
-if src == "--check-drain":          # (the ISA check at the end of this file)
+if src == "--check-drain":          # (the ISA checks at the end of this file)
     src = None
-r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17",
-                    "-I/root/repo/include", "-c", src, "-o", "/tmp/kres.o", "-Rpass-analysis=kernel-resource-usage"],
+r = subprocess.run([HIPCC] + CFLAGS + ["-c", src, "-o", "/tmp/kres.o", "-Rpass-analysis=kernel-resource-usage"],
                    capture_output=True, text=True) if src else subprocess.CompletedProcess([], 0, "", "")
 cur = {}
 for line in r.stderr.splitlines():
@@ -30,15 +34,26 @@ if r.returncode:
 # (FD_MFMA_ASM_DRAIN, fd_common.h); the accumulators are tied to that block as asm operands, so the compiler cannot schedule
 # a consumer above it.  This check reads the ISA anyway: between the last v_mfma in front of a drain block and the block itself
 # no VALU instruction may read a register any of the preceding MFMAs writes.
-def check_drain(src):
-    import os
+def isa_lines(src):
     asm = "/tmp/kres_%s.s" % os.path.basename(src)
-    r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17",
-                        "-I/root/repo/include", "-I" + os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "include"),
-                        "-S", "--cuda-device-only", src, "-o", asm], capture_output=True, text=True)
+    r = subprocess.run([HIPCC] + CFLAGS + ["-S", "--cuda-device-only", src, "-o", asm], capture_output=True, text=True)
     if r.returncode:
         raise RuntimeError(r.stderr[-2000:])
-    lines = [ln.strip() for ln in open(asm)]
+    return [ln.strip() for ln in open(asm)]
+
+
+def vregs(tok):
+    out = set()
+    for m in re.finditer(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b", tok):
+        if m.group(3) is not None:
+            out.add(int(m.group(3)))
+        else:
+            out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    return out
+
+
+def check_drain(src):
+    lines = isa_lines(src)
 
     def regs(tok):
         out = set()
