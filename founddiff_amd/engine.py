@@ -23,6 +23,12 @@ _T = {"fp32": (L.FD_F32, torch.float32), "bf16": (L.FD_BF16, torch.bfloat16), "f
 FP8_ACT_SCALE = 8.0     # activations are multiplied by this power of two before the e4m3 conversion (|x| <= 56 exact range)
 
 
+def _dev(name, default):
+    """Development switch of the host side (A/B tools): honoured only when FOUNDDIFF_DEV=1 is set as well -- a production process
+    ignores it, like the release build of the library ignores the FD_* switches (include/founddiff_hip.h: fd_dev_options)."""
+    return os.environ.get(name, default) if os.environ.get("FOUNDDIFF_DEV") == "1" else default
+
+
 def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
@@ -62,7 +68,7 @@ class ConvW:
                 uh = wu.to(torch.bfloat16)
                 self.w_up_hi, self.w_up_lo = uh.contiguous().to(dev), (wu - uh.float()).to(torch.bfloat16).contiguous().to(dev)
         if (up2x and kh == 3 and kw == 3 and tdt == torch.bfloat16 and cin_pad is None
-                and not (fp8 and os.environ.get("FOUNDDIFF_FP8_UPCONV") == "1")):       # (development: e4m3 9-tap up-sampling convs again)
+                and not (fp8 and _dev("FOUNDDIFF_FP8_UPCONV", "0") == "1")):       # (development: e4m3 9-tap up-sampling convs again)
             self.w_up = pack_up2x(w).to(dev, tdt)          # the up-sampling convs as four 2x2 convs on the source grid
         # (the fp8 mode runs its up-sampling convolutions on the bf16 four-2x2 form: as fast as 9 e4m3 taps at twice the rate
         #  -- 29.5 vs 29.5 slices/s alternated -- and nothing lost to the weight quantisation: drift 3.7e-2 -> 3.1e-2)
@@ -138,11 +144,11 @@ class DAEngine:
         self.scan_dt = self.dt | (L.FD_OPT_LOW_LATENCY if low_latency else 0) | (L.FD_OPT_F32_SPLIT if mode == "fp32s" else 0)
         # z gate of SS2D recomputed inside out_proj instead of written by in_proj and read back (mamba_block); 0 = round-3 dataflow
         # (development: 64 = only in the 64-channel blocks)
-        self.z_recompute = int(os.environ.get("FOUNDDIFF_Z_RECOMPUTE", "1"))
+        self.z_recompute = int(_dev("FOUNDDIFF_Z_RECOMPUTE", "1"))
         # v of the 64-channel TransposedAttention recomputed inside the kernel that applies Weff (mamba_block); 0 = stored v
-        self.v_recompute = os.environ.get("FOUNDDIFF_V_RECOMPUTE", "1") == "1"
+        self.v_recompute = _dev("FOUNDDIFF_V_RECOMPUTE", "1") == "1"
         # GroupNorm apply of the down-path blocks fused with the 4x4 / stride-2 convolution behind them (_down); 0 = two passes
-        self.down_fuse = os.environ.get("FOUNDDIFF_DOWN_FUSE", "1") == "1"
+        self.down_fuse = _dev("FOUNDDIFF_DOWN_FUSE", "1") == "1"
         self.dev = torch.device(device)
         self.f32 = dict(device=self.dev, dtype=torch.float32)
         sd = _Sub(state_dict, prefix)
@@ -977,7 +983,7 @@ class DAEngine:
             fin.update(mode=1, alpha=sched[0], last=int(bool(sched[1])), img=x_t, xin=x_in)
         kw = dict(c0=c0, in1=r, c1=c1)
         if (fr["res"] is not None and (self.tdt == torch.bfloat16 or getattr(self, "f32_split", 0)) and not self.probe
-                and not os.environ.get("FOUNDDIFF_NO_FINAL_FOLD")):
+                and _dev("FOUNDDIFF_NO_FINAL_FOLD", "") == ""):
             mt = L.lib().fd_conv_mtiles(H, W)
             hraw = self._b("res_h", (B, H, W, cw.Cout))
             part = self._b("gn_part", (B, mt, cw.Cout, 2), torch.float32)

@@ -1,8 +1,8 @@
 #!/bin/bash
-# Evidence run of round 5 (run on the GPU box from the repo root): bash tools/profile_round5.sh r05
+# Evidence run of round 6 (run on the GPU box from the repo root): bash tools/profile_round6.sh r06
 # Counters in their own passes with --kernel-trace only (gpurun refuses --pmc next to the other trace domains).
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
