@@ -70,6 +70,8 @@ __global__ __launch_bounds__(TNC * 2, 2) void pw_gemm_kernel(const fd_conv_param
     // of every tile
     __shared__ __attribute__((aligned(16))) float s_bias[PG_MAXC];
     __shared__ __attribute__((aligned(16))) float s_gate[EPI == FD_EPI_GATE_RES ? PG_MAXG : 4];
+    static_assert(PG_NS * PG_SLOT + (PG_MAXC + PG_MAXG) * sizeof(float) <= 160 * 1024 - 1024,
+                  "pw_gemm_kernel: ring + bias + gate tables must fit a CU's 160 KB of LDS (the gated form sits at 152 KB)");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WNW, wn = wave % WNW;
@@ -294,7 +296,7 @@ int fd_pwgemm_ok(const fd_conv_params &p) {
     if (p.epilogue == FD_EPI_SILU_SPLIT && p.epi_split % 8) return 0;
     if (p.ld0 % 8 || p.off0 % 8 || p.ldo % 8 || p.offo % 8) return 0;
     if (p.epilogue == FD_EPI_GATE_RES && (!p.res || !p.gate || p.ld_res % 8 || p.off_res % 8)) return 0;
-    if (p.Cout > PG_MAXC || (p.epilogue == FD_EPI_GATE_RES && (int64_t)p.B * p.Cout > PG_MAXG)) return 0;     // the LDS tables
+    if (p.Cout > PG_MAXC) return 0;     // the LDS bias table (the gate table holds B x Cout floats: larger batches launch in image groups)
     if ((int64_t)p.OH * p.OW * p.ld0 * 2 >= (1ll << 31) || (int64_t)p.Cout * p.c0 * 2 >= (1ll << 31)) return 0;   // 32-bit DMA offsets
     const int64_t tiles = (int64_t)p.B * ((int64_t)p.OH * p.OW / 256) * (p.Cout / 256);
     // K = 256 tiles with the SiLU epilogue are epilogue-bound (8 stages of MFMA against ~1000 VALU instructions per lane):
@@ -304,7 +306,26 @@ int fd_pwgemm_ok(const fd_conv_params &p) {
     return tiles >= 192;
 }
 
-int fd_pwgemm_launch(const fd_conv_params &p, hipStream_t s) {
+int fd_pwgemm_launch(const fd_conv_params &pp, hipStream_t s) {
+    // GATE_RES stages gate[b][n] of the whole launch in LDS (PG_MAXG floats).  A batch beyond that (Cout 512 at sub-batch 16, Cout
+    // 256 at 32 ...) used to leave this kernel for the generic tile without a word: it now runs as several launches
+    // over groups of whole images -- every output element sees the same K order, the results are the same bits.
+    if (pp.epilogue == FD_EPI_GATE_RES && (int64_t)pp.B * pp.Cout > PG_MAXG) {
+        const int per = PG_MAXG / pp.Cout;               // >= 2: Cout <= PG_MAXC
+        const int64_t hw = (int64_t)pp.OH * pp.OW;
+        for (int b0 = 0; b0 < pp.B; b0 += per) {
+            fd_conv_params q = pp;
+            q.B = (pp.B - b0 < per) ? pp.B - b0 : per;
+            q.in0 = (const bf16 *)pp.in0 + (int64_t)b0 * hw * pp.ld0;
+            q.res = (const bf16 *)pp.res + (int64_t)b0 * hw * pp.ld_res;
+            q.out = (bf16 *)pp.out + (int64_t)b0 * hw * pp.ldo;
+            q.gate = pp.gate + (int64_t)b0 * pp.gate_ld;
+            if (pp.w_batch_stride) q.weight = (const bf16 *)pp.weight + (int64_t)b0 * pp.w_batch_stride;
+            fd_pwgemm_launch(q, s);
+        }
+        return 0;
+    }
+    const fd_conv_params &p = pp;
     const int TM = p.B * (int)((int64_t)p.OH * p.OW / 256), TN = p.Cout / 256, nst = p.c0 / 32;
     if (p.epilogue == FD_EPI_SILU_SPLIT) hipLaunchKernelGGL((pw_gemm_kernel<256, FD_EPI_SILU_SPLIT>), dim3(256), dim3(512), 0, s, p, TM, TN, nst);
     else if (p.epilogue == FD_EPI_GATE_RES) hipLaunchKernelGGL((pw_gemm_kernel<256, FD_EPI_GATE_RES>), dim3(256), dim3(512), 0, s, p, TM, TN, nst);

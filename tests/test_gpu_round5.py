@@ -198,7 +198,7 @@ def test_conv3x3_upsample_as_four_2x2(cfg):
     assert torch.equal(o1, first)
 
 
-@pytest.mark.parametrize("cfg", [dict(c0=64, c1=0, cout=64, hw=(64, 64), up=False),          # <64, 16, SPL>
+@pytest.mark.parametrize("cfg", [dict(c0=64, c1=0, cout=64, hw=(64, 64), up=False),          # <64, 8, SPL> (the split form launches 8-row tiles at every width: no SPL TH = 16 instantiation exists)
                                  dict(c0=64, c1=64, cout=64, hw=(72, 64), up=False),         # two sources, <64, 8, SPL>
                                  dict(c0=128, c1=64, cout=128, hw=(64, 64), up=False),       # 192 -> 128: <128, 8, SPL>, three slabs
                                  dict(c0=128, c1=0, cout=64, hw=(64, 64), up=True),          # through the up-sampling index map

@@ -399,3 +399,29 @@ def test_two_stream_sample_repeatable_at_bench_size(prec):
     torch.cuda.synchronize()
     for i, o in enumerate(outs):
         assert torch.equal(o, one), (prec, i, float((o - one).abs().max()))
+
+
+def test_pointwise_gemm_gate_table_batch_groups(eng_factory):  # noqa: F811
+    """pw_gemm_kernel stages gate[b][n] of a launch in LDS (4096 floats).  A GATE_RES layer whose batch exceeds the table (Cout
+    512 at sub-batch 16) used to leave the kernel silently for the generic tile; it now runs as launches over groups
+    of whole images: kernel id 7 at every batch, and the results of a batch of 16 are bitwise those of two batches of 8."""
+    from founddiff_amd import _lib as L
+    from founddiff_amd.engine import ConvW
+    e = eng_factory("bf16")
+    torch.manual_seed(17)
+    B, H, W, K, N = 16, 64, 64, 1024, 512
+    x = (torch.randn(B, H, W, K) * 0.5).to("cuda", torch.bfloat16)
+    res = torch.randn(B, H, W, N).to("cuda", torch.bfloat16)
+    gate = torch.randn(B, N, device="cuda")
+    cw = ConvW(torch.randn(N, K) / 32, None, e.dev, e.tdt)
+    kw = dict(epi=L.EPI_GATE_RES, gate=gate, gate_ld=N)
+    out = torch.empty(B, H, W, N, device="cuda", dtype=torch.bfloat16)
+    assert e.conv(cw, x, B, H, W, out, probe="kid", res=res, **kw) == 7
+    e.conv(cw, x, B, H, W, out, res=res, **kw)
+    halves = torch.empty_like(out)
+    for b0 in (0, 8):
+        e.conv(cw, x[b0:b0 + 8], 8, H, W, halves[b0:b0 + 8], res=res[b0:b0 + 8], epi=L.EPI_GATE_RES, gate=gate[b0:b0 + 8], gate_ld=N)
+    torch.cuda.synchronize()
+    assert torch.equal(out, halves)
+    ref = res.float() + gate[:, None, None, :] * torch.einsum("bhwk,nk->bhwn", x.float(), cw.w.float())
+    assert rel_err(out.float().cpu(), ref.cpu()) < 1.5e-2
