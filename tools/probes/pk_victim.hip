@@ -9,6 +9,7 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 template <int MODE>
 __global__ __launch_bounds__(256) void pk_victim(uint32_t *out, int iters, float a0, float b0, const float *grow) {
+    const float *grow2 = grow + 128;
     const int gid = blockIdx.x * 256 + threadIdx.x;
     f32x2 x = {0.5f + 1e-3f * (gid & 1023), 0.25f + 2e-3f * (gid & 511)};
     float sx = x.x, sy = x.y;
@@ -41,7 +42,13 @@ __global__ __launch_bounds__(256) void pk_victim(uint32_t *out, int iters, float
         } else if (MODE >= 4) {                // the scan step's shape: an LDS broadcast row (ds_read_b128, same address in all lanes) feeds the
                                                // arithmetic; the REFERENCE path reads the same values from global memory (no LDS)
             const int ri = (i & 31) * 4;
-            float4 r = *(const float4 *)&srow[ri];
+            float4 r;
+            if (MODE == 8) {                   // 8: the row from GLOBAL memory (a second copy; asm: a real global_load per iteration)
+                typedef __attribute__((ext_vector_type(4))) float f4;
+                f4 g;
+                asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(g) : "v"(grow2 + ri) : "memory");
+                r.x = g[0]; r.y = g[1]; r.z = g[2]; r.w = g[3];
+            } else r = *(const float4 *)&srow[ri];
             const float4 cg = *(const float4 *)&grow[ri];
             const float c0 = cg.x, c1 = cg.y, c2 = cg.z, c3 = cg.w;
             if (MODE == 6) asm volatile("v_mov_b32 %0, %0\n\tv_mov_b32 %1, %1\n\tv_mov_b32 %2, %2\n\tv_mov_b32 %3, %3" : "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w));
@@ -133,6 +140,7 @@ extern "C" int pk_victim_launch(int mode, uint32_t *out, int iters, int blocks, 
     case 5: hipLaunchKernelGGL(pk_victim<5>, dim3(blocks), dim3(256), 0, s, out, iters, 0.97f, 0.013f, grow); break;
     case 6: hipLaunchKernelGGL(pk_victim<6>, dim3(blocks), dim3(256), 0, s, out, iters, 0.97f, 0.013f, grow); break;
     case 7: hipLaunchKernelGGL(pk_victim<7>, dim3(blocks), dim3(256), 0, s, out, iters, 0.97f, 0.013f, grow); break;
+    case 8: hipLaunchKernelGGL(pk_victim<8>, dim3(blocks), dim3(256), 0, s, out, iters, 0.97f, 0.013f, grow); break;
     default: hipLaunchKernelGGL(pk_victim<3>, dim3(blocks), dim3(256), 0, s, out, iters, 0.97f, 0.013f, grow); break;
     }
     return (int)hipGetLastError();

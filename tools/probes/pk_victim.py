@@ -49,11 +49,11 @@ sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
 blocks, iters = 256 * 4, 20000            # 4 workgroups of 4 waves per CU: one wave per SIMD per workgroup, room for the aggressor
 out = torch.zeros(blocks * 256 * 2, dtype=torch.int32, device=dev)
 names = {0: "v_pk_fma_f32 chain", 1: "v_pk_mul_f32 -> plain adds", 2: "v_exp x2 -> v_pk_mul / v_pk_fma", 3: "v_pk_add_f32 chain",
-         4: "LDS row -> packed arithmetic", 5: "LDS row -> plain arithmetic", 6: "LDS row -> v_mov copies -> packed", 7: "LDS row, wait + s_nop 7 -> packed"}
+         4: "LDS row -> packed arithmetic", 5: "LDS row -> plain arithmetic", 6: "LDS row -> v_mov copies -> packed", 7: "LDS row, wait + s_nop 7 -> packed", 8: "GLOBAL row (global_load_dwordx4) -> packed"}
 dummy = torch.zeros(64, device=dev)
-grow = (0.9 + 0.001 * torch.arange(128, dtype=torch.float32)).to(dev)
+grow = (0.9 + 0.001 * torch.arange(128, dtype=torch.float32)).repeat(2).to(dev)      # [0:128] feeds the LDS row and the reference, [128:256] mode 8
 for key, la in aggr.items():
-    for mode in range(8):
+    for mode in range(9):
         out.zero_()
         torch.cuda.synchronize()
         if la is not None and la[0] == "own":
