@@ -219,6 +219,7 @@ __device__ __forceinline__ u32x4 fd_ln_mod_chunk(u32x4 raw, const f32x2 (&g)[4],
     X(DOWN_TPW, I, 0)           /* fd_downfuse.hip: tiles per workgroup */                             \
     X(ROWS_PER_CU_MAX, I, 0)    /* fd_gemm_rows.hip: persistent workgroups per CU, upper limit */      \
     X(ROWS_PER_CU, I, 0)        /* fd_gemm_rows.hip: persistent workgroups per CU, cap */              \
+    X(ROWS32_PER_CU, I, 3)         /* fd_gemm_rows32.hip: persistent workgroups per CU, upper limit */   \
     X(ZRE_NOPF, F, 0)           /* fd_gemm_rows.hip: z-recompute out_proj without the next-tile prefetch */ \
     X(NO_PWDW128, F, 0)         /* fd_pwdw.hip: the C = 128 fused in_proj kernel off */                \
     X(PWDW_MINPIX, I, 32768)    /* fd_pwdw.hip: smallest image the fused kernels take */               \

@@ -457,7 +457,8 @@ int fd_gemm_rows32_launch(const fd_conv_params &p, hipStream_t s) {
     const int wtiles = (int)((hw + 15) / 16);
     const size_t lds = rows32_lds(p);
     int per_cu = (int)(150 * 1024 / lds);
-    if (per_cu > 3) per_cu = 3;
+    const int pcmax = fd_dev(FD_DEV_ROWS32_PER_CU);
+    if (per_cu > pcmax) per_cu = pcmax;
     if (per_cu < 1) per_cu = 1;
     // one resident workgroup per CU: its waves are the CU's waves (8 of them); otherwise 4-wave workgroups
     const int nt = per_cu >= 2 ? 256 : 512;
