@@ -362,9 +362,12 @@ def fp32_parity_leg(dev, x, noise, steps=1, precision="fp32"):
     torch.cuda.empty_cache()
     return {"value": round(B / dt, 4), "unit": "slices/s", "ms_per_step": round(dt * 1e3, 2),
             "ms_per_unet_forward_per_slice": round(dt / S_DDIM / B * 1e3, 3), "steps": steps, "batch": B,
-            "dtype": "f32 storage, exact-f32 MFMA" if precision == "fp32" else
-                     "f32 storage, split-bf16 contractions (3 bf16 MFMAs per product)",
-            "gate": "<= 1e-3 max-rel vs the reference goldens and the CPU oracle (tests/test_gpu_e2e.py, tests/test_gpu_round5.py)"}
+            "dtype": {"fp32": "f32 storage, exact-f32 MFMA", "fp32s": "f32 storage, split-bf16 contractions (3 bf16 MFMAs per product)",
+                      "fp16": "the bf16 engine's kernels on the library's IEEE-binary16 build (libfounddiff_hip_f16.so): f16 storage "
+                              "and MFMA operands, f32 accumulation; whole last step on the fp32s engine"}[precision],
+            "gate": ("<= 1e-3 L2 (>= 70 dB) vs the CPU oracle over the 50-step loop at 256x256 and 512x512, measured 6.9e-4 / 6.3e-4, "
+                     "max-rel 1.5e-3 (tests/test_gpu_fp16.py); binary16 range: a non-finite result raises" if precision == "fp16" else
+                     "<= 1e-3 max-rel vs the reference goldens and the CPU oracle (tests/test_gpu_e2e.py, tests/test_gpu_round5.py)")}
 
 
 def fp8_leg(dev, x, noise, ddim_steps=25):
@@ -543,9 +546,9 @@ def main():
                     "roofline.box_under_halo_replay (for runs under rocprofv3 --stats: the replayed launches would be counted)")
     ap.add_argument("--no-fp32-leg", action="store_true")
     ap.add_argument("--no-smi", action="store_true", help="skip the untimed replay with the rocm-smi clock / power sampler")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp8"],
-                    help="fp8: BASELINE configs[4] -- e4m3 weights on the fp8 MFMA for the 3x3 convs; a separate "
-                         "variant, never the headline")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp8", "fp16"],
+                    help="fp8: BASELINE configs[4] -- e4m3 weights on the fp8 MFMA for the 3x3 convs; fp16: the same kernels on the "
+                         "library's binary16 build; separate variants, never the headline")
     ap.add_argument("--ddim-steps", type=int, default=S_DDIM, help="25 with --precision fp8 reproduces configs[4]")
     ap.add_argument("--sampler", default="ddim", choices=["ddim", "ancestral"],
                     help="ancestral: BASELINE configs[3]'s 1000-step p_sample_loop (keyed per-slice step noise) as the timed "
@@ -641,11 +644,12 @@ def main():
             "value": round(slices / dt, 4), "unit": "slices/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": ("bf16" if a.precision == "bf16" else "bf16 activations, e4m3 weights (fp8 MFMA) in the 3x3 convs")
+            "dtype": {"bf16": "bf16", "fp16": "f16 (IEEE binary16 storage and MFMA operands, f32 accumulation)",
+                      "fp8": "bf16 activations, e4m3 weights (fp8 MFMA) in the 3x3 convs"}[a.precision]
                      + (f"; last {dif.final_fp32_steps} step(s): "
                         + (f"resolution levels 0-{dif.final_outer_levels - 1}" if dif.final_outer_levels else "whole forward")
                         + (" on the fp32s engine (fp32 storage, split-bf16 contractions: 3 bf16 MFMAs per product)"
-                           if a.precision == "bf16" else " in bf16") if dif.final_fp32_steps else ""),
+                           if a.precision in ("bf16", "fp16") else " in bf16") if dif.final_fp32_steps else ""),
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: 512x512 slice, 50-step DDIM, full FoundDiff UNet "
                                    "(dim 64, mults 1-2-4-8) + DA-CLIP RN50 cond, bf16",
@@ -675,6 +679,8 @@ def main():
             res["ancestral_config3"] = ancestral_leg(dev, x)
             res["latency_b1"] = latency_leg(dev, x, noise)
         if world == 1 and not a.no_fp32_leg and a.precision == "bf16":
+            # the 16-bit engine on the binary16 build: the bf16 mode's speed class at L2 <= 1e-3 against the oracle over the loop
+            res["fp16_mode"] = fp32_parity_leg(dev, x, noise, steps=2, precision="fp16")
             res["fp32s_parity_mode"] = fp32_parity_leg(dev, x, noise, precision="fp32s")
             res["fp32_parity_mode"] = fp32_parity_leg(dev, x, noise)
         if world == 1 and not a.no_cpu_baseline:

@@ -346,7 +346,12 @@ class ResidualDiffusion(nn.Module):
         # engine (tools/e2e_drift.py): pure bf16 1.12e-2 L2 / 49.8 dB at 11.0 slices/s; whole last step in fp32
         # 4.6e-3 / 57.5 dB at 10.2; levels 0-1 of the last step in fp32 (default 2) 7.0e-3 / 53.8 dB at 10.5;
         # level 0 alone 1.01e-2 (the error of the inner levels passes through the outer up path undamped).
-        self.final_outer_levels = int(os.environ.get("FOUNDDIFF_FINAL_OUTER_LEVELS", "2"))
+        # precision='fp16' (the binary16 build of the same kernels): default 0 -- the whole last step on the fp32-storage engine.
+        # Its 49 steps leave 1.6e-3 L2 against the CPU oracle at 512x512 (bf16: 1.3e-2); the last step on levels 0-1 makes that
+        # 1.06e-3, on all levels 6.3e-4 / 75.6 dB for +2.6 % time (tools/probes/fp16_drift.py; profiles/r06/fp16_mode.md).
+        lv = os.environ.get("FOUNDDIFF_FINAL_OUTER_LEVELS")
+        self.final_outer_levels = None if lv is None else int(lv)       # (None: the default of the model's precision, see the property)
+        self.check_fp16_range = os.environ.get("FOUNDDIFF_FP16_CHECK", "1") != "0"
         # how many of those levels also run their DOWN stage on the tail engine (default: all of them)
         self.final_down_levels = int(os.environ.get("FOUNDDIFF_FINAL_DOWN_LEVELS", "-1"))
         # adaLN vectors of all DDIM steps in one pass in front of the captured loop (DAEngine.time_cond_table) instead of six
@@ -563,6 +568,16 @@ class ResidualDiffusion(nn.Module):
                _p(pred_img), _p(x_start), B, x[0].numel(), _stream(x))
         return pred_img, x_start
 
+    @property
+    def final_outer_levels(self):
+        if self._final_outer_levels is not None:
+            return self._final_outer_levels
+        return 0 if self.model.unet0.precision == "fp16" else 2
+
+    @final_outer_levels.setter
+    def final_outer_levels(self, v):
+        self._final_outer_levels = None if v is None else int(v)
+
     # ---- the per-step hot loop: graph-captured UNet forward + one scheduler kernel
     def _tail_engine(self, eng):
         """(K, engine or None): the higher-precision engine of the last K steps of a loop (final_fp32_steps):
@@ -574,7 +589,7 @@ class ResidualDiffusion(nn.Module):
         # 'fp32s' = fp32 storage with split-bf16 contractions (engine.py): 2^-16 per product is far below the bf16
         # error of the 49 steps before it, at a third of the exact-f32 MFMA's time; FOUNDDIFF_TAIL_EXACT=1 restores 'fp32'
         tail32 = "fp32" if os.environ.get("FOUNDDIFF_TAIL_EXACT") else "fp32s"
-        e32 = self.model.unet0.engine(tail32 if eng.mode == "bf16" else "bf16", slot=self._slot)
+        e32 = self.model.unet0.engine(tail32 if eng.mode in ("bf16", "fp16") else "bf16", slot=self._slot)
         e32.share_condition(eng)
         return K, e32
 
@@ -903,6 +918,17 @@ class ResidualDiffusion(nn.Module):
         """src/DADiff.py:1368-1380: x_input = [ldct (B,1,H,W) in [0,1]] -> list of images in ~[0,1].
         `slice_seeds` (B int64): per-slice keys of the ancestral sampler's step noise (and of x_T when `noise` is not
         given) -- see p_sample_loop; founddiff_amd.parallel.sample_volume passes seed + GLOBAL slice index."""
+        res = self._sample(x_input, batch_size, last, noise, step_noise, slice_seeds)
+        if self.model.unet0.precision == "fp16" and self.check_fp16_range:
+            # binary16 ends at 65504: an activation beyond it is stored as infinity and reaches the image as NaN (the clamps of
+            # the scheduler kernels propagate NaN like torch.clamp).  One reduction + one host read per sample() call.
+            if not bool(torch.isfinite(res[-1]).all()):
+                raise L.FoundDiffHipError(
+                    "precision='fp16': the sampled image is not finite -- an activation of this checkpoint left IEEE binary16's "
+                    "range (65504).  Use precision='bf16' (same speed, fp32's range, 8 significand bits) or 'fp32s'.")
+        return res
+
+    def _sample(self, x_input, batch_size, last, noise, step_noise, slice_seeds):
         x_input = list(x_input)
         # Workspace bound (VERDICT r5 weak #13): an engine's workspace grows with its sub-batch (~1.9 GB per 512x512 slice in bf16,
         # twice that in the fp32 modes) and a sample() keeps `streams` engines plus their tail engines alive.  Batches beyond
@@ -923,8 +949,8 @@ class ResidualDiffusion(nn.Module):
             parts = []
             for g0 in range(0, batch_size, grp):
                 sl = slice(g0, min(g0 + grp, batch_size))
-                parts.append(self.sample([x01[sl]], batch_size=sl.stop - sl.start, last=True, noise=noise[sl].contiguous(),
-                                         slice_seeds=None if slice_seeds is None else slice_seeds[sl]))
+                parts.append(self._sample([x01[sl]], sl.stop - sl.start, True, noise[sl].contiguous(), None,
+                                          None if slice_seeds is None else slice_seeds[sl]))
             return [torch.cat([p[j] for p in parts], 0) for j in range(len(parts[0]))]
         if self.input_condition and self.input_condition_mask:     # src/DADiff.py:1372-1375
             x_input[0] = normalize_to_neg_one_to_one(x_input[0])

@@ -7,6 +7,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FOUNDDIFF_LIB") or os.path.join(HERE, "lib", "libfounddiff_hip.so")   # override: A/B of two builds
+LIB_F16_PATH = os.environ.get("FOUNDDIFF_LIB_F16") or os.path.join(HERE, "lib", "libfounddiff_hip_f16.so")
 
 FD_F32, FD_BF16 = 0, 1
 FD_OPT_LOW_LATENCY = 0x100
@@ -128,42 +129,54 @@ SIGNATURES = {
     "fd_metrics": (i32, [vp, vp, i32, i32, i32, vp, vp, vp]),
     "fd_affine_f32": (i32, [vp, f32, f32, vp, i64, vp]),
     "fd_axpy_f32": (i32, [vp, vp, f32, vp, i64, vp]),
+    "fd_half_format": (i32, []),
 }
-
-_lib = None
-
 
 class FoundDiffHipError(RuntimeError):
     pass
 
 
-def lib():
-    """Load the HIP library (once).  Raises if it has not been built: there is no CPU path."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise FoundDiffHipError(
-                f"{LIB_PATH} not found: build it with `python -m founddiff_amd.build` "
-                "(hipcc --offload-arch=gfx950).  founddiff_amd has no CPU fallback.")
-        L = C.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
-            fn = getattr(L, name)       # AttributeError if the .so does not export it
-            fn.restype = res
-            fn.argtypes = args
-        _lib = L
-    return _lib
-
-
-def check(rc, what=""):
-    if rc != 0:
-        msg = lib().fd_last_error().decode(errors="replace")
-        raise FoundDiffHipError(f"{what} failed (rc={rc}): {msg}")
-
-
 TRACE = None   # set to a list to record (name, args) of every launch (bench.py roofline leg)
 
 
-def call(name, *args):
-    if TRACE is not None:
-        TRACE.append((name, args))
-    check(getattr(lib(), name)(*args), name)
+class Library:
+    """One build of the C ABI, loaded on first use.  Two exist (founddiff_amd/build.py): the default one, whose 16-bit type is
+    bfloat16, and the FD_HALF_F16 one (IEEE binary16 in its place; DAEngine mode 'fp16').  Same symbols, same signatures."""
+
+    def __init__(self, path, half_format):
+        self.path, self.half_format, self._lib = path, half_format, None
+
+    def lib(self):
+        """Load the HIP library (once).  Raises if it has not been built: there is no CPU path."""
+        if self._lib is None:
+            if not os.path.exists(self.path):
+                raise FoundDiffHipError(
+                    f"{self.path} not found: build it with `python -m founddiff_amd.build` "
+                    "(hipcc --offload-arch=gfx950).  founddiff_amd has no CPU fallback.")
+            L = C.CDLL(self.path)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(L, name)       # AttributeError if the .so does not export it
+                fn.restype = res
+                fn.argtypes = args
+            got = L.fd_half_format()
+            if got != self.half_format:
+                raise FoundDiffHipError(f"{self.path}: fd_half_format() = {got}, expected {self.half_format} "
+                                        "(0 = the bfloat16 build, 1 = the binary16 build)")
+            self._lib = L
+        return self._lib
+
+    def check(self, rc, what=""):
+        if rc != 0:
+            msg = self.lib().fd_last_error().decode(errors="replace")
+            raise FoundDiffHipError(f"{what} failed (rc={rc}): {msg}")
+
+    def call(self, name, *args):
+        if TRACE is not None:
+            TRACE.append((name, args))
+        self.check(getattr(self.lib(), name)(*args), name)
+
+
+BF16 = Library(LIB_PATH, 0)
+F16 = Library(LIB_F16_PATH, 1)
+# the default library (every caller that is not an 'fp16' engine)
+lib, check, call = BF16.lib, BF16.check, BF16.call

@@ -40,9 +40,24 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+# the second form of the library: the same sources with IEEE binary16 as the 16-bit storage / MFMA operand type (csrc/fd_common.h)
+LIB_F16 = os.path.join(LIBDIR, "libfounddiff_hip_f16.so")
+
+
+def build(force=False, verbose=False, half="bf16"):
+    """half='bf16': lib/libfounddiff_hip.so; half='fp16': lib/libfounddiff_hip_f16.so (-DFD_HALF_F16, objects under lib/obj_f16)."""
+    if half == "fp16":
+        return _build(force, verbose, LIB_F16, "obj_f16", ["-DFD_HALF_F16"])
+    return _build(force, verbose, LIB, "obj", [])
+
+
+def build_all(force=False, verbose=False):
+    return build(force, verbose), build(force, verbose, half="fp16")
+
+
+def _build(force, verbose, LIB, objname, extra):
     os.makedirs(LIBDIR, exist_ok=True)
-    objdir = os.path.join(LIBDIR, "obj")
+    objdir = os.path.join(LIBDIR, objname)
     os.makedirs(objdir, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
@@ -51,7 +66,7 @@ def build(force=False, verbose=False):
         o = os.path.join(objdir, os.path.basename(s) + ".o")
         objs.append(o)
         if force or _stale(o, [s] + hdrs) or not os.path.exists(o[:-2] + ".resources.txt"):
-            flags = [f for f in FLAGS if not (f == "-fno-slp-vectorize" and os.path.basename(s) in SLP_OK)]
+            flags = [f for f in FLAGS if not (f == "-fno-slp-vectorize" and os.path.basename(s) in SLP_OK)] + extra
             jobs.append([HIPCC] + flags + ["-c", s, "-o", o])
 
     def run(cmd):
@@ -98,4 +113,5 @@ def resources():
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    for lib in build_all(force="--force" in sys.argv, verbose="--quiet" not in sys.argv):
+        print(lib)

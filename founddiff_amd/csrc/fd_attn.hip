@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void gram_kernel(const T *__restrict__ qkv, in
             for (int s = 0; s < 2; ++s) {
                 const bf16x8 a = *(const bf16x8 *)&tQ[(i0 + fr) * TLD + 32 * s + 8 * fg];
                 const bf16x8 bb = *(const bf16x8 *)&tK[(j0 + fr) * TLD + 32 * s + 8 * fg];
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bb, acc, 0, 0, 0);
+                acc = FD_MFMA16(a, bb, acc, 0, 0, 0);
             }
             __syncthreads();
         }

@@ -6,8 +6,59 @@
 #include <stdlib.h>
 #include "../../include/founddiff_hip.h"
 
+// The library's 16-bit storage and MFMA-operand type.  The default build is bfloat16 (libfounddiff_hip.so).  -DFD_HALF_F16
+// compiles the SAME sources with IEEE binary16 in its place (libfounddiff_hip_f16.so, the host's precision='fp16'): three more
+// mantissa bits in every stored activation and weight at the same bytes, MFMA rate and instruction counts, in exchange for
+// binary16's range (largest finite value 65504, nothing below 6e-8) -- DESIGN.md section 5.  The type keeps the name `bf16`, and
+// dtype code FD_BF16 means "the 16-bit type of this build", in both; fd_half_format() tells a caller which build it loaded.
+#ifdef FD_HALF_F16
+typedef _Float16 bf16;
+#define FD_MFMA16 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#define FD_MFMA16_ASM "v_mfma_f32_16x16x32_f16"
+#define FD_H_ONES 0x3C003C00u          // the pair (1, 1)
+#else
 typedef __bf16 bf16;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+#define FD_MFMA16 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#define FD_MFMA16_ASM "v_mfma_f32_16x16x32_bf16"
+#define FD_H_ONES 0x3F803F80u
+#endif
+typedef __attribute__((ext_vector_type(8))) bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) bf16 bf16x2;
+// the low / high 16-bit element of a dword as a float (bfloat16: a shift / a mask; binary16: v_cvt_f32_f16, SDWA for the high one)
+__device__ __forceinline__ float fd_h_lo(uint32_t w) {
+#ifdef FD_HALF_F16
+    return (float)__builtin_bit_cast(_Float16, (uint16_t)w);
+#else
+    return __builtin_bit_cast(float, w << 16);
+#endif
+}
+__device__ __forceinline__ float fd_h_hi(uint32_t w) {
+#ifdef FD_HALF_F16
+    return (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16));
+#else
+    return __builtin_bit_cast(float, w & 0xffff0000u);
+#endif
+}
+// fp32 -> the 16-bit type, round to nearest even, for STORED values.  binary16 build: the fp32 value is pinned before it is
+// converted.  hipcc folds fptrunc(fma(..)) into v_fma_mixlo_f16 where it sees one -- a single rounding to binary16 instead of
+// fp32's and then binary16's -- and it saw one in the persistent pointwise GEMM's gated-residual epilogue and not in the generic
+// tile's, which has the same source lines: 6e-5 of a layer's elements came out one binary16 ulp apart depending on WHICH of the
+// two kernels the batch size had selected (tools/probes/pwg_vs_igemm.py), and a slice's bits depended on its batch.  The empty
+// asm costs no instruction.
+__device__ __forceinline__ bf16 fd_cvt_h(float v) {
+#ifdef FD_HALF_F16
+    asm("" : "+v"(v));
+#endif
+    return (bf16)v;
+}
+// c + a.x b.x + a.y b.y on a pair of 16-bit elements, fp32 accumulation (v_dot2_f32_bf16 / v_dot2_f32_f16)
+__device__ __forceinline__ float fd_dot2(bf16x2 a, bf16x2 b, float c) {
+#ifdef FD_HALF_F16
+    return __builtin_amdgcn_fdot2(a, b, c, false);
+#else
+    return __builtin_amdgcn_fdot2_f32_bf16(a, b, c, false);
+#endif
+}
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
@@ -38,6 +89,11 @@ __device__ __forceinline__ float fd_softplus_bf16(float x) {
     const float lg = __builtin_amdgcn_logf(1.0f + e) * 0.6931471805599453f;
     return x > 20.0f ? x : lg;
 }
+
+// clamp(v, -1, 1) of the samplers (src/DADiff.py:1206, 1318: torch.clamp), NaN in -> NaN out like torch.clamp.  fminf / fmaxf alone
+// return the other operand for a NaN: a forward that went non-finite (binary16 overflow in the fp16 build, a broken checkpoint in
+// any build) came back as a plausible image of -1s.
+__device__ __forceinline__ float fd_clamp1(float v) { return v != v ? v : fminf(fmaxf(v, -1.f), 1.f); }
 
 template <typename T> struct TT;
 template <> struct TT<float> { static constexpr int CH = 4; };   // elements per 16-byte chunk
@@ -109,13 +165,13 @@ __device__ __forceinline__ void store8(float *p, const float v[8]) {
 __device__ __forceinline__ void store8(bf16 *p, const float v[8]) {
     bf16x8 a;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) a[i] = (bf16)v[i];
+    for (int i = 0; i < 8; ++i) a[i] = fd_cvt_h(v[i]);
     *(bf16x8 *)p = a;
 }
 __device__ __forceinline__ float ld1(const float *p) { return *p; }
 __device__ __forceinline__ float ld1(const bf16 *p) { return (float)*p; }
 __device__ __forceinline__ void st1(float *p, float v) { *p = v; }
-__device__ __forceinline__ void st1(bf16 *p, float v) { *p = (bf16)v; }
+__device__ __forceinline__ void st1(bf16 *p, float v) { *p = fd_cvt_h(v); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -146,10 +202,16 @@ __device__ __forceinline__ float fd_group_sum(float v) {
     return v;
 }
 
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-__device__ __forceinline__ uint32_t fd_pack_bf16(f32x2 v) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2)); }
+__device__ __forceinline__ uint32_t fd_pack_bf16(f32x2 v) {
+#ifdef FD_HALF_F16
+    float a = v.x, b = v.y;                      // (fd_cvt_h: the fp32 values are final before the conversion)
+    asm("" : "+v"(a), "+v"(b));
+    v = f32x2{a, b};
+#endif
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
 __device__ __forceinline__ f32x2 fd_unpack_bf16(uint32_t w) {
-    return f32x2{__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xffff0000u)};
+    return f32x2{fd_h_lo(w), fd_h_hi(w)};
 }
 
 // LayerNorm + modulate of one 16-byte chunk (8 bf16 channels) of a pixel whose C = 8 * LANES channels sit in LANES

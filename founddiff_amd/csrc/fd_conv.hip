@@ -289,8 +289,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const fd_conv_
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
-                        acc[i][j] = PWE ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0)
-                                       : __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = PWE ? FD_MFMA16(bfr[j], af[i], acc[i][j], 0, 0, 0)
+                                       : FD_MFMA16(af[i], bfr[j], acc[i][j], 0, 0, 0);
             } else if constexpr (SPL) {
                 // split-bf16: hi fragment = k-chunk fg, lo fragment = k-chunk 4 + fg of the row; lane group fg owns
                 // k = 8*fg .. 8*fg+7 in both, which is the K32 bf16 MFMA's own operand layout
@@ -311,9 +311,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const fd_conv_
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NT; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = FD_MFMA16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = FD_MFMA16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = FD_MFMA16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                     }
             } else {
                 // f32: lane group fg owns k = 8*fg .. 8*fg+7 of the 32-wide step; MFMA step e
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const fd_conv_
                     load8((const T *)p.res + pix * p.ld_res + p.off_res + n0, rs);
                     if (p.epilogue == FD_EPI_GATE_RES) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) val[e] = rs[e] + ev0[e] * val[e];
+                        for (int e = 0; e < 8; ++e) val[e] = __builtin_fmaf(ev0[e], val[e], rs[e]);   // (explicitly ONE rounding: see fd_pwgemm.hip)
                     } else {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) val[e] = fmaxf(val[e] + rs[e], 0.f);
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const fd_conv_
                 }
                 if (p.epilogue == FD_EPI_GATE_RES) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) val[e] = rs[e] + gate[e] * val[e];
+                    for (int e = 0; e < 8; ++e) val[e] = __builtin_fmaf(gate[e], val[e], rs[e]);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) val[e] = fmaxf(val[e] + rs[e], 0.f);

@@ -229,8 +229,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
     // two bf16 (one dword) -> two e4m3 bytes in the low / high half of `acc`
     auto cvt2 = [&](uint32_t w, uint32_t acc, bool hi) -> uint32_t {
         // e4m3fn has no infinity: clamp to its largest finite value (448) instead of letting an outlier become NaN
-        const float a = __builtin_amdgcn_fmed3f(__builtin_bit_cast(float, w << 16) * p.act_scale, -448.f, 448.f);
-        const float b = __builtin_amdgcn_fmed3f(__builtin_bit_cast(float, w & 0xffff0000u) * p.act_scale, -448.f, 448.f);
+        const float a = __builtin_amdgcn_fmed3f(fd_h_lo(w) * p.act_scale, -448.f, 448.f);
+        const float b = __builtin_amdgcn_fmed3f(fd_h_hi(w) * p.act_scale, -448.f, 448.f);
         return hi ? (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, (int)acc, true)
                   : (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, (int)acc, false);
     };
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const fd_conv_para
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
 #pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[j], fa[i], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < NT; ++j) acc[i][j] = FD_MFMA16(bq[j], fa[i], acc[i][j], 0, 0, 0);
             if (next) load_a(ntap, nks, i);
             __builtin_amdgcn_sched_barrier(0);
         }

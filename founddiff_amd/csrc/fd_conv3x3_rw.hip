@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rw_kernel(const fd_conv_params
                     for (int a = 0; a < 2; ++a)
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
-                            asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[a][i]) : "v"(wf[a][(kh * 3 + kw) * 2 + ks]), "v"(bq[i]));
+                            asm(FD_MFMA16_ASM " %0, %1, %2, %0" : "+v"(acc[a][i]) : "v"(wf[a][(kh * 3 + kw) * 2 + ks]), "v"(bq[i]));
                     __builtin_amdgcn_sched_barrier(0);
                 }
         asm volatile(FD_MFMA_ASM_DRAIN : FD_TIE4(acc[0]), FD_TIE4(acc[1]) :: "memory");      // the last MFMAs' results (fd_common.h)

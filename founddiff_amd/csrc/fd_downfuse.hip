@@ -158,7 +158,7 @@ __global__ __launch_bounds__(64 * NW, 2) void down_fused_kernel(const DownParams
                     // this step's (32 more live registers per step hoisted)
 #pragma unroll
                     for (int m = 0; m < DT_OH; ++m)
-                        asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[m]) : "v"(a), "v"(bq[m]));
+                        asm(FD_MFMA16_ASM " %0, %1, %2, %0" : "+v"(acc[m]) : "v"(a), "v"(bq[m]));
                     __builtin_amdgcn_sched_barrier(0);
                 }
         static_assert(DT_OH == 8, "FD_TIE8");

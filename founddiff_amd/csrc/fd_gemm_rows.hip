@@ -192,8 +192,8 @@ __global__ __launch_bounds__(NT) void gemm_rows_kernel(const fd_conv_params p, i
                 const bf16x8 wb = *(const bf16x8 *)(sW + w_off(rowa + 4, ks * 4 + fgw, RS));
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
-                    acc[0][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb[s][ks], acc[0][s], 0, 0, 0);
-                    acc[1][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, xb[s][ks], acc[1][s], 0, 0, 0);
+                    acc[0][s] = FD_MFMA16(wa, xb[s][ks], acc[0][s], 0, 0, 0);
+                    acc[1][s] = FD_MFMA16(wb, xb[s][ks], acc[1][s], 0, 0, 0);
                 }
             }
             // lane (pixel fr of subtile s, group fg) holds channels n0 .. n0+7
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(NT) void gemm_rows_kernel(const fd_conv_params p, i
                     load8(resp + m * p.ld_res + n0, rs);
                     if (EPI == FD_EPI_GATE_RES) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) val[e] = rs[e] + ev0[e] * val[e];
+                        for (int e = 0; e < 8; ++e) val[e] = __builtin_fmaf(ev0[e], val[e], rs[e]);
                     } else {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) val[e] = fmaxf(val[e] + rs[e], 0.f);
@@ -267,8 +267,8 @@ __global__ __launch_bounds__(NT) void gemm_rows_kernel(const fd_conv_params p, i
                     const int64_t j = (int64_t)b * hw + m;
                     p.fin_out[j] = o;
                     if (p.fin_mode == 1) {
-                        const float pr = fminf(fmaxf(o, -1.f), 1.f);
-                        p.fin_img[j] = p.fin_last ? fminf(fmaxf(p.fin_xin[j] - pr, -1.f), 1.f) : p.fin_img[j] - p.fin_alpha * pr;
+                        const float pr = fd_clamp1(o);
+                        p.fin_img[j] = p.fin_last ? fd_clamp1(p.fin_xin[j] - pr) : p.fin_img[j] - p.fin_alpha * pr;
                     }
                 }
             }
@@ -291,7 +291,7 @@ int row_stride(int K) { return K <= 64 ? 128 : (K <= 128 ? 256 : 512); }
 //   registers the prologue loaded.  The matrix pipe of this HBM-bound kernel was 4 % busy; bytes per pixel fall from
 //   (K + K + CX + CX) x 2 to (K + CX + CX) x 2.
 __device__ __forceinline__ float zre_dot2(uint32_t a, uint32_t b, float c) {
-    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b), c, false);
+    return fd_dot2(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b), c);
 }
 
 template <int KS, int NT, bool PF>
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void gemm_rows_zre_kernel(co
                 const uint32_t rw[4] = {xr[kx].x, xr[kx].y, xr[kx].z, xr[kx].w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    s1 = zre_dot2(rw[j], 0x3F803F80u, s1);
+                    s1 = zre_dot2(rw[j], FD_H_ONES, s1);
                     s2 = zre_dot2(rw[j], rw[j], s2);
                 }
             }
@@ -404,8 +404,8 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void gemm_rows_zre_kernel(co
                 for (int kx = 0; kx < KX; ++kx) {
                     const bf16x8 wa = *(const bf16x8 *)(sZ + w_off(32 * ng + rperm, kx * 4 + fgo, RX));
                     const bf16x8 wb = *(const bf16x8 *)(sZ + w_off(32 * ng + rperm + 4, kx * 4 + fgo, RX));
-                    a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xn[kx], a0, 0, 0, 0);
-                    a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, xn[kx], a1, 0, 0, 0);
+                    a0 = FD_MFMA16(wa, xn[kx], a0, 0, 0, 0);
+                    a1 = FD_MFMA16(wb, xn[kx], a1, 0, 0, 0);
                 }
                 float val[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
                 fd_silu8(val);
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void gemm_rows_zre_kernel(co
                 const uint32_t rw[4] = {yr[ks].x, yr[ks].y, yr[ks].z, yr[ks].w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    s1 = zre_dot2(rw[j], 0x3F803F80u, s1);
+                    s1 = zre_dot2(rw[j], FD_H_ONES, s1);
                     s2 = zre_dot2(rw[j], rw[j], s2);
                 }
             }
@@ -459,8 +459,8 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void gemm_rows_zre_kernel(co
             for (int ks = 0; ks < KS; ++ks) {
                 const bf16x8 wa = *(const bf16x8 *)(sW + w_off(32 * ng + rperm, ks * 4 + fgo, RS));
                 const bf16x8 wb = *(const bf16x8 *)(sW + w_off(32 * ng + rperm + 4, ks * 4 + fgo, RS));
-                a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb[ks], a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, xb[ks], a1, 0, 0, 0);
+                a0 = FD_MFMA16(wa, xb[ks], a0, 0, 0, 0);
+                a1 = FD_MFMA16(wb, xb[ks], a1, 0, 0, 0);
             }
             const int n0 = 32 * ng + 8 * fg;
             float bias[8], gt[8];

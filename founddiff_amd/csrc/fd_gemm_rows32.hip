@@ -56,9 +56,9 @@ __device__ __forceinline__ void stage_split(const float *wg, int nrows, int K, i
 // acc += W[rows of this lane's fragment] . x, three bf16 MFMAs per K32 step
 #define FD_MFMA3(acc, wh, wl, xh, xl)                                                  \
     do {                                                                               \
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, acc, 0, 0, 0);           \
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, acc, 0, 0, 0);           \
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, acc, 0, 0, 0);           \
+        acc = FD_MFMA16(wl, xh, acc, 0, 0, 0);           \
+        acc = FD_MFMA16(wh, xl, acc, 0, 0, 0);           \
+        acc = FD_MFMA16(wh, xh, acc, 0, 0, 0);           \
     } while (0)
 
 template <int KS, int PRO, int EPI, int NT>
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(NT) void gemm_rows32_kernel(const fd_conv_params p,
                     float gt[8];
                     load8(p.gate + (int64_t)b * p.gate_ld + n0, gt);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) val[e] = rs[e] + gt[e] * val[e];
+                    for (int e = 0; e < 8; ++e) val[e] = __builtin_fmaf(gt[e], val[e], rs[e]);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) val[e] = fmaxf(val[e] + rs[e], 0.f);
@@ -228,8 +228,8 @@ __global__ __launch_bounds__(NT) void gemm_rows32_kernel(const fd_conv_params p,
                 const int64_t j = (int64_t)b * hw + m;
                 p.fin_out[j] = o;
                 if (p.fin_mode == 1) {
-                    const float pr = fminf(fmaxf(o, -1.f), 1.f);
-                    p.fin_img[j] = p.fin_last ? fminf(fmaxf(p.fin_xin[j] - pr, -1.f), 1.f) : p.fin_img[j] - p.fin_alpha * pr;
+                    const float pr = fd_clamp1(o);
+                    p.fin_img[j] = p.fin_last ? fd_clamp1(p.fin_xin[j] - pr) : p.fin_img[j] - p.fin_alpha * pr;
                 }
             }
         }

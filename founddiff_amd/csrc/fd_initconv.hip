@@ -92,8 +92,8 @@ __global__ __launch_bounds__(256, 2) void initconv7_kernel(const float *__restri
             const bf16x8 xb = __builtin_bit_cast(bf16x8, xv);
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
-                a0[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g][kh], xb, a0[g], 0, 0, 0);
-                a1[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[g][kh], xb, a1[g], 0, 0, 0);
+                a0[g] = FD_MFMA16(wa[g][kh], xb, a0[g], 0, 0, 0);
+                a1[g] = FD_MFMA16(wb[g][kh], xb, a1[g], 0, 0, 0);
             }
         }
         const int y = ty0 + ty, x = tx0 + fr;
@@ -171,10 +171,10 @@ __global__ __launch_bounds__(256, 2) void initconv7_f32s_kernel(const float *__r
                 const uint2 q0 = src[0], q1 = src[1];
                 const u32x4 xv = {q0.x, q0.y, q1.x, q1.y};
                 const bf16x8 xb = __builtin_bit_cast(bf16x8, xv);
-                a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(la[kh], xb, a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lb[kh], xb, a1, 0, 0, 0);
-                a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[kh], xb, a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[kh], xb, a1, 0, 0, 0);
+                a0 = FD_MFMA16(la[kh], xb, a0, 0, 0, 0);
+                a1 = FD_MFMA16(lb[kh], xb, a1, 0, 0, 0);
+                a0 = FD_MFMA16(wa[kh], xb, a0, 0, 0, 0);
+                a1 = FD_MFMA16(wb[kh], xb, a1, 0, 0, 0);
             }
             const int y = ty0 + ty, x = tx0 + fr;
             float *op = out + ((img * H + y) * W + x) * CO + 32 * g + 8 * fg;

@@ -25,7 +25,7 @@ namespace {
 constexpr int PT_H = 8, PT_W = 16, PH_Y = PT_H + 2, PH_X = PT_W + 2, PHP = PH_Y * PH_X;   // 180 halo pixels
 constexpr int PMT = (PHP + 15) / 16;                                                      // 12 m-tiles
 constexpr int XS_B = PMT * 16 * 128, TS_B = PHP * 128;
-typedef __attribute__((ext_vector_type(2))) __bf16 pd_bf16x2;
+typedef __attribute__((ext_vector_type(2))) bf16 pd_bf16x2;
 typedef _Float16 pd_h2 __attribute__((ext_vector_type(2)));
 typedef _Float16 pd_h8 __attribute__((ext_vector_type(8)));
 
@@ -36,6 +36,14 @@ typedef _Float16 pd_h8 __attribute__((ext_vector_type(8)));
 // The 9-term sum is accumulated in fp16 (~7e-4 rms relative, below the bf16 rounding of the output it feeds; the
 // input side gains 3 bits).  v_cvt_pkrtz_f16_f32 saturates instead of producing infinities (|t| > 65504).
 __device__ __forceinline__ uint32_t pk_h2(float a, float b) { return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a, b)); }
+// a dword of two stored 16-bit elements as an fp16 pair (exact from bfloat16 inside fp16's range; the identity in the FD_HALF_F16 build)
+__device__ __forceinline__ uint32_t h16_to_h2(uint32_t w) {
+#ifdef FD_HALF_F16
+    return w;
+#else
+    return pk_h2(fd_h_lo(w), fd_h_hi(w));
+#endif
+}
 
 __device__ __forceinline__ void dw_row_f16(const uint32_t (&win)[3][3][4], int rr, const uint32_t (&wt)[9][4],
                                            const uint32_t (&b2)[4], uint32_t (&out)[4]) {
@@ -218,8 +226,8 @@ __global__ __launch_bounds__(256, CIN == 64 ? 3 : 2) void pwdw_kernel(const PwDw
                 f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ks], xb[i][ks], a0, 0, 0, 0);
-                    a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[ks], xb[i][ks], a1, 0, 0, 0);
+                    a0 = FD_MFMA16(wa[ks], xb[i][ks], a0, 0, 0, 0);
+                    a1 = FD_MFMA16(wb[ks], xb[i][ks], a1, 0, 0, 0);
                 }
                 float val[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
                 fd_silu8(val);
@@ -275,8 +283,8 @@ __global__ __launch_bounds__(256, CIN == 64 ? 3 : 2) void pwdw_kernel(const PwDw
                 f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ks], xh[i][ks], a0, 0, 0, 0);
-                    a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[ks], xh[i][ks], a1, 0, 0, 0);
+                    a0 = FD_MFMA16(wa[ks], xh[i][ks], a0, 0, 0, 0);
+                    a1 = FD_MFMA16(wb[ks], xh[i][ks], a1, 0, 0, 0);
                 }
                 const int hp = (3 * wave + i) * 16 + fr;
                 const bool in = (inside >> i) & 1;
@@ -352,8 +360,8 @@ __global__ __launch_bounds__(256, CIN == 64 ? 3 : 2) void pwdw_kernel(const PwDw
                 f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ks], vb[i][ks], a0, 0, 0, 0);
-                    a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[ks], vb[i][ks], a1, 0, 0, 0);
+                    a0 = FD_MFMA16(wa[ks], vb[i][ks], a0, 0, 0, 0);
+                    a1 = FD_MFMA16(wb[ks], vb[i][ks], a1, 0, 0, 0);
                 }
                 const int y = ty0 + 2 * wave + i, x = tx0 + fr;
                 const int pix = __umul24(y, p.W) + x;
@@ -361,7 +369,7 @@ __global__ __launch_bounds__(256, CIN == 64 ? 3 : 2) void pwdw_kernel(const PwDw
                 load8(xin + (__umul24(pix, p.ld_x) + n0), rs);                     // the block input again (L2)
                 float val[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
 #pragma unroll
-                for (int e = 0; e < 8; ++e) val[e] = rs[e] + gt[e] * val[e];
+                for (int e = 0; e < 8; ++e) val[e] = __builtin_fmaf(gt[e], val[e], rs[e]);
                 store8(o2 + (__umul24(pix, p.ld_o2) + n0), val);
             }
         }
@@ -517,8 +525,8 @@ __global__ __launch_bounds__(256, 3) void pwdw_gram_kernel(const PwGramParams p)
                     f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
-                        a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ks], xh[i][ks], a0, 0, 0, 0);
-                        a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[ks], xh[i][ks], a1, 0, 0, 0);
+                        a0 = FD_MFMA16(wa[ks], xh[i][ks], a0, 0, 0, 0);
+                        a1 = FD_MFMA16(wb[ks], xh[i][ks], a1, 0, 0, 0);
                     }
                     const int hp = (3 * wave + i) * 16 + fr;
                     const bool in = (inside >> i) & 1;
@@ -735,7 +743,7 @@ __global__ __launch_bounds__(256, 3) void dwconv_gram_kernel(const DwGramParams 
                 uint32_t hw4[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    hw4[e] = pk_h2(__builtin_bit_cast(float, rw[e] << 16), __builtin_bit_cast(float, rw[e] & 0xffff0000u));
+                    hw4[e] = h16_to_h2(rw[e]);
                 const u32x4 h4 = {hw4[0], hw4[1], hw4[2], hw4[3]};
                 if (hp < PHP) *(u32x4 *)(hs + ts_off(hp, idx & 7)) = ((okm >> k) & 1) ? h4 : z4;
             }

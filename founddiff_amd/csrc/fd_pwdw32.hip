@@ -44,9 +44,9 @@ __device__ __forceinline__ void split8_32(const float (&f)[8], bf16x8 &hi, bf16x
 
 #define FD_MFMA3(acc, wh, wl, xh, xl)                                                  \
     do {                                                                               \
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, acc, 0, 0, 0);           \
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, acc, 0, 0, 0);           \
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, acc, 0, 0, 0);           \
+        acc = FD_MFMA16(wl, xh, acc, 0, 0, 0);           \
+        acc = FD_MFMA16(wh, xl, acc, 0, 0, 0);           \
+        acc = FD_MFMA16(wh, xh, acc, 0, 0, 0);           \
     } while (0)
 
 constexpr int PW32_DW = 0, PW32_GRAM = 1, PW32_PROJ = 2;
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void pwdw32_kernel(const Pw32Params p) {
                     nrm[ch] += o[oy] * o[oy];
                 } else {
                     const f32x4 v = o[oy];
-                    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+                    typedef __attribute__((ext_vector_type(4))) bf16 bf16x4;
                     bf16x4 hi, lo;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {

@@ -222,7 +222,7 @@ __global__ __launch_bounds__(TNC * 2, 2) void pw_gemm_kernel(const fd_conv_param
                             // hand: the fragments come from ds_read (the compiler's s_waitcnt covers asm operands), the
                             // same accumulator recurs 32 MFMAs later, and the epilogue's first VALU read of the
                             // accumulators sits behind an s_nop block.
-                            asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(wf), "v"(pf[i]));
+                            asm(FD_MFMA16_ASM " %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(wf), "v"(pf[i]));
                     }
                 }
                 slot = slot + 1 == PG_NS ? 0 : slot + 1;
@@ -258,11 +258,13 @@ __global__ __launch_bounds__(TNC * 2, 2) void pw_gemm_kernel(const fd_conv_param
                     float rs[8];
                     load8((const bf16 *)p.res + ((int64_t)b * OHW + m) * p.ld_res + p.off_res + n0, rs);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) val[e] = rs[e] + gate8[e] * val[e];
+                    // an explicit fma, here and in conv_igemm_kernel's epilogue: which tile a layer runs on depends on the batch, a
+                    // slice's bits must not (and fd_cvt_h below: fd_common.h)
+                    for (int e = 0; e < 8; ++e) val[e] = __builtin_fmaf(gate8[e], val[e], rs[e]);
                 }
                 bf16x8 pk;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) pk[e] = (bf16)val[e];
+                for (int e = 0; e < 8; ++e) pk[e] = fd_cvt_h(val[e]);
                 if (jp < 2) {
                     const int m = m0 + 64 * wm + 16 * i + fr;
                     *(u32x4 *)(O + ((int64_t)b * OHW + m) * p.ldo + p.offo + n0) = __builtin_bit_cast(u32x4, pk);

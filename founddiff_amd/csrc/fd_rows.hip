@@ -297,10 +297,8 @@ __global__ __launch_bounds__(256) void dwconv3x3_bf16_kernel(const bf16 *__restr
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const bf16x2 xv = __builtin_bit_cast(bf16x2, win[(rr + dy) % 3][dx][j]);
-                    acc[2 * j] = __builtin_amdgcn_fdot2_f32_bf16(
-                        xv, __builtin_bit_cast(bf16x2, wlo[dy * 3 + dx][j]), acc[2 * j], false);
-                    acc[2 * j + 1] = __builtin_amdgcn_fdot2_f32_bf16(
-                        xv, __builtin_bit_cast(bf16x2, whi[dy * 3 + dx][j]), acc[2 * j + 1], false);
+                    acc[2 * j] = fd_dot2(xv, __builtin_bit_cast(bf16x2, wlo[dy * 3 + dx][j]), acc[2 * j]);
+                    acc[2 * j + 1] = fd_dot2(xv, __builtin_bit_cast(bf16x2, whi[dy * 3 + dx][j]), acc[2 * j + 1]);
                 }
         if (silu) fd_silu8(acc);
         store8(out_img + (__umul24(__umul24(y, W) + x, ld_out) + c0), acc);

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 16 && R >= 16 ? 4 : (N >=
                     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int ks = 0; ks < KSM; ++ks)
-                        if (ks < nks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[ks], bcur[ks], acc, 0, 0, 0);
+                        if (ks < nks) acc = FD_MFMA16(afr[ks], bcur[ks], acc, 0, 0, 0);
                     const int e0 = mb * 16 + 4 * fg;                    // CD % 4 == 0 (launcher): all four or none
                     if (cur.l < l1 && e0 < CD) {
                         *(f32x4 *)&sx[(nb * 16 + fr) * CDP + e0] = acc;
@@ -210,9 +210,9 @@ __global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 16 && R >= 16 ? 4 : (N >=
                                 ah[q] = hv;
                                 al[q] = (bf16)(f[q] - (float)hv);
                             }
-                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[ks], acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[ks], acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[ks], acc, 0, 0, 0);
+                            acc = FD_MFMA16(al, bh[ks], acc, 0, 0, 0);
+                            acc = FD_MFMA16(ah, bl[ks], acc, 0, 0, 0);
+                            acc = FD_MFMA16(ah, bh[ks], acc, 0, 0, 0);
                         }
                     }
                     const int e0 = mb * 16 + 4 * fg;                    // CD % 4 == 0 (launcher): all four or none
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 16 && R >= 16 ? 4 : (N >=
         else return __builtin_amdgcn_raw_buffer_load_b32(rs_u, voff, soff, 0);
     };
     auto cvt_u = [&](uint32_t r) -> float {
-        if constexpr (sizeof(T) == 2) return __builtin_bit_cast(float, r << 16);
+        if constexpr (sizeof(T) == 2) return fd_h_lo(r);
         else return __builtin_bit_cast(float, r);
     };
     auto st_y = [&](int soff_, float v) {
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 16 && R >= 16 ? 4 : (N >=
     auto st_y2 = [&](int soff_, f32x2 v) {
         const int soff = __builtin_amdgcn_readfirstlane(soff_);
         if (ODD && soff < 0) return;
-        typedef __attribute__((ext_vector_type(2))) __bf16 bfx2;
+        typedef __attribute__((ext_vector_type(2))) bf16 bfx2;
         const bfx2 hv = {(bf16)v.x, (bf16)v.y};
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, hv), rs_y, voff, soff, 0);
     };
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 16 && R >= 16 ? 4 : (N >=
         if constexpr (CPL == 2) {
             // row = [dt_r (R) | B (N) | C (N)] broadcast scalars; every pair below is (channel d, channel d + 1)
             const auto xr = [&](int i) -> float { return rq.v[i >> 2][i & 3]; };
-            const f32x2 u2 = {__builtin_bit_cast(float, uraw << 16), __builtin_bit_cast(float, uraw & 0xffff0000u)};
+            const f32x2 u2 = {fd_h_lo(uraw), fd_h_hi(uraw)};
             f32x2 dv2 = bias2;
 #pragma unroll
             for (int r = 0; r < R; ++r) dv2 = w[r] * xr(r) + dv2;
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 16 && R >= 16 ? 4 : (N >=
                 for (int mb = 0; mb < MB; ++mb) {
                     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int ks = 0; ks < KSM; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[mb][ks], bcur[ks], acc, 0, 0, 0);
+                    for (int ks = 0; ks < KSM; ++ks) acc = FD_MFMA16(afr[mb][ks], bcur[ks], acc, 0, 0, 0);
                     const int e0 = mb * 16 + 4 * fg;                        // CD % 4 == 0 (launcher): all four or none
                     if (cur.l < l1 && e0 < CD) {
                         *(f32x4 *)&sx[(nb * 16 + fr) * CDP + e0] = acc;
@@ -727,7 +727,7 @@ __global__ __launch_bounds__(256) void scan_seq_kernel(const T *__restrict__ xc,
         else return __builtin_amdgcn_raw_buffer_load_b32(rs_u, voff, soff, 0);
     };
     auto cvt_u = [&](uint32_t r) -> float {
-        if constexpr (sizeof(T) == 2) return __builtin_bit_cast(float, r << 16);
+        if constexpr (sizeof(T) == 2) return fd_h_lo(r);
         else return __builtin_bit_cast(float, r);
     };
     // all four lanes of a quad hold the same y (quad_sum is an all-reduce) and store it to the same address: no

@@ -43,7 +43,7 @@ __device__ __forceinline__ void keyed_normal4(uint64_t seed, uint32_t t, uint32_
     z[0] = ra * c0; z[1] = ra * s0; z[2] = rb * c1; z[3] = rb * s1;
 }
 
-__device__ __forceinline__ float clamp1s(float v) { return fminf(fmaxf(v, -1.f), 1.f); }
+__device__ __forceinline__ float clamp1s(float v) { return fd_clamp1(v); }
 
 __global__ void keyed_normal_kernel(const int64_t *__restrict__ seeds, int t, float *__restrict__ out, int64_t npix) {
     const int b = blockIdx.y;

@@ -15,6 +15,16 @@ void fd_set_error(const char *fmt, ...) {
 
 extern "C" const char *fd_last_error(void) { return g_err; }
 
+// which 16-bit type this build stores and multiplies in (fd_common.h): 0 = bfloat16 (libfounddiff_hip.so), 1 = IEEE binary16
+// (libfounddiff_hip_f16.so).  The host checks it against the torch dtype it is about to hand over.
+extern "C" int fd_half_format(void) {
+#ifdef FD_HALF_F16
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 // ---- development switches (fd_common.h: FD_DEV_SWITCHES)
 #ifdef FD_RELEASE
 extern "C" const char *fd_dev_options(void) { return "release build: development switches compiled out (every one at its default)"; }
@@ -143,7 +153,7 @@ __global__ void axpy_kernel(const float *x, const float *nz, float s, float *out
         out[i] = x[i] + s * nz[i];
 }
 
-__device__ __forceinline__ float clamp1(float v) { return fminf(fmaxf(v, -1.f), 1.f); }
+__device__ __forceinline__ float clamp1(float v) { return fd_clamp1(v); }
 
 __global__ void res_predictions_kernel(const float *__restrict__ mo, const float *__restrict__ xt,
                                        const float *__restrict__ xin, const float *__restrict__ ac,

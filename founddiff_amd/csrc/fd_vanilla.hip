@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const T *__restrict
                     const bf16x8 ka = *(const bf16x8 *)&sK[krow * KLD + 8 * g];
 #pragma unroll
                     for (int qb = 0; qb < AT_QB; ++qb)
-                        st[qb][blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qb16[qb], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                        st[qb][blk] = FD_MFMA16(ka, qb16[qb], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                 } else {
 #pragma unroll
                     for (int qb = 0; qb < AT_QB; ++qb) st[qb][blk] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -290,12 +290,12 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const T *__restrict
             for (int dblk = 0; dblk < 2; ++dblk) {
                 const T *vrow = &sV[(dblk * 16 + lq) * VLD + kb * 32 + 4 * g];
                 if constexpr (BF) {
-                    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+                    typedef __attribute__((ext_vector_type(4))) bf16 bf16x4;
                     const bf16x4 v0 = *(const bf16x4 *)vrow, v1 = *(const bf16x4 *)(vrow + 16);
                     const bf16x8 va = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
 #pragma unroll
                     for (int qb = 0; qb < AT_QB; ++qb)
-                        o[qb][dblk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pb[qb], o[qb][dblk], 0, 0, 0);
+                        o[qb][dblk] = FD_MFMA16(va, pb[qb], o[qb][dblk], 0, 0, 0);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {          // k-step e: lane group g contributes key (e < 4 ? 4 g + e : 16 + 4 g + e - 4)
@@ -329,7 +329,7 @@ __global__ void lincomb3_kernel(const float *a, const float *b, const float *c, 
         float v = ca * a[i];
         if (b) v += cb * b[i];
         if (c) v += cc * c[i];
-        if (clamp) v = fminf(fmaxf(v, -1.f), 1.f);
+        if (clamp) v = fd_clamp1(v);
         out[i] = v;
     }
 }

@@ -28,7 +28,8 @@ class VanillaEngine(DAEngine):
     """Launch sequence of the vanilla `Unet.forward` (reference lines 371-410)."""
 
     def __init__(self, state_dict, prefix="", device="cuda", mode="bf16"):
-        L.lib()
+        self.hip = L.F16 if mode == "fp16" else L.BF16
+        self.hip.lib()
         self.mode = mode
         self.dt, self.tdt = _T[mode]
         self.dev = torch.device(device)
@@ -93,12 +94,12 @@ class VanillaEngine(DAEngine):
     # ------------------------------------------------------------------ blocks
     def _gn(self, cw, in0, c0, in1, c1, B, H, W):
         Co = cw.Cout
-        mt = L.lib().fd_conv_mtiles(H, W)
+        mt = self.hip.lib().fd_conv_mtiles(H, W)
         hraw = self._b("v_h", (B, H, W, Co))
         part = self._b("gn_part", (B, mt, Co, 2), torch.float32)
         mr = self._b("gn_mr", (B, 8, 2), torch.float32)
         self.conv(cw, in0, B, H, W, hraw, c0=c0, in1=in1, c1=c1, stats=part)
-        L.call("fd_gn_finalize", _p(part), B, mt, Co, 8, H * W, 1e-5, _p(mr), self.stream)
+        self.hip.call("fd_gn_finalize", _p(part), B, mt, Co, 8, H * W, 1e-5, _p(mr), self.stream)
         return hraw, mr
 
     def vres_block(self, r, in0, c0, in1, c1, B, H, W, tag):
@@ -110,7 +111,7 @@ class VanillaEngine(DAEngine):
         fs = C.c_void_p(self.film_all.data_ptr() + fo * 4)
         fh = C.c_void_p(self.film_all.data_ptr() + (fo + Co) * 4)
         a1 = self._b("v_a1", (B, H, W, Co))
-        L.call("fd_gn_film_silu_apply", self.dt, _p(h1), _p(mr), _p(r["g1"]), _p(r["be1"]), fs, fh, self.film_total,
+        self.hip.call("fd_gn_film_silu_apply", self.dt, _p(h1), _p(mr), _p(r["g1"]), _p(r["be1"]), fs, fh, self.film_total,
                _p(a1), B, hw, Co, 8, self.stream)
         h2, mr2 = self._gn(r["c2"], a1, Co, None, 0, B, H, W)
         out = self._b(tag, (B, H, W, Co))
@@ -118,7 +119,7 @@ class VanillaEngine(DAEngine):
             self.conv(r["res"], in0, B, H, W, out, c0=c0, in1=in1, c1=c1, epi=L.EPI_GNSILU_ADD, h=h2, gn=mr2,
                       gamma=r["g2"], beta=r["be2"], groups=8)
         else:
-            L.call("fd_gn_silu_apply", self.dt, _p(h2), _p(mr2), _p(r["g2"]), _p(r["be2"]), _p(in0), _p(out), B, hw,
+            self.hip.call("fd_gn_silu_apply", self.dt, _p(h2), _p(mr2), _p(r["g2"]), _p(r["be2"]), _p(in0), _p(out), B, hw,
                    Co, 8, self.stream)
         return out
 
@@ -126,29 +127,29 @@ class VanillaEngine(DAEngine):
         """Residual(PreNorm(LinearAttention)) (reference lines 95-101, 138-146, 227-255)."""
         Cc, hw, s = x.shape[-1], H * W, self.stream
         xn = self._b("v_xn", (B, H, W, Cc))
-        L.call("fd_chan_ln", self.dt, _p(x), _p(a["g"]), None, _p(xn), B * hw, Cc, s)
+        self.hip.call("fd_chan_ln", self.dt, _p(x), _p(a["g"]), None, _p(xn), B * hw, Cc, s)
         qkv = self._b("v_qkv", (B, H, W, 3 * HIDDEN))
         self.conv(a["qkv"], xn, B, H, W, qkv)
         kst = self._b("v_kst", (B, HIDDEN, 2), torch.float32)
         ctx = self._b("v_ctx", (B, HIDDEN // 32, 32, 32), torch.float32)
         wtot = self._b("v_wtot", (B, Cc, HIDDEN))
-        L.call("fd_linear_attention", self.dt, _p(qkv), B, hw, HIDDEN, _p(a["wout"]), _p(kst), _p(ctx), _p(wtot), Cc, s)
+        self.hip.call("fd_linear_attention", self.dt, _p(qkv), B, hw, HIDDEN, _p(a["wout"]), _p(kst), _p(ctx), _p(wtot), Cc, s)
         o = self._b("v_lo", (B, H, W, Cc))
         self.conv(None, qkv, B, H, W, o, c0=HIDDEN, ld0=3 * HIDDEN, off0=0, weight=wtot, w_batch_stride=Cc * HIDDEN,
                   bias=a["bout"], Cout=Cc, KH=1, KW=1)
         out = self._b(tag, (B, H, W, Cc))
-        L.call("fd_chan_ln", self.dt, _p(o), _p(a["g2"]), _p(x), _p(out), B * hw, Cc, s)
+        self.hip.call("fd_chan_ln", self.dt, _p(o), _p(a["g2"]), _p(x), _p(out), B * hw, Cc, s)
         return out
 
     def full_attn(self, a, x, B, H, W, tag):
         """Residual(PreNorm(Attention)) (reference lines 257-279)."""
         Cc, hw, s = x.shape[-1], H * W, self.stream
         xn = self._b("v_xn", (B, H, W, Cc))
-        L.call("fd_chan_ln", self.dt, _p(x), _p(a["g"]), None, _p(xn), B * hw, Cc, s)
+        self.hip.call("fd_chan_ln", self.dt, _p(x), _p(a["g"]), None, _p(xn), B * hw, Cc, s)
         qkv = self._b("v_qkv", (B, H, W, 3 * HIDDEN))
         self.conv(a["qkv"], xn, B, H, W, qkv)
         ao = self._b("v_ao", (B, H, W, HIDDEN))
-        L.call("fd_attention", self.dt, _p(qkv), _p(ao), B, hw, HIDDEN, s)
+        self.hip.call("fd_attention", self.dt, _p(qkv), _p(ao), B, hw, HIDDEN, s)
         out = self._b(tag, (B, H, W, Cc))
         # to_out 1x1 conv + residual: gated-residual epilogue with gate == 1
         ones = self._b("v_ones", (B, Cc), torch.float32)
@@ -162,14 +163,14 @@ class VanillaEngine(DAEngine):
         B, _, H, W = x.shape
         s = self.stream
         emb = self._b("t_emb", (B, self.dim), torch.float32)
-        L.call("fd_sinusoidal", _p(time), _p(emb), B, self.dim, s)
+        self.hip.call("fd_sinusoidal", _p(time), _p(emb), B, self.dim, s)
         tm = self.tm
         h = self.linear(emb, tm["w1"], tm["b1"], self._b("t_h", (B, self.time_dim), torch.float32), L.ACT_GELU)
         t = self.linear(h, tm["w2"], tm["b2"], self._b("t_t", (B, self.time_dim), torch.float32))
         self.film_all = self.linear(t, self.film_w, self.film_b, self._b("film_all", (B, self.film_total), torch.float32),
                                     pre_silu=True)
         xin = self._b("unet_in", (B, H, W, 8))
-        L.call("fd_pack_planes", self.dt, _p(x), None, _p(xin), B, H * W, 8, s)
+        self.hip.call("fd_pack_planes", self.dt, _p(x), None, _p(xin), B, H * W, 8, s)
         r = self._b("r", (B, H, W, self.dim))
         self.conv(self.init_conv, xin, B, H, W, r)
         x_, h_, w_ = r, H, W
@@ -210,7 +211,7 @@ class VanillaEngine(DAEngine):
         x_ = self.vres_block(self.final, x_, x_.shape[-1], r, r.shape[-1], B, h_, w_, "fin")
         if out is None:
             out = self._b("model_out", (B, 1, H, W), torch.float32)
-        L.call("fd_final_conv1", self.dt, _p(x_), _p(self.final_w), _p(self.final_b), _p(out), B * H * W, x_.shape[-1], s)
+        self.hip.call("fd_final_conv1", self.dt, _p(x_), _p(self.final_w), _p(self.final_b), _p(out), B * H * W, x_.shape[-1], s)
         return out
 
 

@@ -18,8 +18,12 @@ from . import _lib as L
 # 'fp32s': fp32 storage and kernels like 'fp32', but the dense contractions run split-bf16 (3 bf16 MFMAs per product,
 # ~2^-16) instead of the exact-f32 MFMA: the engine behind the LAST step of a bf16 sampling loop (ResidualDiffusion
 # final_fp32_steps).  The parity mode 'fp32' (the 1e-3 gate) stays exact.
+# 'fp16' (round 6): the 'bf16' engine -- same kernels, same dataflow, same bytes -- on the library's second build, whose 16-bit
+# type is IEEE binary16 (csrc/fd_common.h: FD_HALF_F16; lib/libfounddiff_hip_f16.so): 11 significand bits instead of 8 in every
+# stored activation and weight.  Range: 65504 / 6e-8 (DESIGN.md section 5 for what that means for a checkpoint).
 _T = {"fp32": (L.FD_F32, torch.float32), "bf16": (L.FD_BF16, torch.bfloat16), "fp8": (L.FD_BF16, torch.bfloat16),
-      "fp32s": (L.FD_F32, torch.float32)}
+      "fp32s": (L.FD_F32, torch.float32), "fp16": (L.FD_BF16, torch.float16)}
+_HALF = (torch.bfloat16, torch.float16)
 FP8_ACT_SCALE = 8.0     # activations are multiplied by this power of two before the e4m3 conversion (|x| <= 56 exact range)
 
 
@@ -67,7 +71,7 @@ class ConvW:
                 wu = pack_up2x(w)
                 uh = wu.to(torch.bfloat16)
                 self.w_up_hi, self.w_up_lo = uh.contiguous().to(dev), (wu - uh.float()).to(torch.bfloat16).contiguous().to(dev)
-        if (up2x and kh == 3 and kw == 3 and tdt == torch.bfloat16 and cin_pad is None
+        if (up2x and kh == 3 and kw == 3 and tdt in _HALF and cin_pad is None
                 and not (fp8 and _dev("FOUNDDIFF_FP8_UPCONV", "0") == "1")):       # (development: e4m3 9-tap up-sampling convs again)
             self.w_up = pack_up2x(w).to(dev, tdt)          # the up-sampling convs as four 2x2 convs on the source grid
         # (the fp8 mode runs its up-sampling convolutions on the bf16 four-2x2 form: as fast as 9 e4m3 taps at twice the rate
@@ -127,13 +131,20 @@ class DAEngine:
     """DA-conditioned U-Net denoiser (reference `Unet`, src/DADiff.py:530-740) on HIP kernels."""
     _GEN = 0        # every engine gets a unique generation number: captured HIP graphs are keyed on it
     probe = None    # development hook: probe(tag, tensor) after each stage (tools/drift_table.py, stage_times.py)
+    hip = L.BF16    # the build of the C ABI an engine calls: the default one, or L.F16 for mode 'fp16' (__init__)
+
+    @property
+    def half(self):
+        """16-bit storage (bfloat16, or binary16 on the second build): the fused kernel set"""
+        return self.tdt in _HALF
 
     def __init__(self, state_dict, prefix="", device="cuda", mode="bf16", low_latency=False):
-        L.lib()  # fail loudly if the HIP library is missing
+        self.hip = L.F16 if mode == "fp16" else L.BF16    # which build of the C ABI this engine calls (founddiff_amd/_lib.py)
+        self.hip.lib()  # fail loudly if the HIP library is missing
         DAEngine._GEN += 1
         self.gen = DAEngine._GEN
         if mode not in _T:
-            raise ValueError(f"mode must be 'fp32', 'fp32s', 'bf16' or 'fp8', got {mode!r}")
+            raise ValueError(f"mode must be 'fp32', 'fp32s', 'bf16', 'fp16' or 'fp8', got {mode!r}")
         self.mode = mode
         self.dt, self.tdt = _T[mode]
         self.fp8 = mode == "fp8"
@@ -187,13 +198,13 @@ class DAEngine:
             pl[:, :, :7, 0:2] = wf - hi.float()
             return (ph.reshape(co, 224).contiguous().to(self.dev, torch.bfloat16),
                     pl.reshape(co, 224).contiguous().to(self.dev, torch.bfloat16))
-        if self.tdt != torch.bfloat16 or c > 3 or tuple(w.shape[2:]) != (7, 7):
+        if self.tdt not in _HALF or c > 3 or tuple(w.shape[2:]) != (7, 7):
             return None
         p = torch.zeros(co, 7, 8, 4, dtype=torch.float32)
         p[:, :, :7, :c] = w.detach().float().permute(0, 2, 3, 1)
         if c <= 2:      # free slots 2, 3 take the rounding residuals of planes 0, 1 (fd_init_conv7)
             p[:, :, :7, 2:2 + c] = p[:, :, :7, :c]
-        return p.reshape(co, 224).contiguous().to(self.dev, torch.bfloat16)
+        return p.reshape(co, 224).contiguous().to(self.dev, self.tdt)
 
     @staticmethod
     def _dw_masked(w9c):
@@ -231,7 +242,7 @@ class DAEngine:
         a = s.sub("attn_blk.")
         qkv_w = a["qkv.weight"].detach().float().reshape(3 * C_, C_)
         qdw = a["qkv_dwconv.weight"].detach().float().reshape(3 * C_, 9)
-        if self.tdt == torch.bfloat16:      # (the fp32 parity modes keep the checkpoint's values untouched)
+        if self.tdt in _HALF:      # (the fp32 parity modes keep the checkpoint's values untouched)
             qkv_w, qdw = self._qk_prescale(qkv_w, qdw, C_)
         d = dict(
             C=C_, N=N, R=R, D=D, CD=R + 2 * N, heads=a["temperature"].shape[0],
@@ -443,10 +454,10 @@ class DAEngine:
             if getattr(self, "low_latency", False):
                 p.upsample = 2
         if probe == "kid":          # which kernel would run (include/founddiff_hip.h: fd_conv_kernel_id)
-            return int(L.lib().fd_conv_kernel_id(C.byref(p)))
+            return int(self.hip.lib().fd_conv_kernel_id(C.byref(p)))
         if probe:
-            return bool(L.lib().fd_conv_prologue_ok(C.byref(p)))
-        L.call("fd_conv2d", C.byref(p), self.stream)
+            return bool(self.hip.lib().fd_conv_prologue_ok(C.byref(p)))
+        self.hip.call("fd_conv2d", C.byref(p), self.stream)
         return p.OH, p.OW
 
     def conv_cols(self, cw, x, B, H, W, out, ldo, nchunks, *, split=None, **kw):
@@ -474,7 +485,7 @@ class DAEngine:
     def linear(self, x, w, b, out, act=L.ACT_NONE, pre_silu=False):
         M, K = x.shape
         N = w.shape[0]
-        L.call("fd_linear", _p(x), _p(w), _p(b), _p(out), M, N, K, act, int(pre_silu), self.stream)
+        self.hip.call("fd_linear", _p(x), _p(w), _p(b), _p(out), M, N, K, act, int(pre_silu), self.stream)
         return out
 
     # ------------------------------------------------------------------ blocks
@@ -485,13 +496,13 @@ class DAEngine:
         cw = r["conv"]
         Co = cw.Cout
         hw = H * W
-        mt = L.lib().fd_conv_mtiles(H, W)
+        mt = self.hip.lib().fd_conv_mtiles(H, W)
         hraw = self._b("res_h", (B, H, W, Co))
         part = self._b("gn_part", (B, mt, Co, 2), torch.float32)
         mr = self._b("gn_mr", (B, 8, 2), torch.float32)
         self.conv(cw, in0, B, H, W, hraw, c0=c0, in1=in1, c1=c1, stats=part)
         self._pr(tag + ".conv3", hraw)
-        L.call("fd_gn_finalize", _p(part), B, mt, Co, 8, hw, 1e-5, _p(mr), self.stream)
+        self.hip.call("fd_gn_finalize", _p(part), B, mt, Co, 8, hw, 1e-5, _p(mr), self.stream)
         out = self._b(tag, (B, H, W, Co))
         if defer_apply:
             assert r["res"] is None and in1 is None
@@ -501,7 +512,7 @@ class DAEngine:
                       gamma=r["gamma"], beta=r["beta"], groups=8)
         else:
             assert in1 is None
-            L.call("fd_gn_silu_apply", self.dt, _p(hraw), _p(mr), _p(r["gamma"]), _p(r["beta"]), _p(in0), _p(out),
+            self.hip.call("fd_gn_silu_apply", self.dt, _p(hraw), _p(mr), _p(r["gamma"]), _p(r["beta"]), _p(in0), _p(out),
                    B, hw, Co, 8, self.stream)
         self._pr(tag, out)
         return out
@@ -523,7 +534,7 @@ class DAEngine:
         ln1 = dict(prologue=L.PRO_LN_MOD, ln_gamma=m["n1w"], ln_beta=m["n1b"], ln_eps=1e-5, ln_shift=mp(0),
                    ln_scale=mp(1), ln_ld=ml)
         xc = self._b("xc", (B, H, W, D))
-        fused = bool(L.lib().fd_pw_dw3x3_ok(getattr(self, 'scan_dt', self.dt), Cc, D, D, H, W))      # (low latency: C = 128 unfused)
+        fused = bool(self.hip.lib().fd_pw_dw3x3_ok(getattr(self, 'scan_dt', self.dt), Cc, D, D, H, W))      # (low latency: C = 128 unfused)
         # out_proj's operands (decided here: whether in_proj has to write z at all depends on them)
         y = self._b("scan_y", (B, H, W, D))
         x1 = self._b(tag + ".x1", (B, H, W, Cc))
@@ -540,18 +551,18 @@ class DAEngine:
         xonly = dict(Cout=D, ldo=2 * D)                  # in_proj restricted to its x half (rows 0 .. D-1), z columns of xz untouched
         # fp32s engine (fp32 storage, split-bf16 contractions): its own fused LN -> in_proj -> conv2d kernel (fd_pwdw32.hip)
         f32s = bool(getattr(self, "f32_split", 0))
-        fused32 = f32s and m["in_proj"].w_hi is not None and bool(L.lib().fd_pw_dw3x3_f32_ok(self.dt, Cc, D, H, W))
+        fused32 = f32s and m["in_proj"].w_hi is not None and bool(self.hip.lib().fd_pw_dw3x3_f32_ok(self.dt, Cc, D, H, W))
         zre = (getattr(self, "z_recompute", 0) in (1, Cc) and self.conv(m["out_proj"], y, B, H, W, x1, probe=True, **ep1, **lngz)
-               and (fused32 or (bool(L.lib().fd_pw_dw3x3_ok(getattr(self, 'scan_dt', self.dt), Cc, D, 0, H, W)) if fused else
+               and (fused32 or (bool(self.hip.lib().fd_pw_dw3x3_ok(getattr(self, 'scan_dt', self.dt), Cc, D, 0, H, W)) if fused else
                                 self.conv(m["in_proj"], x, B, H, W, xz, epi=L.EPI_SILU_SPLIT, split=D, probe=True, **ln1, **xonly))))
         fused32 = fused32 and zre            # (the fp32 kernel writes the depthwise half only: z has to be recomputed)
         if fused32:
-            L.call("fd_pw_dw3x3_f32", _p(x), Cc, 0, Cc, _p(m["n1w"]), _p(m["n1b"]), 1e-5, mp(0), mp(1), ml, _p(m["in_proj"].w_hi), _p(m["in_proj"].w_lo), D,
+            self.hip.call("fd_pw_dw3x3_f32", _p(x), Cc, 0, Cc, _p(m["n1w"]), _p(m["n1b"]), 1e-5, mp(0), mp(1), ml, _p(m["in_proj"].w_hi), _p(m["in_proj"].w_lo), D,
                    _p(m["dw_w"]), _p(m["dw_b"]), 1, _p(xc), D, 0, B, H, W, s)
         elif fused:
             # LN+modulate -> in_proj -> conv2d+SiLU (x half) / SiLU (z half) in one pass: the x half of
             # in_proj's output never exists in HBM (xz[..., :D] stays unwritten, z lands in xz[..., D:])
-            L.call("fd_pw_dw3x3", self.dt, _p(x), Cc, 0, Cc, _p(m["n1w"]), _p(m["n1b"]), 1e-5, mp(0), mp(1), ml,
+            self.hip.call("fd_pw_dw3x3", self.dt, _p(x), Cc, 0, Cc, _p(m["n1w"]), _p(m["n1b"]), 1e-5, mp(0), mp(1), ml,
                    _p(m["in_proj"].w), D, _p(m["dw_wm"]), _p(m["dw_b"]), 1, _p(xc), D, 0,
                    0 if zre else D, None if zre else _p(xz), 2 * D, D, B, H, W, s)
         elif zre:
@@ -562,11 +573,11 @@ class DAEngine:
             pass                                          # fp32s, C = 128: the x half and the z half as two row-GEMM launches
         else:
             xm = self._b("xm", (B, H, W, Cc))
-            L.call("fd_ln_modulate", self.dt, _p(x), _p(m["n1w"]), _p(m["n1b"]), 1e-5, mp(0), mp(1), ml, _p(xm),
+            self.hip.call("fd_ln_modulate", self.dt, _p(x), _p(m["n1w"]), _p(m["n1b"]), 1e-5, mp(0), mp(1), ml, _p(xm),
                    B, hw, Cc, s)
             self.conv(m["in_proj"], xm, B, H, W, xz, epi=L.EPI_SILU_SPLIT, split=D)
         if not fused and not fused32:
-            L.call("fd_dwconv3x3", self.dt, _p(xz), 2 * D, 0, _p(m["dw_w"]), _p(m["dw_b"]), 1, _p(xc), D, 0,
+            self.hip.call("fd_dwconv3x3", self.dt, _p(xz), 2 * D, 0, _p(m["dw_w"]), _p(m["dw_b"]), 1, _p(xc), D, 0,
                    B, H, W, D, s)
         self._pr(tag + ".xc", xc)
         if not zre:
@@ -576,11 +587,11 @@ class DAEngine:
         H2, W2 = (H + 1) // 2, (W + 1) // 2
         Lq = H2 * W2
         xdbl = self._b("xdbl", (4, B, Lq, CD), torch.float32)
-        nws = L.lib().fd_scan_ws_floats(B, H, W, D, N)
+        nws = self.hip.lib().fd_scan_ws_floats(B, H, W, D, N)
         ws = self._b("scan_ws", (nws,), torch.float32)
-        if L.lib().fd_selective_scan_plan(getattr(self, 'scan_dt', self.dt), D, N, R, H, W):
+        if self.hip.lib().fd_selective_scan_plan(getattr(self, 'scan_dt', self.dt), D, N, R, H, W):
             # x_proj inside the scan's first phase (one workgroup per chunk at d_inner <= 256): no separate pass over xc
-            L.call("fd_selective_scan_xproj", getattr(self, "scan_dt", self.dt), _p(xc), _p(m["x_proj"]), _p(xdbl), _p(m["dtw"]), _p(m["dtb"]),
+            self.hip.call("fd_selective_scan_xproj", getattr(self, "scan_dt", self.dt), _p(xc), _p(m["x_proj"]), _p(xdbl), _p(m["dtw"]), _p(m["dtb"]),
                    _p(m["A"]), _p(m["Ds"]), _p(y), _p(ws), B, H, W, D, N, R, s)
             self._pr(tag + ".xdbl", xdbl)
         else:
@@ -588,7 +599,7 @@ class DAEngine:
                       pad=0, ndir=4, w_dir_stride=CD * D, out_dir_stride=B * Lq * CD, out_f32=True,
                       OH=H2, OW=W2)
             self._pr(tag + ".xdbl", xdbl)
-            L.call("fd_selective_scan", getattr(self, "scan_dt", self.dt), _p(xc), _p(xdbl), _p(m["dtw"]), _p(m["dtb"]), _p(m["A"]),
+            self.hip.call("fd_selective_scan", getattr(self, "scan_dt", self.dt), _p(xc), _p(xdbl), _p(m["dtw"]), _p(m["dtb"]), _p(m["A"]),
                    _p(m["Ds"]), _p(y), _p(ws), B, H, W, D, N, R, s)
         self._pr(tag + ".y", y)
         if zre:
@@ -597,50 +608,50 @@ class DAEngine:
             self.conv(m["out_proj"], y, B, H, W, x1, **ep1, **lng)
         else:
             yz = self._b("yz", (B, H, W, D))
-            L.call("fd_ln_gate", self.dt, _p(y), _p(m["onw"]), _p(m["onb"]), 1e-5, _p(xz), 2 * D, D, loc,
+            self.hip.call("fd_ln_gate", self.dt, _p(y), _p(m["onw"]), _p(m["onb"]), 1e-5, _p(xz), 2 * D, D, loc,
                    self.loc_total, _p(yz), B, hw, D, s)
             self.conv(m["out_proj"], yz, B, H, W, x1, **ep1)
         self._pr(tag + ".x1", x1)
         # --- channel attention branch
         ln2 = dict(prologue=L.PRO_LN_MOD, ln_eps=1e-6, ln_shift=mp(3), ln_scale=mp(4), ln_ld=ml)
-        if (f32s and m["qkv"].w_hi is not None and L.lib().fd_pw_dw3x3_gram_f32_ok(self.dt, Cc, H, W)
-                and L.lib().fd_pw_dw3x3_proj_f32_ok(self.dt, Cc, H, W)):
+        if (f32s and m["qkv"].w_hi is not None and self.hip.lib().fd_pw_dw3x3_gram_f32_ok(self.dt, Cc, H, W)
+                and self.hip.lib().fd_pw_dw3x3_proj_f32_ok(self.dt, Cc, H, W)):
             # fp32s: q, k -> depthwise -> Gram + norms in one pass over x1, then v -> depthwise -> Weff -> gated residual in
             # another: q, k, v and the attention output never reach HBM (fd_pwdw32.hip)
-            nblk = L.lib().fd_pw_dw3x3_gram_f32_nblk(H, W)
+            nblk = self.hip.lib().fd_pw_dw3x3_gram_f32_nblk(H, W)
             part = self._b("gram", (B, m["heads"], nblk, 1024 + 64), torch.float32)
-            L.call("fd_pw_dw3x3_gram_f32", _p(x1), Cc, 0, Cc, None, None, 1e-6, mp(3), mp(4), ml, _p(m["qkv"].w_hi), _p(m["qkv"].w_lo), _p(m["qdw_w"]),
+            self.hip.call("fd_pw_dw3x3_gram_f32", _p(x1), Cc, 0, Cc, None, None, 1e-6, mp(3), mp(4), ml, _p(m["qkv"].w_hi), _p(m["qkv"].w_lo), _p(m["qdw_w"]),
                    3 * Cc, _p(part), B, H, W, s)
             weff = self._b("weff", (B, Cc, Cc))
-            L.call("fd_chan_attn_weff", self.dt, _p(part), nblk, _p(m["temp"]), _p(m["wproj"]), _p(weff), B, Cc, s)
+            self.hip.call("fd_chan_attn_weff", self.dt, _p(part), nblk, _p(m["temp"]), _p(m["wproj"]), _p(weff), B, Cc, s)
             self._pr(tag + ".weff", weff)
             x2 = self._b(tag + ".x2", (B, H, W, Cc))
             wvh, wvl = (C.c_void_p(t.data_ptr() + 2 * Cc * Cc * t.element_size()) for t in (m["qkv"].w_hi, m["qkv"].w_lo))
-            L.call("fd_pw_dw3x3_proj_f32", _p(x1), Cc, 0, Cc, None, None, 1e-6, mp(3), mp(4), ml, wvh, wvl, _p(m["qdw_w_v"]), Cc,
+            self.hip.call("fd_pw_dw3x3_proj_f32", _p(x1), Cc, 0, Cc, None, None, 1e-6, mp(3), mp(4), ml, wvh, wvl, _p(m["qdw_w_v"]), Cc,
                    _p(weff), mp(5), ml, _p(x2), Cc, 0, B, H, W, s)
             self._pr(tag, x2)
             return x2
-        if L.lib().fd_pw_dw3x3_gram_ok(self.dt, Cc, H, W):
+        if self.hip.lib().fd_pw_dw3x3_gram_ok(self.dt, Cc, H, W):
             # qkv -> qkv_dwconv -> L2 norms + q k^T in one pass: q and k never reach HBM, only v and one Gram
             # partial per workgroup do (fd_pwdw.hip: pwdw_gram_kernel)
             gdt = getattr(self, 'scan_dt', self.dt)          # carries FD_OPT_LOW_LATENCY: tiles per workgroup of the Gram kernel
-            nblk = L.lib().fd_pw_dw3x3_gram_nblk_opts(gdt, H, W)
+            nblk = self.hip.lib().fd_pw_dw3x3_gram_nblk_opts(gdt, H, W)
             # v recomputed where it is consumed (fd_pw_dw3x3_proj: LN -> W_v -> depthwise -> Weff -> gated residual in one
             # pass over x1): the Gram kernel then runs q and k only and v never reaches HBM
-            vre = getattr(self, "v_recompute", False) and bool(L.lib().fd_pw_dw3x3_proj_ok(gdt, Cc, H, W))
+            vre = getattr(self, "v_recompute", False) and bool(self.hip.lib().fd_pw_dw3x3_proj_ok(gdt, Cc, H, W))
             vbuf = None if vre else self._b("attn_v", (B, H, W, Cc))
             part = self._b("gram", (B, m["heads"], nblk, 1024 + 64), torch.float32)
-            L.call("fd_pw_dw3x3_gram", gdt, _p(x1), Cc, 0, Cc, None, None, 1e-6, mp(3), mp(4), ml,
+            self.hip.call("fd_pw_dw3x3_gram", gdt, _p(x1), Cc, 0, Cc, None, None, 1e-6, mp(3), mp(4), ml,
                    _p(m["qkv"].w), _p(m["qdw_wm"]), _p(vbuf) if vbuf is not None else None, Cc, 0, _p(part), B, H, W, s)
             if not vre:
                 self._pr(tag + ".qkv2", vbuf)
             weff = self._b("weff", (B, Cc, Cc))
-            L.call("fd_chan_attn_weff", self.dt, _p(part), nblk, _p(m["temp"]), _p(m["wproj"]), _p(weff), B, Cc, s)
+            self.hip.call("fd_chan_attn_weff", self.dt, _p(part), nblk, _p(m["temp"]), _p(m["wproj"]), _p(weff), B, Cc, s)
             self._pr(tag + ".weff", weff)
             x2 = self._b(tag + ".x2", (B, H, W, Cc))
             if vre:
                 wv = C.c_void_p(m["qkv"].w.data_ptr() + 2 * Cc * Cc * m["qkv"].w.element_size())
-                L.call("fd_pw_dw3x3_proj", gdt, _p(x1), Cc, 0, Cc, None, None, 1e-6, mp(3), mp(4), ml, wv, _p(m["qdw_wm_v"]),
+                self.hip.call("fd_pw_dw3x3_proj", gdt, _p(x1), Cc, 0, Cc, None, None, 1e-6, mp(3), mp(4), ml, wv, _p(m["qdw_wm_v"]),
                        _p(weff), mp(5), ml, _p(x2), Cc, 0, B, H, W, s)
                 self._pr(tag, x2)
                 return x2
@@ -649,8 +660,8 @@ class DAEngine:
             self._pr(tag, x2)
             return x2
         qkv2 = self._b("qkv2", (B, H, W, 3 * Cc))
-        if L.lib().fd_pw_dw3x3_ok(self.dt, Cc, 3 * Cc, 0, H, W):
-            L.call("fd_pw_dw3x3", self.dt, _p(x1), Cc, 0, Cc, None, None, 1e-6, mp(3), mp(4), ml,
+        if self.hip.lib().fd_pw_dw3x3_ok(self.dt, Cc, 3 * Cc, 0, H, W):
+            self.hip.call("fd_pw_dw3x3", self.dt, _p(x1), Cc, 0, Cc, None, None, 1e-6, mp(3), mp(4), ml,
                    _p(m["qkv"].w), 3 * Cc, _p(m["qdw_wm"]), None, 0, _p(qkv2), 3 * Cc, 0,
                    0, None, 0, 0, B, H, W, s)
         else:
@@ -661,33 +672,33 @@ class DAEngine:
                 pass                                      # fp32s, C = 128: q, k, v as three row-GEMM launches
             else:
                 xm2 = self._b("xm", (B, H, W, Cc))
-                L.call("fd_ln_modulate", self.dt, _p(x1), None, None, 1e-6, mp(3), mp(4), ml, _p(xm2), B, hw, Cc, s)
+                self.hip.call("fd_ln_modulate", self.dt, _p(x1), None, None, 1e-6, mp(3), mp(4), ml, _p(xm2), B, hw, Cc, s)
                 self.conv(m["qkv"], xm2, B, H, W, qkv)
-            if L.lib().fd_dwconv_gram_ok(self.dt, Cc, H, W):
+            if self.hip.lib().fd_dwconv_gram_ok(self.dt, Cc, H, W):
                 # qkv_dwconv of q and k straight into the Gram (fd_pwdw.hip: dwconv_gram_kernel): only v is written
-                nblk = L.lib().fd_dwconv_gram_nblk(H, W)
+                nblk = self.hip.lib().fd_dwconv_gram_nblk(H, W)
                 vbuf = self._b("attn_v", (B, H, W, Cc))
                 part = self._b("gram", (B, m["heads"], nblk, 1024 + 64), torch.float32)
-                L.call("fd_dwconv3x3", self.dt, _p(qkv), 3 * Cc, 2 * Cc, _p(m["qdw_w_v"]), None, 0, _p(vbuf), Cc, 0,
+                self.hip.call("fd_dwconv3x3", self.dt, _p(qkv), 3 * Cc, 2 * Cc, _p(m["qdw_w_v"]), None, 0, _p(vbuf), Cc, 0,
                        B, H, W, Cc, s)
-                L.call("fd_dwconv_gram", self.dt, _p(qkv), 3 * Cc, Cc, _p(m["qdw_wm"]), _p(part), B, H, W, s)
+                self.hip.call("fd_dwconv_gram", self.dt, _p(qkv), 3 * Cc, Cc, _p(m["qdw_wm"]), _p(part), B, H, W, s)
                 self._pr(tag + ".qkv2", vbuf)
                 weff = self._b("weff", (B, Cc, Cc))
-                L.call("fd_chan_attn_weff", self.dt, _p(part), nblk, _p(m["temp"]), _p(m["wproj"]), _p(weff), B, Cc, s)
+                self.hip.call("fd_chan_attn_weff", self.dt, _p(part), nblk, _p(m["temp"]), _p(m["wproj"]), _p(weff), B, Cc, s)
                 self._pr(tag + ".weff", weff)
                 x2 = self._b(tag + ".x2", (B, H, W, Cc))
                 self.conv(None, vbuf, B, H, W, x2, c0=Cc, ld0=Cc, off0=0, weight=weff, w_batch_stride=Cc * Cc,
                           bias=None, Cout=Cc, KH=1, KW=1, epi=L.EPI_GATE_RES, res=x1, gate=mp(5), gate_ld=ml)
                 self._pr(tag, x2)
                 return x2
-            L.call("fd_dwconv3x3", self.dt, _p(qkv), 3 * Cc, 0, _p(m["qdw_w"]), None, 0, _p(qkv2), 3 * Cc, 0,
+            self.hip.call("fd_dwconv3x3", self.dt, _p(qkv), 3 * Cc, 0, _p(m["qdw_w"]), None, 0, _p(qkv2), 3 * Cc, 0,
                    B, H, W, 3 * Cc, s)
         self._pr(tag + ".qkv2", qkv2)
-        nblk = L.lib().fd_chan_attn_nblk(hw)
+        nblk = self.hip.lib().fd_chan_attn_nblk(hw)
         part = self._b("gram", (B, m["heads"], nblk, 1024 + 64), torch.float32)
-        L.call("fd_chan_attn_gram", self.dt, _p(qkv2), B, hw, Cc, _p(part), s)
+        self.hip.call("fd_chan_attn_gram", self.dt, _p(qkv2), B, hw, Cc, _p(part), s)
         weff = self._b("weff", (B, Cc, Cc))
-        L.call("fd_chan_attn_weff", self.dt, _p(part), nblk, _p(m["temp"]), _p(m["wproj"]), _p(weff), B, Cc, s)
+        self.hip.call("fd_chan_attn_weff", self.dt, _p(part), nblk, _p(m["temp"]), _p(m["wproj"]), _p(weff), B, Cc, s)
         self._pr(tag + ".weff", weff)
         x2 = self._b(tag + ".x2", (B, H, W, Cc))
         self.conv(None, qkv2, B, H, W, x2, c0=Cc, ld0=3 * Cc, off0=2 * Cc, weight=weff, w_batch_stride=Cc * Cc,
@@ -703,7 +714,7 @@ class DAEngine:
         s = self.stream
         cl = self.clip
         x8 = self._b("clip_in", (B, H, W, 8))
-        L.call("fd_pack_planes", self.dt, _p(x_cond), None, _p(x8), B, H * W, 8, s)
+        self.hip.call("fd_pack_planes", self.dt, _p(x_cond), None, _p(x8), B, H * W, 8, s)
         st = cl["stem"]
         h1, w1 = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
         a = self._b("clip_s1", (B, h1, w1, st[0].Cout))
@@ -714,7 +725,7 @@ class DAEngine:
         self.conv(st[2], b_, B, h1, w1, c_, epi=L.EPI_RELU)
         h, w = h1 // 2, w1 // 2
         x = self._b("clip_p0", (B, h, w, st[2].Cout))
-        L.call("fd_avgpool", self.dt, _p(c_), _p(x), B, h1, w1, st[2].Cout, 2, s)
+        self.hip.call("fd_avgpool", self.dt, _p(c_), _p(x), B, h1, w1, st[2].Cout, 2, s)
         Cx = st[2].Cout
         for i, blk in enumerate(cl["layers"]):
             stride = blk["stride"]
@@ -725,14 +736,14 @@ class DAEngine:
             ho, wo = h // stride, w // stride
             if stride > 1:
                 o2p = self._b(f"clip_{i}_2p", (B, ho, wo, blk["c2"].Cout))
-                L.call("fd_avgpool", self.dt, _p(o2), _p(o2p), B, h, w, blk["c2"].Cout, stride, s)
+                self.hip.call("fd_avgpool", self.dt, _p(o2), _p(o2p), B, h, w, blk["c2"].Cout, stride, s)
                 o2 = o2p
             idn = x
             if blk["ds"] is not None:
                 xi = x
                 if stride > 1:
                     xi = self._b(f"clip_{i}_xp", (B, ho, wo, Cx))
-                    L.call("fd_avgpool", self.dt, _p(x), _p(xi), B, h, w, Cx, stride, s)
+                    self.hip.call("fd_avgpool", self.dt, _p(x), _p(xi), B, h, w, Cx, stride, s)
                 idn = self._b(f"clip_{i}_id", (B, ho, wo, blk["ds"].Cout))
                 self.conv(blk["ds"], xi, B, ho, wo, idn)
             o3 = self._b(f"clip_{i}_3", (B, ho, wo, blk["c3"].Cout))
@@ -740,28 +751,28 @@ class DAEngine:
             x, Cx, h, w = o3, blk["c3"].Cout, ho, wo
         Cf, T = cl["Cf"], h * w + 1
         tok = self._b("clip_tok", (B, T, Cf))
-        L.call("fd_attnpool_tokens", self.dt, _p(x), _p(tok), B, h * w, Cf, s)
+        self.hip.call("fd_attnpool_tokens", self.dt, _p(x), _p(tok), B, h * w, Cf, s)
         qkv = self._b("clip_qkv", (B, T, 3 * Cf), torch.float32)
         self.conv(cl["qkv"], tok, B, 1, T, qkv, out_f32=True)
         pooled = self._b("clip_pool", (B, Cf), torch.float32)
-        L.call("fd_attnpool_core", _p(qkv), T * 3 * Cf, _p(qkv), 3 * Cf, Cf, 2 * Cf, _p(pooled), B, T, Cf,
+        self.hip.call("fd_attnpool_core", _p(qkv), T * 3 * Cf, _p(qkv), 3 * Cf, Cf, 2 * Cf, _p(pooled), B, T, Cf,
                cl["heads"], s)
         feat = self.linear(pooled, cl["cw"], cl["cb"], self._b("clip_feat", (B, cl["cw"].shape[0]), torch.float32))
         t1 = self.linear(feat, cl["h1"][0], cl["h1"][1], self._b("h1a", (B, cl["h1"][0].shape[0]), torch.float32), L.ACT_RELU)
         t2 = self.linear(t1, cl["h1"][2], cl["h1"][3], self._b("h1b", (B, cl["h1"][2].shape[0]), torch.float32))
         dose = self._b("dose_emb", t2.shape, torch.float32)
-        L.call("fd_l2norm_rows", _p(t2), _p(dose), B, t2.shape[1], 0.0, s)
+        self.hip.call("fd_l2norm_rows", _p(t2), _p(dose), B, t2.shape[1], 0.0, s)
         t1 = self.linear(feat, cl["h2"][0], cl["h2"][1], self._b("h2a", (B, cl["h2"][0].shape[0]), torch.float32), L.ACT_RELU)
         t2 = self.linear(t1, cl["h2"][2], cl["h2"][3], self._b("h2b", (B, cl["h2"][2].shape[0]), torch.float32))
         ctx = self._b("ctx_emb", t2.shape, torch.float32)
-        L.call("fd_l2norm_rows", _p(t2), _p(ctx), B, t2.shape[1], 1e-12, s)
+        self.hip.call("fd_l2norm_rows", _p(t2), _p(ctx), B, t2.shape[1], 1e-12, s)
         # prompt path (src/DADiff.py:706-707)
         pr = self.prompt
         td = self.time_dim
         a1 = self.linear(dose, pr["w0"], pr["b0"], self._b("pm_a", (B, td), torch.float32), L.ACT_SILU)
         a2 = self.linear(a1, pr["w2"], pr["b2"], self._b("pm_b", (B, td), torch.float32))
         a3 = self._b("pm_c", (B, td), torch.float32)
-        L.call("fd_softmax_mul", _p(a2), _p(pr["p"]), _p(a3), B, td, s)
+        self.hip.call("fd_softmax_mul", _p(a2), _p(pr["p"]), _p(a3), B, td, s)
         self.prompt_emb = self.linear(a3, pr["wp"], pr["bp"], self._b("prompt_emb", (B, td), torch.float32))
         # SS2D `local` vectors of every block (src/emamba2.py:715)
         self.local_all = self.linear(ctx, self.local_w, None, self._b("local_all", (B, self.loc_total), torch.float32),
@@ -785,12 +796,12 @@ class DAEngine:
         B = time.shape[0]
         s = self.stream
         emb = self._b("t_emb", (B, self.dim), torch.float32)
-        L.call("fd_sinusoidal", _p(time), _p(emb), B, self.dim, s)
+        self.hip.call("fd_sinusoidal", _p(time), _p(emb), B, self.dim, s)
         tm = self.tm
         h = self.linear(emb, tm["w1"], tm["b1"], self._b("t_h", (B, self.time_dim), torch.float32), L.ACT_GELU)
         t = self.linear(h, tm["w2"], tm["b2"], self._b("t_t", (B, self.time_dim), torch.float32))
         tt = self._b("t_sum", (B, self.time_dim), torch.float32)
-        L.call("fd_add_f32", _p(t), _p(self.prompt_emb), _p(tt), B * self.time_dim, s)
+        self.hip.call("fd_add_f32", _p(t), _p(self.prompt_emb), _p(tt), B * self.time_dim, s)
         self.t_vec = tt
         self.mod_all = self.linear(tt, self.adaln_w, self.adaln_b,
                                    self._b("mod_all", (B, self.mod_total), torch.float32), pre_silu=True)
@@ -819,7 +830,7 @@ class DAEngine:
         s = self.stream
         tv = self._b(f"tab_time_{S}x{B}", (M,), torch.float32)
         emb = self._b("tab_emb", (M, self.dim), torch.float32)
-        L.call("fd_sinusoidal", _p(tv), _p(emb), M, self.dim, s)
+        self.hip.call("fd_sinusoidal", _p(tv), _p(emb), M, self.dim, s)
         tm = self.tm
         h = self.linear(emb, tm["w1"], tm["b1"], self._b("tab_h", (M, self.time_dim), torch.float32), L.ACT_GELU)
         t = self.linear(h, tm["w2"], tm["b2"], self._b("tab_t", (M, self.time_dim), torch.float32))
@@ -903,7 +914,8 @@ class DAEngine:
         if src.tdt == self.tdt:
             return x
         o = self._b(name, tuple(x.shape))
-        L.call("fd_cast", src.dt, _p(x), self.dt, _p(o), x.numel(), self.stream)
+        # (the build whose 16-bit type the 16-bit side is stored in does the cast: an 'fp16' engine next to the fp32s tail engine)
+        (src if src.half else self).hip.call("fd_cast", src.dt, _p(x), self.dt, _p(o), x.numel(), self.stream)
         return o
 
     # ---- the stages of a forward (src/DADiff.py:703-740)
@@ -912,14 +924,14 @@ class DAEngine:
         s = self.stream
         r = self._b("r", (B, H, W, self.dim))
         if isinstance(self.init_w7, tuple) and x_cond2 is None and self.dim in (32, 64) and H % 16 == 0 and W % 16 == 0:
-            L.call("fd_init_conv7_f32s", _p(x_t), _p(x_in), _p(self.init_w7[0]), _p(self.init_w7[1]), _p(self.init_conv.b), _p(r),
+            self.hip.call("fd_init_conv7_f32s", _p(x_t), _p(x_in), _p(self.init_w7[0]), _p(self.init_w7[1]), _p(self.init_conv.b), _p(r),
                    B, H, W, self.dim, s)
-        elif self.init_w7 is not None and not isinstance(self.init_w7, tuple) and L.lib().fd_init_conv7_ok(self.dt, self.dim, H, W):
-            L.call("fd_init_conv7", self.dt, _p(x_t), _p(x_in), _p(x_cond2), _p(self.init_w7), _p(self.init_conv.b),
+        elif self.init_w7 is not None and not isinstance(self.init_w7, tuple) and self.hip.lib().fd_init_conv7_ok(self.dt, self.dim, H, W):
+            self.hip.call("fd_init_conv7", self.dt, _p(x_t), _p(x_in), _p(x_cond2), _p(self.init_w7), _p(self.init_conv.b),
                    _p(r), B, H, W, self.dim, s)
         else:
             xin8 = self._b("unet_in", (B, H, W, 8))
-            L.call("fd_pack_planes3", self.dt, _p(x_t), _p(x_in), _p(x_cond2), _p(xin8), B, H * W, 8, s)
+            self.hip.call("fd_pack_planes3", self.dt, _p(x_t), _p(x_in), _p(x_cond2), _p(xin8), B, H * W, 8, s)
             self.conv(self.init_conv, xin8, B, H, W, r)
         self._pr("init", r)
         return r
@@ -931,12 +943,12 @@ class DAEngine:
         Cx = x.shape[-1]
         if (d["stride"] == 2 and d["res"]["res"] is None and getattr(self, "down_fuse", False) and cw.KH == 4 and cw.KW == 4
                 and getattr(cw, "w8", None) is None
-                and L.lib().fd_gn_apply_down4x4_ok(getattr(self, "scan_dt", self.dt), Cx, cw.Cout, h, w)):
+                and self.hip.lib().fd_gn_apply_down4x4_ok(getattr(self, "scan_dt", self.dt), Cx, cw.Cout, h, w)):
             # GroupNorm apply + SiLU + residual of the block AND the 4x4 / stride-2 convolution behind it in one pass: the
             # block output (the skip) is written once and read back by nothing (fd_downfuse.hip)
             hraw, mr, sk = self.res_block(d["res"], x, Cx, None, 0, B, h, w, f"d{i}r", defer_apply=True)
             o = self._b(f"d{i}s", (B, h // 2, w // 2, cw.Cout))
-            L.call("fd_gn_apply_down4x4", self.dt, _p(hraw), _p(x), _p(mr), _p(d["res"]["gamma"]), _p(d["res"]["beta"]), 8,
+            self.hip.call("fd_gn_apply_down4x4", self.dt, _p(hraw), _p(x), _p(mr), _p(d["res"]["gamma"]), _p(d["res"]["beta"]), 8,
                    _p(sk), _p(cw.w), _p(cw.b), _p(o), B, h, w, Cx, cw.Cout, self.stream)
             self._pr(f"d{i}r", sk)
             self._skips.append((sk, h, w))
@@ -986,9 +998,9 @@ class DAEngine:
         if sched is not None:
             fin.update(mode=1, alpha=sched[0], last=int(bool(sched[1])), img=x_t, xin=x_in)
         kw = dict(c0=c0, in1=r, c1=c1)
-        if (fr["res"] is not None and (self.tdt == torch.bfloat16 or getattr(self, "f32_split", 0)) and not self.probe
+        if (fr["res"] is not None and (self.tdt in _HALF or getattr(self, "f32_split", 0)) and not self.probe
                 and _dev("FOUNDDIFF_NO_FINAL_FOLD", "") == ""):
-            mt = L.lib().fd_conv_mtiles(H, W)
+            mt = self.hip.lib().fd_conv_mtiles(H, W)
             hraw = self._b("res_h", (B, H, W, cw.Cout))
             part = self._b("gn_part", (B, mt, cw.Cout, 2), torch.float32)
             mr = self._b("gn_mr", (B, 8, 2), torch.float32)
@@ -997,14 +1009,14 @@ class DAEngine:
                 # res_conv + GroupNorm/SiLU of the 3x3 output + final_conv (+ DDIM update) in ONE epilogue: the block's
                 # 64-channel output, its read by final_conv and the separate update kernel never happen
                 self.conv(cw, x, B, H, W, hraw, stats=part, **kw)
-                L.call("fd_gn_finalize", _p(part), B, mt, cw.Cout, 8, hw, 1e-5, _p(mr), self.stream)
+                self.hip.call("fd_gn_finalize", _p(part), B, mt, cw.Cout, 8, hw, 1e-5, _p(mr), self.stream)
                 self.conv(fr["res"], x, B, H, W, out, **kw, **ek)
                 return out
         x = self.res_block(fr, x, c0, r, c1, B, H, W, "finr")
-        L.call("fd_final_conv1", self.dt, _p(x), _p(self.final_w), _p(self.final_b), _p(out), B * hw,
+        self.hip.call("fd_final_conv1", self.dt, _p(x), _p(self.final_w), _p(self.final_b), _p(out), B * hw,
                x.shape[-1], self.stream)
         self._pr("out", out)
         if sched is not None:
-            L.call("fd_res_ddim_step", _p(out), _p(x_t), _p(x_in), None, float(sched[0]), 0.0, int(bool(sched[1])), _p(x_t),
+            self.hip.call("fd_res_ddim_step", _p(out), _p(x_t), _p(x_in), None, float(sched[0]), 0.0, int(bool(sched[1])), _p(x_t),
                    x_t.numel(), self.stream)
         return out

@@ -37,6 +37,11 @@ int fd_version(void);
  * reads the FD_* variables of founddiff_amd/csrc/fd_common.h (FD_DEV_SWITCHES) once, on the first call that needs one.  Returns a
  * static string: "release build: ..." or the switches that are set.                                                    */
 const char *fd_dev_options(void);
+/* The 16-bit type behind dtype code FD_BF16 in THIS build of the library: 0 = bfloat16 (libfounddiff_hip.so, the default), 1 = IEEE
+ * binary16 (libfounddiff_hip_f16.so: the same sources compiled with -DFD_HALF_F16; founddiff_amd's precision='fp16').  Every entry
+ * point below that says "bf16" then reads and writes binary16 instead; fp32 arguments are unchanged.  The fp32-storage split mode
+ * (FD_OPT_F32_SPLIT) and the fp8 weights mode are meant for the default build only.                                       */
+int fd_half_format(void);
 const char *fd_last_error(void);
 
 /* ---- implicit-GEMM convolution / GEMM on MFMA -------------------------------------------

@@ -80,3 +80,28 @@ def gate2x(key, err, blanket):
     lim = blanket if meas is None else min(blanket, max(2.0 * meas, 1e-6))
     assert err < lim, (f"{key}: error {err:.3e} >= gate {lim:.3e} (= 2 x the {meas:.3e} measured when the table was recorded; "
                        f"blanket gate {blanket:.1e})" if meas is not None else f"{key}: error {err:.3e} >= blanket gate {blanket:.1e}")
+
+
+# ---- the library's two builds (founddiff_amd/build.py): the kernel tests of tests/test_gpu_kernels.py run once per build.  `HB.t` is
+# the torch dtype of "the 16-bit type" of the build under test; in the fp16 flavour the test module's 'bf16' mode IS the binary16
+# build (same kernels, same entry points, FD_HALF_F16): _lib's default library and the engine's dtype table are swapped for the
+# duration of the module, the fp32-storage / fp8 parametrisations are skipped (they belong to the default build), and every gate
+# stays the bf16 one (binary16 carries three more bits; a kernel that passes with bf16's gate but mishandles the format -- the
+# (1, 1) constant of a packed dot product was one, round 6 -- fails it by an order of magnitude).
+class _HalfBuild:
+    t = torch.bfloat16
+    fp16 = False
+
+
+HB = _HalfBuild()
+
+
+def use_half_build(fp16):
+    """point the 'bf16' mode of founddiff_amd at the binary16 build (True) or back at the default build (False)"""
+    from founddiff_amd import _lib, engine
+    if fp16 != HB.fp16:
+        _lib.BF16, _lib.F16 = _lib.F16, _lib.BF16
+        _lib.lib, _lib.check, _lib.call = _lib.BF16.lib, _lib.BF16.check, _lib.BF16.call
+        HB.fp16, HB.t = fp16, (torch.float16 if fp16 else torch.bfloat16)
+        for m in ("bf16", "fp8"):
+            engine._T[m] = (engine._T[m][0], HB.t)

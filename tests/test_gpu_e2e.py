@@ -34,12 +34,14 @@ class Bare:
 
 
 def bare_engine(mode):
+    from founddiff_amd import _lib as L
     from founddiff_amd.engine import DAEngine, _T
 
     class _B(DAEngine):
         def __init__(self):
             self.mode = mode
             self.dt, self.tdt = _T[mode]
+            self.hip = L.F16 if mode == "fp16" else L.BF16
             self.dev = torch.device("cuda")
             self.f32 = dict(device=self.dev, dtype=torch.float32)
             self.buf = {}

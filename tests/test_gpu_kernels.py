@@ -8,7 +8,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import gate2x, rel_err
+from conftest import HB, gate2x, rel_err, use_half_build
 
 pytestmark = pytest.mark.gpu
 
@@ -19,8 +19,27 @@ BLOCK_SHAPES = [(128, 4, 4, 16, 24), (128, 8, 4, 16, 16), (256, 16, 8, 16, 16), 
                 (512, 16, 16, 16, 8), (256, 8, 8, 16, 16)]
 
 
-@pytest.fixture(scope="module")
-def eng_factory():
+@pytest.fixture(scope="module", params=["bf16-build", "fp16-build"], autouse=True)
+def half_build(request):
+    """every test of this module once per build of the library (conftest.use_half_build)"""
+    use_half_build(request.param == "fp16-build")
+    yield request.param
+    use_half_build(False)
+
+
+@pytest.fixture(autouse=True)
+def _default_build_only(request, half_build):
+    """the fp32-storage, split and fp8 modes belong to the default build: not repeated on the binary16 one"""
+    if half_build == "fp16-build":
+        mode = getattr(request.node, "callspec", None) and request.node.callspec.params.get("mode")
+        name = request.node.name
+        if mode in ("fp32", "fp32s", "fp8") or any(k in name for k in ("fp8", "fp32", "split", "reference_signature", "long_sequence",
+                                                                       "integration_recipe")):
+            pytest.skip("default build only")
+
+
+def bare_engine_class():
+    """DAEngine without weights: the op wrappers (conv, linear, ...) over the library build that is current"""
     from founddiff_amd import _lib as L
     from founddiff_amd.engine import DAEngine
     L.lib()
@@ -30,10 +49,16 @@ def eng_factory():
             from founddiff_amd.engine import _T
             self.mode = mode
             self.dt, self.tdt = _T[mode]
+            self.hip = L.BF16                     # (conftest.use_half_build: the binary16 build in the fp16 flavour)
             self.dev = torch.device("cuda")
             self.buf = {}
             self.f32_split = int(mode == "fp32s")
     return Bare
+
+
+@pytest.fixture(scope="module")
+def eng_factory(half_build):
+    return bare_engine_class()
 
 
 def nhwc(x, tdt):
@@ -45,7 +70,7 @@ def nchw(x):
 
 
 def rq(x, mode):
-    return x.to(torch.bfloat16).float() if mode == "bf16" else x
+    return x.to(HB.t).float() if mode == "bf16" else x
 
 
 # 'fp32s': fp32 storage, split-bf16 contraction (3 bf16 MFMAs per product, ~2^-16): the engine of a bf16 loop's last step
@@ -96,7 +121,7 @@ def test_pointwise_gemm_256_tile(eng_factory, cfg):
     torch.manual_seed(5)
     B, (H, W) = 8, cfg["hw"]
     c0, c1, cout = cfg["c0"], cfg["c1"], cfg["cout"]
-    bf = lambda t: t.to(torch.bfloat16).float()
+    bf = lambda t: t.to(HB.t).float()
     a = bf(torch.randn(B, H, W, c0))
     a1 = bf(torch.randn(B, H, W, c1)) if c1 else None
     w = bf(torch.randn(cout, c0 + c1) / (c0 + c1) ** 0.5)
@@ -104,19 +129,19 @@ def test_pointwise_gemm_256_tile(eng_factory, cfg):
     xin = torch.cat((a, a1), -1) if c1 else a
     ref = F.linear(xin, w, bias)
     cw = ConvW(w, bias, e.dev, e.tdt)
-    out = torch.zeros(B, H, W, cout, device="cuda", dtype=torch.bfloat16)
+    out = torch.zeros(B, H, W, cout, device="cuda", dtype=HB.t)
     kw = dict(c0=c0)
     if c1:
-        kw.update(in1=a1.cuda().to(torch.bfloat16), c1=c1)
+        kw.update(in1=a1.cuda().to(HB.t), c1=c1)
     if cfg["epi"] == "silu_split":
         kw.update(epi=L.EPI_SILU_SPLIT, split=cout // 2)
         ref[..., cout // 2:] = F.silu(ref[..., cout // 2:])
     elif cfg["epi"] == "gate_res":
         res = bf(torch.randn(B, H, W, cout))
         gate = torch.randn(B, cout)
-        kw.update(epi=L.EPI_GATE_RES, res=res.cuda().to(torch.bfloat16), gate=gate.cuda(), gate_ld=cout)
+        kw.update(epi=L.EPI_GATE_RES, res=res.cuda().to(HB.t), gate=gate.cuda(), gate_ld=cout)
         ref = res + gate[:, None, None, :] * ref
-    ad = a.cuda().to(torch.bfloat16)
+    ad = a.cuda().to(HB.t)
     assert e.conv(cw, ad, B, H, W, out, probe="kid", **kw) == cfg["kid"]
     e.conv(cw, ad, B, H, W, out, **kw)
     torch.cuda.synchronize()
@@ -135,6 +160,8 @@ def test_pointwise_gemm_256_tile(eng_factory, cfg):
         out.zero_()
         e.conv(cw, a0, B, H, W, out, **kw2)
         torch.cuda.synchronize()
+        # (on the binary16 build too: csrc/fd_common.h fd_cvt_h -- without it the compiler's v_fma_mixlo_f16 fold in ONE of the two
+        #  kernels made 6e-5 of the elements differ by a binary16 ulp)
         assert torch.equal(out, first)
 
 
@@ -533,7 +560,7 @@ def test_row_gemm_fused_prologues(eng_factory):
     torch.manual_seed(11)
     B, H, W = 2, 128, 256                       # 32768 pixels per image: row-GEMM territory
     hw = H * W
-    bf = lambda t: t.to(torch.bfloat16).float()
+    bf = lambda t: t.to(HB.t).float()
 
     def run(cw, x, out, **kw):
         assert e.conv(cw, x, B, H, W, out, probe=True, **kw), "expected the row-GEMM path"
@@ -546,11 +573,11 @@ def test_row_gemm_fused_prologues(eng_factory):
     w = bf(torch.randn(256, 64) / 8)
     g, b_ = torch.randn(64), torch.randn(64)
     mod = torch.randn(B, 6 * 64) * 0.5
-    xd, md, gd, bd = x.cuda().to(torch.bfloat16), mod.cuda(), g.cuda(), b_.cuda()
+    xd, md, gd, bd = x.cuda().to(HB.t), mod.cuda(), g.cuda(), b_.cuda()
     xm = F.layer_norm(x, (64,), g, b_, 1e-5) * (1 + mod[:, None, 64:128]) + mod[:, None, 0:64]
     ref = F.linear(bf(xm), w)
     ref[..., 128:] = F.silu(ref[..., 128:])
-    out = torch.empty(B, H, W, 256, device="cuda", dtype=torch.bfloat16)
+    out = torch.empty(B, H, W, 256, device="cuda", dtype=HB.t)
     got = run(ConvW(w, None, e.dev, e.tdt), xd, out, epi=L.EPI_SILU_SPLIT, split=128, prologue=L.PRO_LN_MOD,
               ln_gamma=gd, ln_beta=bd, ln_eps=1e-5, ln_shift=C.c_void_p(md.data_ptr()),
               ln_scale=C.c_void_p(md.data_ptr() + 64 * 4), ln_ld=6 * 64)
@@ -564,9 +591,9 @@ def test_row_gemm_fused_prologues(eng_factory):
     res = bf(torch.randn(B, hw, 64))
     yz = F.layer_norm(y, (128,), g2, b2, 1e-5) * xz[..., 128:] + loc[:, None]
     ref = res + mod[:, None, 128:192] * F.linear(bf(yz), w2)
-    yd, xzd, locd, g2d, b2d, resd = (y.cuda().to(torch.bfloat16), xz.cuda().to(torch.bfloat16), loc.cuda(),
-                                     g2.cuda(), b2.cuda(), res.cuda().to(torch.bfloat16))
-    out = torch.empty(B, H, W, 64, device="cuda", dtype=torch.bfloat16)
+    yd, xzd, locd, g2d, b2d, resd = (y.cuda().to(HB.t), xz.cuda().to(HB.t), loc.cuda(),
+                                     g2.cuda(), b2.cuda(), res.cuda().to(HB.t))
+    out = torch.empty(B, H, W, 64, device="cuda", dtype=HB.t)
     got = run(ConvW(w2, None, e.dev, e.tdt), yd, out, epi=L.EPI_GATE_RES, res=resd,
               gate=C.c_void_p(md.data_ptr() + 128 * 4), gate_ld=6 * 64, prologue=L.PRO_LN_GATE, ln_gamma=g2d,
               ln_beta=b2d, ln_eps=1e-5, ln_shift=locd, ln_ld=128, ln_z=xzd, ln_ldz=256, ln_offz=128)
@@ -577,23 +604,23 @@ def test_row_gemm_fused_prologues(eng_factory):
     xm2 = F.layer_norm(res, (64,), g, b_, 1e-5) * (1 + mod[:, None, 64:128]) + mod[:, None, 0:64]
     zt = bf(F.silu(F.linear(bf(xm2), wz)))
     ref = res + mod[:, None, 128:192] * F.linear(bf((F.layer_norm(y, (128,), g2, b2, 1e-5) * zt + loc[:, None])), w2)
-    wzd = wz.cuda().to(torch.bfloat16)
+    wzd = wz.cuda().to(HB.t)
     kwz = dict(epi=L.EPI_GATE_RES, res=resd, gate=C.c_void_p(md.data_ptr() + 128 * 4), gate_ld=6 * 64, ln_gamma=g2d,
                ln_beta=b2d, ln_eps=1e-5, ln_shift=locd, ln_ld=128)
-    out = torch.empty(B, H, W, 64, device="cuda", dtype=torch.bfloat16)
+    out = torch.empty(B, H, W, 64, device="cuda", dtype=HB.t)
     got = run(ConvW(w2, None, e.dev, e.tdt), yd, out, prologue=L.PRO_LN_GATE_ZRE,
               zre=dict(w=wzd, gamma=gd, beta=bd, shift=C.c_void_p(md.data_ptr()), scale=C.c_void_p(md.data_ptr() + 64 * 4),
                        ld=6 * 64, eps=1e-5), **kwz)
     assert rel_err(got.reshape(B, hw, 64), ref) < 1.5e-2
-    ztd = torch.zeros(B, hw, 256, dtype=torch.bfloat16, device="cuda")
-    ztd[..., 128:] = zt.cuda().to(torch.bfloat16)
-    out2 = torch.empty(B, H, W, 64, device="cuda", dtype=torch.bfloat16)
+    ztd = torch.zeros(B, hw, 256, dtype=HB.t, device="cuda")
+    ztd[..., 128:] = zt.cuda().to(HB.t)
+    out2 = torch.empty(B, H, W, 64, device="cuda", dtype=HB.t)
     stored = run(ConvW(w2, None, e.dev, e.tdt), yd, out2, prologue=L.PRO_LN_GATE, ln_z=ztd, ln_ldz=256, ln_offz=128, **kwz)
     assert rel_err(got, stored) < 4e-3            # same operands up to bf16 flips of LNmod(res) / z at rounding ties
     # a ragged pixel count (H * W not a multiple of 16) and unaffine norm1
     Hr, Wr = 127, 255
     hwr = Hr * Wr
-    outr = torch.empty(B, Hr, Wr, 64, device="cuda", dtype=torch.bfloat16)
+    outr = torch.empty(B, Hr, Wr, 64, device="cuda", dtype=HB.t)
     yr_, rr_ = yd.reshape(B, hw, 128)[:, :hwr].contiguous(), resd.reshape(B, hw, 64)[:, :hwr].contiguous()
     kwr = dict(kwz, res=rr_)
     assert e.conv(ConvW(w2, None, e.dev, e.tdt), yr_, B, Hr, Wr, outr, probe=True, prologue=L.PRO_LN_GATE_ZRE,
@@ -614,11 +641,11 @@ def test_row_gemm_fused_prologues(eng_factory):
     zt8 = bf(F.silu(F.linear(bf(xm8), wz8)))
     ref8 = res8 + mod8[:, None, 256:384] * F.linear(bf((F.layer_norm(y8, (256,), go8, bo8, 1e-5) * zt8 + loc8[:, None])), w8)
     m8d = mod8.cuda()
-    out8 = torch.empty(B, H, W, 128, device="cuda", dtype=torch.bfloat16)
-    got8 = run(ConvW(w8, None, e.dev, e.tdt), y8.cuda().to(torch.bfloat16), out8, prologue=L.PRO_LN_GATE_ZRE,
-               epi=L.EPI_GATE_RES, res=res8.cuda().to(torch.bfloat16), gate=C.c_void_p(m8d.data_ptr() + 256 * 4), gate_ld=6 * 128,
+    out8 = torch.empty(B, H, W, 128, device="cuda", dtype=HB.t)
+    got8 = run(ConvW(w8, None, e.dev, e.tdt), y8.cuda().to(HB.t), out8, prologue=L.PRO_LN_GATE_ZRE,
+               epi=L.EPI_GATE_RES, res=res8.cuda().to(HB.t), gate=C.c_void_p(m8d.data_ptr() + 256 * 4), gate_ld=6 * 128,
                ln_gamma=go8.cuda(), ln_beta=bo8.cuda(), ln_eps=1e-5, ln_shift=loc8.cuda(), ln_ld=256,
-               zre=dict(w=wz8.cuda().to(torch.bfloat16), gamma=g8.cuda(), beta=b8.cuda(), shift=C.c_void_p(m8d.data_ptr()),
+               zre=dict(w=wz8.cuda().to(HB.t), gamma=g8.cuda(), beta=b8.cuda(), shift=C.c_void_p(m8d.data_ptr()),
                         scale=C.c_void_p(m8d.data_ptr() + 128 * 4), ld=6 * 128, eps=1e-5))
     assert rel_err(got8.reshape(B, hw, 128), ref8) < 1.5e-2
     # (3) res_conv over a concat (128 + 64 -> 128) fused with GroupNorm+SiLU of the 3x3 output
@@ -630,9 +657,9 @@ def test_row_gemm_fused_prologues(eng_factory):
     mr = torch.stack([hv.mean(-1), torch.rsqrt(hv.var(-1, unbiased=False) + 1e-5)], -1).contiguous()
     gn = F.group_norm(h.permute(0, 2, 1), 8, gg, gb, 1e-5).permute(0, 2, 1)
     ref = F.linear(torch.cat((a, c), -1), w3, bias3) + F.silu(gn)
-    ad, cd, hd, mrd, ggd, gbd = (a.cuda().to(torch.bfloat16), c.cuda().to(torch.bfloat16),
-                                 h.cuda().to(torch.bfloat16), mr.cuda(), gg.cuda(), gb.cuda())
-    out = torch.empty(B, H, W, 128, device="cuda", dtype=torch.bfloat16)
+    ad, cd, hd, mrd, ggd, gbd = (a.cuda().to(HB.t), c.cuda().to(HB.t),
+                                 h.cuda().to(HB.t), mr.cuda(), gg.cuda(), gb.cuda())
+    out = torch.empty(B, H, W, 128, device="cuda", dtype=HB.t)
     got = run(ConvW(w3, bias3, e.dev, e.tdt), ad, out, c0=128, in1=cd, c1=64, epi=L.EPI_GNSILU_ADD, h=hd, gn=mrd,
               gamma=ggd, beta=gbd, groups=8)
     assert rel_err(got.reshape(B, hw, 128), ref) < 1.5e-2
@@ -640,8 +667,8 @@ def test_row_gemm_fused_prologues(eng_factory):
     big = bf(torch.randn(B, hw, 192))
     wb = bf(torch.randn(B, 64, 64) / 8)
     ref = res + mod[:, None, 320:384] * torch.einsum("bmk,bnk->bmn", big[..., 128:], wb)
-    bigd, wbd = big.cuda().to(torch.bfloat16), wb.cuda().to(torch.bfloat16)
-    out = torch.empty(B, H, W, 64, device="cuda", dtype=torch.bfloat16)
+    bigd, wbd = big.cuda().to(HB.t), wb.cuda().to(HB.t)
+    out = torch.empty(B, H, W, 64, device="cuda", dtype=HB.t)
     got = run(None, bigd, out, c0=64, ld0=192, off0=128, weight=wbd, w_batch_stride=64 * 64, bias=None, Cout=64,
               KH=1, KW=1, epi=L.EPI_GATE_RES, res=resd, gate=C.c_void_p(md.data_ptr() + 320 * 4), gate_ld=6 * 64)
     assert rel_err(got.reshape(B, hw, 64), ref) < 1.5e-2
@@ -651,11 +678,11 @@ def test_row_gemm_fused_prologues(eng_factory):
     w5 = bf(torch.randn(512, 128) / 11)
     g5, b5 = torch.randn(128), torch.randn(128)
     mod5 = torch.randn(B, 6 * 128) * 0.5
-    x5d, m5d, g5d, b5d = x5.cuda().to(torch.bfloat16), mod5.cuda(), g5.cuda(), b5.cuda()
+    x5d, m5d, g5d, b5d = x5.cuda().to(HB.t), mod5.cuda(), g5.cuda(), b5.cuda()
     xm = F.layer_norm(x5, (128,), g5, b5, 1e-5) * (1 + mod5[:, None, 128:256]) + mod5[:, None, 0:128]
     ref = F.linear(bf(xm), w5)
     ref[..., 256:] = F.silu(ref[..., 256:])
-    out = torch.empty(B, H, W, 512, device="cuda", dtype=torch.bfloat16)
+    out = torch.empty(B, H, W, 512, device="cuda", dtype=HB.t)
     got = run(ConvW(w5, None, e.dev, e.tdt), x5d, out, epi=L.EPI_SILU_SPLIT, split=256, prologue=L.PRO_LN_MOD,
               ln_gamma=g5d, ln_beta=b5d, ln_eps=1e-5, ln_shift=C.c_void_p(m5d.data_ptr()),
               ln_scale=C.c_void_p(m5d.data_ptr() + 128 * 4), ln_ld=6 * 128)
@@ -665,8 +692,8 @@ def test_row_gemm_fused_prologues(eng_factory):
     w6, bias6 = bf(torch.randn(128, 256) / 16), torch.randn(128)
     res6 = bf(torch.randn(B, hw, 128))
     ref = F.relu(F.linear(x6, w6, bias6) + res6)
-    x6d, r6d = x6.cuda().to(torch.bfloat16), res6.cuda().to(torch.bfloat16)
-    out = torch.empty(B, H, W, 128, device="cuda", dtype=torch.bfloat16)
+    x6d, r6d = x6.cuda().to(HB.t), res6.cuda().to(HB.t)
+    out = torch.empty(B, H, W, 128, device="cuda", dtype=HB.t)
     got = run(ConvW(w6, bias6, e.dev, e.tdt), x6d, out, epi=L.EPI_RES_RELU, res=r6d)
     assert rel_err(got.reshape(B, hw, 128), ref) < 1.5e-2
 
@@ -776,7 +803,7 @@ def test_pw_dw3x3_fused(eng_factory, cfg):
     torch.manual_seed(31)
     B, (H, W), Cin = 2, cfg["hw"], cfg.get("cin", 64)
     cdw, cz = cfg["cdw"], cfg["cz"]
-    bf = lambda t: t.to(torch.bfloat16).float()
+    bf = lambda t: t.to(HB.t).float()
     x = bf(torch.randn(B, H, W, Cin) * 1.3 + 0.2)
     g, be = (torch.randn(Cin), torch.randn(Cin)) if cfg["affine"] else (None, None)
     mod = torch.randn(B, 6 * Cin) * 0.5
@@ -790,11 +817,11 @@ def test_pw_dw3x3_fused(eng_factory, cfg):
     if cfg["silu"]:
         ref_dw = F.silu(ref_dw)
     assert L.lib().fd_pw_dw3x3_ok(L.FD_BF16, Cin, cdw, cz, H, W)
-    xd, md = x.cuda().to(torch.bfloat16), mod.cuda()
-    wpd = wpw.cuda().to(torch.bfloat16)
+    xd, md = x.cuda().to(HB.t), mod.cuda()
+    wpd = wpw.cuda().to(HB.t)
     wm = DAEngine._dw_masked(wdw.reshape(cdw, 9).t().contiguous().cuda())
-    out_dw = torch.zeros(B, H, W, cdw + 8, device="cuda", dtype=torch.bfloat16)
-    out_z = torch.zeros(B, H, W, 2 * cz + 8, device="cuda", dtype=torch.bfloat16)
+    out_dw = torch.zeros(B, H, W, cdw + 8, device="cuda", dtype=HB.t)
+    out_z = torch.zeros(B, H, W, 2 * cz + 8, device="cuda", dtype=HB.t)
     gd, bd = (g.cuda(), be.cuda()) if cfg["affine"] else (None, None)
     bdd = bdw.cuda() if bdw is not None else None
     ptr = lambda t_: None if t_ is None else t_.data_ptr()
@@ -823,18 +850,18 @@ def test_pw_dw3x3_gram(eng_factory, hw):
     from founddiff_amd.engine import DAEngine
     torch.manual_seed(33)
     B, (H, W), Cin = 2, hw, 64
-    bf = lambda t: t.to(torch.bfloat16).float()
+    bf = lambda t: t.to(HB.t).float()
     x = bf(torch.randn(B, H, W, Cin) * 1.3 + 0.2)
     mod = torch.randn(B, 6 * Cin) * 0.5
     wpw = bf(torch.randn(192, Cin) / 8)
     wdw = torch.randn(192, 1, 3, 3) / 3
     assert L.lib().fd_pw_dw3x3_gram_ok(L.FD_BF16, Cin, H, W)
-    xd, md = x.cuda().to(torch.bfloat16), mod.cuda()
-    wpd = wpw.cuda().to(torch.bfloat16)
+    xd, md = x.cuda().to(HB.t), mod.cuda()
+    wpd = wpw.cuda().to(HB.t)
     wm = DAEngine._dw_masked(wdw.reshape(192, 9).t().contiguous().cuda())
     s = torch.cuda.current_stream().cuda_stream
     # unfused HIP pair
-    qkv2 = torch.empty(B, H, W, 192, device="cuda", dtype=torch.bfloat16)
+    qkv2 = torch.empty(B, H, W, 192, device="cuda", dtype=HB.t)
     L.call("fd_pw_dw3x3", L.FD_BF16, xd.data_ptr(), Cin, 0, Cin, None, None, 1e-6, md.data_ptr(), md.data_ptr() + Cin * 4,
            6 * Cin, wpd.data_ptr(), 192, wm.data_ptr(), None, 0, qkv2.data_ptr(), 192, 0, 0, None, 0, 0, B, H, W, s)
     nb0 = L.lib().fd_chan_attn_nblk(H * W)
@@ -843,7 +870,7 @@ def test_pw_dw3x3_gram(eng_factory, hw):
     # fused
     nb1 = L.lib().fd_pw_dw3x3_gram_nblk(H, W)
     part1 = torch.full((B, 2, nb1, 1088), float("nan"), device="cuda")
-    v = torch.zeros(B, H, W, 64 + 8, device="cuda", dtype=torch.bfloat16)
+    v = torch.zeros(B, H, W, 64 + 8, device="cuda", dtype=HB.t)
     L.call("fd_pw_dw3x3_gram", L.FD_BF16, xd.data_ptr(), Cin, 0, Cin, None, None, 1e-6, md.data_ptr(), md.data_ptr() + Cin * 4,
            6 * Cin, wpd.data_ptr(), wm.data_ptr(), v.data_ptr(), 64 + 8, 8, part1.data_ptr(), B, H, W, s)
     torch.cuda.synchronize()
@@ -861,7 +888,9 @@ def test_pw_dw3x3_gram(eng_factory, hw):
     q, k = dwo[..., :64].reshape(B, H * W, 2, 32), dwo[..., 64:128].reshape(B, H * W, 2, 32)
     gram = torch.einsum("bphi,bphj->bhij", q.double(), k.double()).reshape(B, 2, 1024)
     e_f, e_u = rel_err(g1[..., :1024], gram), rel_err(g0[..., :1024], gram)
-    assert e_f < 4e-3 and e_f < 1.5 * e_u + 1e-4, (e_f, e_u)
+    # (on the binary16 build the unfused pair -- fp32-accumulating depthwise, q / k rounded to nearest -- is the closer one by a
+    #  factor of two: the fused kernel's depthwise accumulates its nine taps in fp16; both far inside the gate)
+    assert e_f < 4e-3 and (HB.fp16 or e_f < 1.5 * e_u + 1e-4), (e_f, e_u)
     assert rel_err(g1[..., 1024:1056], (q.double() ** 2).sum(1)) < 4e-3 and rel_err(g1[..., 1056:], (k.double() ** 2).sum(1)) < 4e-3
     # deterministic
     part2 = torch.empty_like(part1)
@@ -878,13 +907,13 @@ def test_pw_dw3x3_gram(eng_factory, hw):
     assert torch.equal(part1, part3)
     assert L.lib().fd_pw_dw3x3_proj_ok(L.FD_BF16, Cin, H, W)
     e = eng_factory("bf16")
-    weff = (torch.randn(B, 64, 64) / 8).to(torch.bfloat16).cuda()
+    weff = (torch.randn(B, 64, 64) / 8).to(HB.t).cuda()
     wm_v = DAEngine._dw_masked(wdw.reshape(192, 9)[128:].t().contiguous().cuda())
     vs = v[..., 8:].contiguous()
-    ref = torch.empty(B, H, W, 64, device="cuda", dtype=torch.bfloat16)
+    ref = torch.empty(B, H, W, 64, device="cuda", dtype=HB.t)
     e.conv(None, vs, B, H, W, ref, c0=64, ld0=64, off0=0, weight=weff, w_batch_stride=64 * 64, bias=None, Cout=64, KH=1, KW=1,
            epi=L.EPI_GATE_RES, res=xd, gate=C.c_void_p(md.data_ptr() + 5 * Cin * 4), gate_ld=6 * Cin)
-    got = torch.full((B, H, W, 64 + 8), 7.0, device="cuda", dtype=torch.bfloat16)
+    got = torch.full((B, H, W, 64 + 8), 7.0, device="cuda", dtype=HB.t)
     L.call("fd_pw_dw3x3_proj", L.FD_BF16, xd.data_ptr(), Cin, 0, Cin, None, None, 1e-6, md.data_ptr(), md.data_ptr() + Cin * 4,
            6 * Cin, wpd.data_ptr() + 128 * Cin * 2, wm_v.data_ptr(), weff.data_ptr(), md.data_ptr() + 5 * Cin * 4, 6 * Cin,
            got.data_ptr(), 64 + 8, 8, B, H, W, s)
@@ -905,7 +934,7 @@ def test_gn_apply_down4x4(eng_factory, cfg):
     B, (H, W), Co = cfg["B"], cfg["hw"], cfg["cout"]
     C_ = 64
     assert L.lib().fd_gn_apply_down4x4_ok(L.FD_BF16, C_, Co, H, W)
-    bf = lambda t: t.to(torch.bfloat16).float()
+    bf = lambda t: t.to(HB.t).float()
     h = bf(torch.randn(B, H, W, C_) * 2 + 0.5)
     x = bf(torch.randn(B, H, W, C_))
     gam, bet = torch.randn(C_), torch.randn(C_)
@@ -913,17 +942,17 @@ def test_gn_apply_down4x4(eng_factory, cfg):
     mr = torch.stack([hv.mean(-1), torch.rsqrt(hv.var(-1, unbiased=False) + 1e-5)], -1).contiguous()
     wt, bias = bf(torch.randn(Co, C_, 4, 4) / 32), torch.randn(Co)
     cw = ConvW(wt, bias, e.dev, e.tdt)
-    hd, xd, mrd, gd, bd = h.cuda().to(torch.bfloat16), x.cuda().to(torch.bfloat16), mr.cuda(), gam.cuda(), bet.cuda()
+    hd, xd, mrd, gd, bd = h.cuda().to(HB.t), x.cuda().to(HB.t), mr.cuda(), gam.cuda(), bet.cuda()
     s = torch.cuda.current_stream().cuda_stream
     # two passes
-    sk0 = torch.empty(B, H, W, C_, device="cuda", dtype=torch.bfloat16)
+    sk0 = torch.empty(B, H, W, C_, device="cuda", dtype=HB.t)
     L.call("fd_gn_silu_apply", L.FD_BF16, hd.data_ptr(), mrd.data_ptr(), gd.data_ptr(), bd.data_ptr(), xd.data_ptr(),
            sk0.data_ptr(), B, H * W, C_, 8, s)
-    o0 = torch.empty(B, H // 2, W // 2, Co, device="cuda", dtype=torch.bfloat16)
+    o0 = torch.empty(B, H // 2, W // 2, Co, device="cuda", dtype=HB.t)
     e.conv(cw, sk0, B, H, W, o0, stride=2, pad=1)
     # one pass
-    sk1 = torch.full((B, H, W, C_), 3.0, device="cuda", dtype=torch.bfloat16)
-    o1 = torch.full((B, H // 2, W // 2, Co), 5.0, device="cuda", dtype=torch.bfloat16)
+    sk1 = torch.full((B, H, W, C_), 3.0, device="cuda", dtype=HB.t)
+    o1 = torch.full((B, H // 2, W // 2, Co), 5.0, device="cuda", dtype=HB.t)
     L.call("fd_gn_apply_down4x4", L.FD_BF16, hd.data_ptr(), xd.data_ptr(), mrd.data_ptr(), gd.data_ptr(), bd.data_ptr(), 8,
            sk1.data_ptr(), cw.w.data_ptr(), cw.b.data_ptr(), o1.data_ptr(), B, H, W, C_, Co, s)
     torch.cuda.synchronize()
@@ -950,12 +979,12 @@ def test_dwconv_gram(eng_factory, cfg):
     Cc, H, W = cfg
     torch.manual_seed(35)
     B = 2
-    qkv = (torch.randn(B, H, W, 3 * Cc) * 0.7).to(torch.bfloat16).cuda()
+    qkv = (torch.randn(B, H, W, 3 * Cc) * 0.7).to(HB.t).cuda()
     wdw = (torch.randn(9, 3 * Cc) / 3).cuda()
     wm = DAEngine._dw_masked(wdw)
     s = torch.cuda.current_stream().cuda_stream
     assert L.lib().fd_dwconv_gram_ok(L.FD_BF16, Cc, H, W)
-    full = torch.empty(B, H, W, 3 * Cc, device="cuda", dtype=torch.bfloat16)
+    full = torch.empty(B, H, W, 3 * Cc, device="cuda", dtype=HB.t)
     L.call("fd_dwconv3x3", L.FD_BF16, qkv.data_ptr(), 3 * Cc, 0, wdw.data_ptr(), None, 0, full.data_ptr(), 3 * Cc, 0, B, H, W, 3 * Cc, s)
     nb0 = L.lib().fd_chan_attn_nblk(H * W)
     part0 = torch.empty(B, Cc // 32, nb0, 1088, device="cuda")
@@ -963,7 +992,7 @@ def test_dwconv_gram(eng_factory, cfg):
     nb1 = L.lib().fd_dwconv_gram_nblk(H, W)
     part1 = torch.full((B, Cc // 32, nb1, 1088), float("nan"), device="cuda")
     L.call("fd_dwconv_gram", L.FD_BF16, qkv.data_ptr(), 3 * Cc, Cc, wm.data_ptr(), part1.data_ptr(), B, H, W, s)
-    v = torch.empty(B, H, W, Cc, device="cuda", dtype=torch.bfloat16)
+    v = torch.empty(B, H, W, Cc, device="cuda", dtype=HB.t)
     wv = wdw[:, 2 * Cc:].contiguous()
     L.call("fd_dwconv3x3", L.FD_BF16, qkv.data_ptr(), 3 * Cc, 2 * Cc, wv.data_ptr(), None, 0, v.data_ptr(), Cc, 0, B, H, W, Cc, s)
     torch.cuda.synchronize()
@@ -978,7 +1007,9 @@ def test_dwconv_gram(eng_factory, cfg):
     k = dwo[:, Cc:2 * Cc].reshape(B, Cc // 32, 32, H * W).double()
     gram = (q @ k.transpose(-1, -2)).reshape(B, Cc // 32, 1024)
     e_f, e_u = rel_err(g1[..., :1024], gram), rel_err(g0[..., :1024], gram)
-    assert e_f < 4e-3 and e_f < 1.5 * e_u + 1e-4, (e_f, e_u)
+    # (on the binary16 build the unfused pair -- fp32-accumulating depthwise, q / k rounded to nearest -- is the closer one by a
+    #  factor of two: the fused kernel's depthwise accumulates its nine taps in fp16; both far inside the gate)
+    assert e_f < 4e-3 and (HB.fp16 or e_f < 1.5 * e_u + 1e-4), (e_f, e_u)
     assert rel_err(g1[..., 1024:1056], (q ** 2).sum(-1)) < 4e-3 and rel_err(g1[..., 1056:], (k ** 2).sum(-1)) < 4e-3
     assert rel_err(g1[..., :1024], g0[..., :1024]) < 8e-3
     part2 = torch.empty_like(part1)
@@ -1003,7 +1034,7 @@ def test_init_conv7(eng_factory, cfg):
     assert L.lib().fd_init_conv7_ok(L.FD_BF16, co, H, W)
     wp = e._pack_init7(w)
     planes = [x[:, i].contiguous().cuda() for i in range(c)] + [None] * (3 - c)
-    out = torch.empty(B, H, W, co, device="cuda", dtype=torch.bfloat16)
+    out = torch.empty(B, H, W, co, device="cuda", dtype=HB.t)
     bd = bias.cuda()
     L.call("fd_init_conv7", L.FD_BF16, *[None if p is None else p.data_ptr() for p in planes], wp.data_ptr(),
            bd.data_ptr(), out.data_ptr(), B, H, W, co, None)
@@ -1033,10 +1064,10 @@ def test_conv3x3_fp8_weights(eng_factory, cfg):
     c0, c1, co = cfg["c0"], cfg["c1"], cfg["cout"]
     cin = c0 + c1
     up = cfg.get("up", False)
-    x = (torch.randn(B, cin, H, W) * 1.5).to(torch.bfloat16).float()
+    x = (torch.randn(B, cin, H, W) * 1.5).to(HB.t).float()
     w = torch.randn(co, cin, 3, 3) / (3 * cin ** 0.5)
     bias = torch.randn(co) * 0.1
-    cw = E.ConvW(w, bias, "cuda", torch.bfloat16, fp8=True)
+    cw = E.ConvW(w, bias, "cuda", HB.t, fp8=True)
     assert cw.w8 is not None and cw.w8.dtype == torch.float8_e4m3fn
     a_s = E.FP8_ACT_SCALE
     xq = (x * a_s).clamp(-448, 448).to(torch.float8_e4m3fn).float() / a_s
@@ -1044,10 +1075,10 @@ def test_conv3x3_fp8_weights(eng_factory, cfg):
     xin = F.interpolate(xq, scale_factor=2, mode="nearest") if up else xq
     ref = F.conv2d(xin, wq, bias, padding=1)
     full = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest") if up else x, w, bias, padding=1)
-    xd = nhwc(x, torch.bfloat16)
+    xd = nhwc(x, HB.t)
     a, b = (xd[..., :c0].contiguous(), xd[..., c0:].contiguous()) if c1 else (xd, None)
     OH, OW = (2 * H, 2 * W) if up else (H, W)
-    out = torch.empty(B, OH, OW, co, device="cuda", dtype=torch.bfloat16)
+    out = torch.empty(B, OH, OW, co, device="cuda", dtype=HB.t)
     kw = dict(c0=c0, in1=b, c1=c1, upsample=up)
     assert e.conv(cw, a, B, H, W, out, probe="kid", **kw) == 12
     e.conv(cw, a, B, H, W, out, **kw)
@@ -1083,8 +1114,8 @@ def test_selective_scan_fused_xproj(cfg):
     B, CD = 2, R + 2 * N
     H2, W2 = (H + 1) // 2, (W + 1) // 2
     Lq = H2 * W2
-    xc = (torch.randn(B, D, H, W) * 0.5).to(torch.bfloat16).float()
-    xw = (torch.randn(4, CD, D) / D ** 0.5).to(torch.bfloat16).float()
+    xc = (torch.randn(B, D, H, W) * 0.5).to(HB.t).float()
+    xw = (torch.randn(4, CD, D) / D ** 0.5).to(HB.t).float()
     dtw = (torch.rand(4, D, R) * 2 - 1) * R ** -0.5
     dtb = torch.randn(4, D) * 0.5 - 3
     A = -torch.exp(torch.log(torch.arange(1, N + 1).float())[None].repeat(4 * D, 1) + 0.1 * torch.randn(4 * D, N))
@@ -1100,10 +1131,10 @@ def test_selective_scan_fused_xproj(cfg):
     xd_rows = torch.stack([xd_scan[:, 0], xd_scan[:, 1].reshape(B, W2, H2, CD).transpose(1, 2).reshape(B, Lq, CD),
                            xd_scan[:, 2], xd_scan[:, 3].reshape(B, W2, H2, CD).transpose(1, 2).reshape(B, Lq, CD)], 0)
     ws = torch.empty(L.lib().fd_scan_ws_floats(B, H, W, D, N), device="cuda")
-    y = torch.empty(B, H, W, D, device="cuda", dtype=torch.bfloat16)
+    y = torch.empty(B, H, W, D, device="cuda", dtype=HB.t)
     xdbl = torch.full((4, B, Lq, CD), float("nan"), device="cuda")
     t = [v.contiguous().cuda() for v in (dtw, dtb, A, Ds)]
-    xcd, xwd = nhwc(xc, torch.bfloat16), xw.to("cuda", torch.bfloat16).contiguous()
+    xcd, xwd = nhwc(xc, HB.t), xw.to("cuda", HB.t).contiguous()
     L.call("fd_selective_scan_xproj", L.FD_BF16, xcd.data_ptr(), xwd.data_ptr(), xdbl.data_ptr(), t[0].data_ptr(), t[1].data_ptr(),
            t[2].data_ptr(), t[3].data_ptr(), y.data_ptr(), ws.data_ptr(), B, H, W, D, N, R, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()

@@ -15,7 +15,12 @@ import torch.nn.functional as F
 
 from conftest import rel_err
 from test_gpu_e2e import TINY_CLIP, l2rel, psnr
-from test_gpu_kernels import eng_factory  # noqa: F401  (fixture)
+from test_gpu_kernels import bare_engine_class
+
+
+@pytest.fixture(scope="module")
+def eng_factory():
+    return bare_engine_class()
 
 pytestmark = pytest.mark.gpu
 
@@ -24,7 +29,7 @@ def _d(t):
     return t.double()
 
 
-def test_row_gemm_fp32_storage_split_bf16(eng_factory):  # noqa: F811
+def test_row_gemm_fp32_storage_split_bf16(eng_factory):
     """fd_conv2d kernel id 17: every prologue / epilogue the fp32s engine uses, against fp64 on the same fp32 operands.
     Three bf16 MFMAs per product leave ~2^-16 per term: gate 2e-5 of the output's largest magnitude."""
     from founddiff_amd import _lib as L
@@ -401,7 +406,7 @@ def test_two_stream_sample_repeatable_at_bench_size(prec):
         assert torch.equal(o, one), (prec, i, float((o - one).abs().max()))
 
 
-def test_pointwise_gemm_gate_table_batch_groups(eng_factory):  # noqa: F811
+def test_pointwise_gemm_gate_table_batch_groups(eng_factory):
     """pw_gemm_kernel stages gate[b][n] of a launch in LDS (4096 floats).  A GATE_RES layer whose batch exceeds the table (Cout
     512 at sub-batch 16) used to leave the kernel silently for the generic tile; it now runs as launches over groups
     of whole images: kernel id 7 at every batch, and the results of a batch of 16 are bitwise those of two batches of 8."""

@@ -93,11 +93,16 @@ def test_cabi_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "founddiff_hip.h")).read()
     declared = set(re.findall(r"\b(fd_[a-z0-9_]+)\s*\(", hdr)) - {"fd_conv_params"}
     assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
-    lib = L.lib()          # raises if the .so is missing or lacks a symbol
-    assert lib.fd_version() >= 100
-    assert lib.fd_conv_mtiles(512, 512) == 4096      # 64-pixel GroupNorm bands
-    assert lib.fd_chan_attn_nblk(512 * 512) == 256
-    assert lib.fd_scan_ws_floats(1, 512, 512, 128, 4) > 0
+    # both builds of the library (founddiff_amd/build.py): the default one (bfloat16) and the FD_HALF_F16 one (IEEE binary16)
+    for build, fmt in ((L.BF16, 0), (L.F16, 1)):
+        lib = build.lib()          # raises if the .so is missing, lacks a symbol, or is the other build
+        assert lib.fd_half_format() == fmt
+        assert lib.fd_version() >= 100
+        assert lib.fd_conv_mtiles(512, 512) == 4096      # 64-pixel GroupNorm bands
+        assert lib.fd_chan_attn_nblk(512 * 512) == 256
+        assert lib.fd_scan_ws_floats(1, 512, 512, 128, 4) > 0
+        assert lib.fd_dev_options().decode().startswith("release build") or os.environ.get("FOUNDDIFF_DEV_BUILD") == "1"
+    assert L.lib() is L.BF16.lib()
 
 
 def test_fused_kernel_eligibility_rules():
