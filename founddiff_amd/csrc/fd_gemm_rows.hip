@@ -24,7 +24,7 @@ __device__ __forceinline__ void unpack8(const bf16x8 &v, float f[8]) {
 __device__ __forceinline__ bf16x8 pack8(const float f[8]) {
     bf16x8 v;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = (bf16)f[i];
+    for (int i = 0; i < 8; ++i) v[i] = fd_cvt_h(f[i]);
     return v;
 }
 
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(NT) void gemm_rows_kernel(const fd_conv_params p, i
                     float fw[8];
                     load8(p.fin_w + n0, fw);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) fdot[s] += (float)(bf16)val[e] * fw[e];
+                    for (int e = 0; e < 8; ++e) fdot[s] += (float)fd_cvt_h(val[e]) * fw[e];
                 } else {
                     store8(outp + m * p.ldo + n0, val);
                 }

@@ -35,7 +35,16 @@ typedef _Float16 pd_h8 __attribute__((ext_vector_type(8)));
 // 40 v_dot2 (the bf16 form had to gather tap pairs per channel because the dot product contracts WITHIN a register).
 // The 9-term sum is accumulated in fp16 (~7e-4 rms relative, below the bf16 rounding of the output it feeds; the
 // input side gains 3 bits).  v_cvt_pkrtz_f16_f32 saturates instead of producing infinities (|t| > 65504).
-__device__ __forceinline__ uint32_t pk_h2(float a, float b) { return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a, b)); }
+// (binary16 build: v_cvt_pk_f16_f32, round to nearest even -- there the tile's rounding is no longer below the output's, and a
+//  round-toward-zero conversion is a bias of half an ulp in every stored xc / q / k / v; out-of-range values become infinities like
+//  everywhere else in that build, and sample() reports them)
+__device__ __forceinline__ uint32_t pk_h2(float a, float b) {
+#ifdef FD_HALF_F16
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){a, b}, pd_h2));
+#else
+    return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a, b));
+#endif
+}
 // a dword of two stored 16-bit elements as an fp16 pair (exact from bfloat16 inside fp16's range; the identity in the FD_HALF_F16 build)
 __device__ __forceinline__ uint32_t h16_to_h2(uint32_t w) {
 #ifdef FD_HALF_F16

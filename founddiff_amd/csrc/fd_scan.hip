@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 16 && R >= 16 ? 4 : (N >=
         const int soff = __builtin_amdgcn_readfirstlane(soff_);     // (a VGPR offset turns the store into a waterfall loop)
         if (ODD && soff < 0) return;
         if constexpr (sizeof(T) == 2) {
-            const bf16 hv = (bf16)v;
+            const bf16 hv = fd_cvt_h(v);
             __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hv), rs_y, voff, soff, 0);
         } else {
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs_y, voff, soff, 0);
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256, (N >= 32 ? 3 : (N >= 16 && R >= 16 ? 4 : (N >=
         const int soff = __builtin_amdgcn_readfirstlane(soff_);
         if (ODD && soff < 0) return;
         typedef __attribute__((ext_vector_type(2))) bf16 bfx2;
-        const bfx2 hv = {(bf16)v.x, (bf16)v.y};
+        const bfx2 hv = {fd_cvt_h(v.x), fd_cvt_h(v.y)};
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, hv), rs_y, voff, soff, 0);
     };
     // scan position -> (h2, w2) kept as scalar counters: no division in the loop
@@ -738,7 +738,7 @@ __global__ __launch_bounds__(256) void scan_seq_kernel(const T *__restrict__ xc,
         const int soff = __builtin_amdgcn_readfirstlane(soff_);
         if (ODD && soff < 0) return;
         if constexpr (sizeof(T) == 2) {
-            const bf16 hv = (bf16)v;
+            const bf16 hv = fd_cvt_h(v);
             __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hv), rs_y, voff, soff, 0);
         } else {
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs_y, voff, soff, 0);

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const T *__restrict
             float v[8];
             load8(qp + 8 * g, v);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) qb16[qb][e] = (bf16)(v[e] * scale);
+            for (int e = 0; e < 8; ++e) qb16[qb][e] = fd_cvt_h(v[e] * scale);
         } else {
 #pragma unroll
             for (int s = 0; s < 8; ++s) qf[qb][s] = (float)qp[4 * s + g] * scale;      // k-step s: d = 4 s + g
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const T *__restrict
                 for (int dblk = 0; dblk < 2; ++dblk) o[qb][dblk] *= corr;
                 if constexpr (BF) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) pb[qb][e] = (bf16)pf[qb][e];
+                    for (int e = 0; e < 8; ++e) pb[qb][e] = fd_cvt_h(pf[qb][e]);
                 }
             }
             // ---- O^T += V^T P^T: rows = d, k = the 32 keys in accumulator order (e < 4: key 4 g + e; e >= 4: 16 + 4 g + e - 4)

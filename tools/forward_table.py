@@ -14,7 +14,7 @@ from founddiff_amd import _lib as L, synth  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=8)
-ap.add_argument("--precision", default="bf16", help="bf16 | fp32s | fp32 | fp8: the kernel mode of the forward")
+ap.add_argument("--precision", default="bf16", help="bf16 | fp16 | fp32s | fp32 | fp8: the kernel mode of the forward")
 a = ap.parse_args()
 dev = torch.device("cuda")
 dif, _ = bench.build_model(dev, precision=a.precision)
@@ -29,7 +29,7 @@ eng.forward(img, x_in, tb)
 L.TRACE = []
 eng.forward(img, x_in, tb)
 trace, L.TRACE = L.TRACE, None
-lib = L.lib()
+lib = eng.hip.lib()          # the build of the library this engine calls (the binary16 one for --precision fp16)
 KID = {0: "igemm 128x128", 1: "igemm 128x64", 2: "igemm 64x128", 3: "igemm 64x64", 4: "igemm 128x256", 5: "igemm 256x256",
        6: "igemm 128x32", 7: "pw_gemm 256x256 persistent", 10: "row-GEMM", 11: "halo 3x3", 12: "halo 3x3 fp8", 13: "3x3 weights in registers", 14: "halo 3x3, up-sampling as four 2x2 (GFLOP of the 9-tap form)",
        15: "halo 3x3 split-bf16 (fp32 storage)", 16: "halo 3x3 split-bf16, up-sampling as four 2x2 (GFLOP of the 9-tap form)", 17: "row-GEMM fp32 storage split-bf16"}

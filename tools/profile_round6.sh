@@ -38,4 +38,12 @@ find $OUT -name "*_kernel_trace.csv" -delete; find $OUT -name "*counter_collecti
 timeout 3000 python3 -m pytest tests -m gpu -q > $OUT/pytest_gpu.txt 2>&1; tail -2 $OUT/pytest_gpu.txt
 python3 -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1; tail -3 $OUT/smoke.txt
 FOUNDDIFF_LOW_LATENCY=1 python3 tools/forward_table.py --batch 1 > $OUT/forward_launches_b1_low_latency.md 2> /dev/null
-ls -la $OUT; cat $OUT/pmc_two_stream.md; cat $OUT/traffic_summary.txt
+# 6. precision='fp16' (the binary16 build): loop drift against the CPU oracle at both sizes beside bf16, stage by stage against the fp32
+# engine, repeatability / batch invariance, the two GEMM kernels bit for bit, and the forward launch by launch
+python3 tools/probes/fp16_drift.py --size 256 --modes bf16,fp16 --tails 1:0,1:2,0:2 > $OUT/fp16_drift_256.md 2> /dev/null
+python3 tools/probes/fp16_drift.py --size 512 --modes bf16,fp16 --tails 1:0,1:2,0:2 > $OUT/fp16_drift_512.md 2> /dev/null
+python3 tools/probes/fp16_stages.py --size 256 > $OUT/fp16_stage_errors_256.md 2> /dev/null
+python3 tools/probes/fp16_repeat.py > $OUT/fp16_repeat.txt 2> /dev/null
+python3 tools/probes/pwg_vs_igemm.py > $OUT/fp16_pwg_vs_igemm.txt 2> /dev/null
+python3 tools/forward_table.py --precision fp16 > $OUT/forward_launches_fp16.md 2> /dev/null
+ls -la $OUT; cat $OUT/pmc_two_stream.md; cat $OUT/traffic_summary.txt; cat $OUT/fp16_drift_512.md
