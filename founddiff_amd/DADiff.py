@@ -96,8 +96,9 @@ def _build_tree(root, spec):
 
 class Unet(_ParamTree):
     """DA-CLIP conditioned U-Net (reference src/DADiff.py:530-740).  `condition` is forced on
-    as in the reference (line 588).  Extra kwargs: `precision` ('bf16' | 'fp32' | 'fp8': bf16 kernels with e4m3
-    weights on the fp8 MFMA for the 3x3 convolutions, BASELINE configs[4]) selects the kernel mode; `clip_cfg` overrides the RN50 DA-CLIP geometry (tests use a shrunken one)."""
+    as in the reference (line 586).  Extra kwargs: `precision` selects the kernel mode -- 'bf16' (default) | 'fp16' (the same kernels
+    on the library's IEEE-binary16 build: 8 x smaller drift at the same speed, binary16's range) | 'fp32s' | 'fp32' | 'fp8' (bf16
+    kernels with e4m3 weights on the fp8 MFMA for the 3x3 convolutions, BASELINE configs[4]); `clip_cfg` overrides the RN50 DA-CLIP geometry (tests use a shrunken one)."""
 
     def __init__(self, dim, init_dim=None, out_dim=None, dim_mults=(1, 2, 4, 8), channels=1,
                  self_condition=False, resnet_block_groups=8, learned_variance=False,

@@ -16,12 +16,14 @@
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 enum Kind { FMA = 0, PKFMA, EXP, LOG, PKMUL, PKADD, MIX_EXP_2FMA, MIX_EXP_4FMA, MIX_EXP_2PK, CVTPK, PKFMA16, MULLO, SPLIT_EXP_FMA, SPLIT_EXP_PK,
-            FMA_DEP, MIX_SCAN, NKIND };
+            FMA_DEP, MIX_SCAN, CVTPK_F16, CVTPKRTZ, CVT_F32_F16, CVT_F32_F16_SDWA, FMA_MIX, FMA_MIXLO, LSHL, NKIND };
 static const char *KN[NKIND] = {"v_fma_f32", "v_pk_fma_f32", "v_exp_f32", "v_log_f32", "v_pk_mul_f32", "v_pk_add_f32",
                                 "in-wave 1 exp : 2 fma", "in-wave 1 exp : 4 fma", "in-wave 1 exp : 2 pk_fma", "v_cvt_pk_bf16_f32",
                                 "v_pk_fma_f16", "v_mul_lo_u32", "across waves: even waves exp, odd waves fma",
                                 "across waves: even waves exp, odd waves pk_fma", "v_fma_f32 one dependent chain",
-                                "scan step mix (12 exp/log + 26 pk + 6 plain per pair)"};
+                                "scan step mix (12 exp/log + 26 pk + 6 plain per pair)",
+                                "v_cvt_pk_f16_f32", "v_cvt_pkrtz_f16_f32", "v_cvt_f32_f16", "v_cvt_f32_f16 sdwa (high half)",
+                                "v_fma_mix_f32 (f16 src2)", "v_fma_mixlo_f16", "v_lshlrev_b32"};
 
 constexpr int NACC = 8, INNER = 8, ITERS = 512;      // instructions per wave = ITERS * INNER * NACC (per kind unit)
 
@@ -56,6 +58,13 @@ __global__ __launch_bounds__(256) void probe(const float *in, float *out, uint64
                 else if constexpr (K == EXP) { asm volatile("v_exp_f32 %0, %0" : "+v"(a[i])); }
                 else if constexpr (K == LOG) { asm volatile("v_log_f32 %0, %0" : "+v"(a[i])); }
                 else if constexpr (K == CVTPK) { asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b)); }
+                else if constexpr (K == CVTPK_F16) { asm volatile("v_cvt_pk_f16_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b)); }
+                else if constexpr (K == CVTPKRTZ) { asm volatile("v_cvt_pkrtz_f16_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b)); }
+                else if constexpr (K == CVT_F32_F16) { asm volatile("v_cvt_f32_f16 %0, %0" : "+v"(a[i])); }
+                else if constexpr (K == CVT_F32_F16_SDWA) { asm volatile("v_cvt_f32_f16_sdwa %0, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "+v"(a[i])); }
+                else if constexpr (K == FMA_MIX) { asm volatile("v_fma_mix_f32 %0, %0, %1, %2 op_sel_hi:[0,0,1]" : "+v"(a[i]) : "v"(b), "v"(c)); }
+                else if constexpr (K == FMA_MIXLO) { asm volatile("v_fma_mixlo_f16 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c)); }
+                else if constexpr (K == LSHL) { asm volatile("v_lshlrev_b32 %0, 16, %0" : "+v"(a[i])); }
                 else if constexpr (K == PKFMA16) { asm volatile("v_pk_fma_f16 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c)); }
                 else if constexpr (K == MULLO) { asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(ua) : "v"(ub)); }
                 else if constexpr (K == MIX_EXP_2FMA) {
@@ -152,6 +161,18 @@ int main() {
     // warm the clocks
     for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(probe<FMA>, dim3(2048), dim3(256), 0, 0, in, out, cyc, ninstr);
     hipDeviceSynchronize();
+    if (getenv("VR_CVT_ONLY")) {           // the 16-bit format conversions of the library's two builds (round 6)
+        sweep<FMA>(in, out, cyc, ninstr);
+        sweep<CVTPK>(in, out, cyc, ninstr);
+        sweep<CVTPK_F16>(in, out, cyc, ninstr);
+        sweep<CVTPKRTZ>(in, out, cyc, ninstr);
+        sweep<LSHL>(in, out, cyc, ninstr);
+        sweep<CVT_F32_F16>(in, out, cyc, ninstr);
+        sweep<CVT_F32_F16_SDWA>(in, out, cyc, ninstr);
+        sweep<FMA_MIX>(in, out, cyc, ninstr);
+        sweep<FMA_MIXLO>(in, out, cyc, ninstr);
+        return 0;
+    }
     sweep<FMA>(in, out, cyc, ninstr);
     sweep<FMA_DEP>(in, out, cyc, ninstr);
     sweep<PKFMA>(in, out, cyc, ninstr);
