@@ -40,6 +40,13 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+# The binary16 build without v_fma_mix_f32.  With f16 values in sight hipcc selects v_fma_mix_f32 (VOP3P) for plain fp32 fmas too --
+# 84 of the 1355 VALU instructions of pwdw_kernel<64>, one for one against v_fma_f32 / v_fmac_f32, every operand fp32 -- and the fused
+# LN -> 1x1 -> depthwise kernels ran 8-13 % slower than their bfloat16 twins with the SAME instruction count (PMC: VALU busy 71 %
+# against 79 %, 44 % of wave time parked against 38 %: the instruction issues at the v_fma_f32 rate, tools/probes/valu_rate.hip, but
+# dependent instructions wait longer for it).  Without the feature the same fmas are v_fma_f32 again, bit for bit the same results,
+# and half of that gap closes (launch 6 of the forward: 279-286 -> 257-265 us, bf16 239-245; profiles/r06/fp16_mode.md).
+NO_FMA_MIX = ["-Xclang", "-target-feature", "-Xclang", "-fma-mix-insts"]
 # the second form of the library: the same sources with IEEE binary16 as the 16-bit storage / MFMA operand type (csrc/fd_common.h)
 LIB_F16 = os.path.join(LIBDIR, "libfounddiff_hip_f16.so")
 
@@ -47,7 +54,7 @@ LIB_F16 = os.path.join(LIBDIR, "libfounddiff_hip_f16.so")
 def build(force=False, verbose=False, half="bf16"):
     """half='bf16': lib/libfounddiff_hip.so; half='fp16': lib/libfounddiff_hip_f16.so (-DFD_HALF_F16, objects under lib/obj_f16)."""
     if half == "fp16":
-        return _build(force, verbose, LIB_F16, "obj_f16", ["-DFD_HALF_F16"])
+        return _build(force, verbose, LIB_F16, "obj_f16", ["-DFD_HALF_F16", *NO_FMA_MIX])
     return _build(force, verbose, LIB, "obj", [])
 
 

@@ -105,3 +105,26 @@ def use_half_build(fp16):
         HB.fp16, HB.t = fp16, (torch.float16 if fp16 else torch.bfloat16)
         for m in ("bf16", "fp8"):
             engine._T[m] = (engine._T[m][0], HB.t)
+
+
+# ---- the CPU oracle's 50-step DDIM loop of the shipped architecture at a BASELINE size: minutes of CPU per call (50 forwards; ~35 s at
+# 256x256, ~160 s at 512x512 on 32 host threads), asked for by several GPU tests with the same inputs -- computed once per session.
+_ORACLE_LOOPS = {}
+
+
+def oracle_ddim_loop(size, steps=50, noise_seed=7):
+    """(weights, x_in [0, 1], x_T noise, oracle.sampler.ResidualOracle.sample(...)[-1]) for the synthetic-weight full model on the
+    seed-10 CT phantom"""
+    key = (size, steps, noise_seed)
+    if key not in _ORACLE_LOOPS:
+        from founddiff_amd import arch, synth
+        from oracle import sampler
+        spec = arch.da_unet_spec(64, (1, 2, 4, 8), prefix="model.unet0.")
+        w = synth.synth_state_dict(spec, seed=0)
+        _, ld = synth.ct_phantom(1, size, seed=10)
+        x_in = torch.from_numpy(ld)
+        noise = torch.randn(1, 1, size, size, generator=torch.Generator().manual_seed(noise_seed))
+        torch.set_num_threads(min(32, torch.get_num_threads()))
+        ref = sampler.ResidualOracle(w, prefix="model.unet0.", sampling_timesteps=steps).sample(x_in, noise)[-1]
+        _ORACLE_LOOPS[key] = (w, x_in, noise, ref)
+    return _ORACLE_LOOPS[key]

@@ -104,19 +104,6 @@ def test_mamba_block_fp16(golden, tag):
     assert err < 4e-3, err
 
 
-def _oracle_loop(size, S):
-    from founddiff_amd import arch, synth
-    from oracle import sampler
-    spec = arch.da_unet_spec(64, (1, 2, 4, 8), prefix="model.unet0.")
-    w = synth.synth_state_dict(spec, seed=0)
-    _, ld = synth.ct_phantom(1, size, seed=10)
-    x_in = torch.from_numpy(ld)
-    noise = torch.randn(1, 1, size, size, generator=torch.Generator().manual_seed(7))
-    torch.set_num_threads(min(32, torch.get_num_threads()))
-    ref = sampler.ResidualOracle(w, prefix="model.unet0.", sampling_timesteps=S).sample(x_in, noise)[-1]
-    return w, x_in, noise, ref
-
-
 def _fp16_model(w, size, S, **kw):
     from founddiff_amd.DADiff import ResidualDiffusion, UnetRes, load_weights
     net = UnetRes(dim=64, dim_mults=(1, 2, 4, 8), num_unet=1, condition=True, objective="pred_res", test_res_or_noise="res",
@@ -134,7 +121,8 @@ def test_fp16_50step_vs_oracle(size):
     """BASELINE configs[1] / configs[2] geometry, 50-step DDIM, precision='fp16' in its default configuration against
     oracle.sampler.ResidualOracle.sample on the same x_T: L2 <= 1e-3 -- the tolerance of the north star, over the loop -- and
     >= 70 dB; without the tail (the 16-bit engine alone for all 50 steps) <= 2.5e-3."""
-    w, x_in, noise, ref = _oracle_loop(size, 50)
+    from conftest import oracle_ddim_loop
+    w, x_in, noise, ref = oracle_ddim_loop(size, 50, noise_seed=7 if size == 256 else 1000)     # (the loops the bf16 / fp32s tests use)
     dif = _fp16_model(w, size, 50)
     assert dif.final_fp32_steps == 1
     out = dif.sample([x_in.cuda()], batch_size=1, noise=noise.cuda())[-1].float().cpu()

@@ -90,17 +90,10 @@ def test_config2_256_production_vs_oracle_50step():
     tolerance, over the whole loop).  Measured in round 5: production 7.3e-3-class (engine-vs-engine figure of
     test_config2_256_bf16_50step_drift), and at 10 steps 1.37e-2 / 47.3 dB (fewer, larger steps weigh the bf16 steps more);
     fp32s 6e-5.  ~50 CPU forwards at 256x256: about a minute on 32 host threads."""
-    from founddiff_amd import arch, synth
+    from conftest import oracle_ddim_loop
     from founddiff_amd.DADiff import ResidualDiffusion, UnetRes, load_weights
-    from oracle import sampler
     S = 50
-    spec = arch.da_unet_spec(64, (1, 2, 4, 8), prefix="model.unet0.")
-    w = synth.synth_state_dict(spec, seed=0)
-    _, ld = synth.ct_phantom(1, 256, seed=10)
-    x_in = torch.from_numpy(ld)
-    noise = torch.randn(1, 1, 256, 256, generator=torch.Generator().manual_seed(7))
-    torch.set_num_threads(min(32, torch.get_num_threads()))
-    ref = sampler.ResidualOracle(w, prefix="model.unet0.", sampling_timesteps=S).sample(x_in, noise)[-1]
+    w, x_in, noise, ref = oracle_ddim_loop(256, S, noise_seed=7)          # (shared with tests/test_gpu_fp16.py)
     outs = {}
     for prec in ("bf16", "fp32s"):
         net = UnetRes(dim=64, dim_mults=(1, 2, 4, 8), num_unet=1, condition=True, objective="pred_res",

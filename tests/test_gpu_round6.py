@@ -284,16 +284,9 @@ def test_config3_512_production_and_fp32s_vs_oracle_50step():
     (the mode `fp32s_parity_mode` of the bench line times) <= 1e-3 max-rel, the north star's tolerance.  Until round 6 the
     512x512 loop was only compared with this library's own fp32 engine.  ~50 CPU forwards at 512x512: about 3-4 minutes on 32
     host threads."""
-    from founddiff_amd import arch, synth
-    from oracle import sampler
+    from conftest import oracle_ddim_loop
     S = 50
-    spec = arch.da_unet_spec(64, (1, 2, 4, 8), prefix="model.unet0.")
-    w = synth.synth_state_dict(spec, seed=0)
-    _, ld = synth.ct_phantom(1, 512, seed=10)
-    x_in = torch.from_numpy(ld)
-    noise = torch.randn(1, 1, 512, 512, generator=torch.Generator().manual_seed(1000))
-    torch.set_num_threads(min(32, torch.get_num_threads()))
-    ref = sampler.ResidualOracle(w, prefix="model.unet0.", sampling_timesteps=S).sample(x_in, noise)[-1]
+    w, x_in, noise, ref = oracle_ddim_loop(512, S, noise_seed=1000)       # (shared with tests/test_gpu_fp16.py: one oracle loop per session)
     outs = {}
     for prec in ("bf16", "fp32s"):
         dif = _full_model(prec, 512, S, w)
