@@ -97,7 +97,8 @@ def _build_tree(root, spec):
 class Unet(_ParamTree):
     """DA-CLIP conditioned U-Net (reference src/DADiff.py:530-740).  `condition` is forced on
     as in the reference (line 586).  Extra kwargs: `precision` selects the kernel mode -- 'bf16' (default) | 'fp16' (the same kernels
-    on the library's IEEE-binary16 build: 8 x smaller drift at the same speed, binary16's range) | 'fp32s' | 'fp32' | 'fp8' (bf16
+    on the library's IEEE-binary16 build: 8 x smaller drift at 0.96 of the speed, binary16's range) | 'auto' ('fp16' until a sample()
+    leaves that range, 'bf16' from then on) | 'fp32s' | 'fp32' | 'fp8' (bf16
     kernels with e4m3 weights on the fp8 MFMA for the 3x3 convolutions, BASELINE configs[4]); `clip_cfg` overrides the RN50 DA-CLIP geometry (tests use a shrunken one)."""
 
     def __init__(self, dim, init_dim=None, out_dim=None, dim_mults=(1, 2, 4, 8), channels=1,
@@ -116,6 +117,7 @@ class Unet(_ParamTree):
         self.out_dim = default(out_dim, channels)
         self.random_or_learned_sinusoidal_cond = False
         self.precision = precision or os.environ.get("FOUNDDIFF_PRECISION", "bf16")
+        self._auto_bf16 = False          # precision='auto': set once a sample() left binary16's range (ResidualDiffusion.sample)
         # kernel set for one slice at a time (DAEngine low_latency); Trainer.test(batch_size=1) turns it on
         self.low_latency = bool(int(os.environ.get("FOUNDDIFF_LOW_LATENCY", "0")))
         self.clip_cfg = clip_cfg or arch.RN50
@@ -156,11 +158,20 @@ class Unet(_ParamTree):
         self._engine = None
         return res
 
+    @property
+    def kernel_precision(self):
+        """the kernel mode `precision` stands for: 'auto' = 'fp16' (the 16-bit kernels on the binary16 build: 8 x smaller drift than
+        'bf16' at 0.96 of its speed) until a sample() of this model has produced a non-finite image -- an activation beyond binary16's
+        65504 -- and 'bf16' from then on"""
+        if self.precision == "auto":
+            return "bf16" if self._auto_bf16 else "fp16"
+        return self.precision
+
     def engine(self, precision=None, slot=0):
         """The packed-weight HIP engine of this UNet for `precision` (default: self.precision); one per
         precision is kept (the samplers run their last step(s) on the fp32 engine, see ResidualDiffusion).
         `slot`: engines with their own workspaces for concurrent half-batches (ResidualDiffusion.sample)."""
-        prec = precision or self.precision
+        prec = precision or self.kernel_precision
         if self._engine is None:
             self._engine = {}
         key = (prec, slot) if not self.low_latency else (prec, slot, "ll")
@@ -573,7 +584,7 @@ class ResidualDiffusion(nn.Module):
     def final_outer_levels(self):
         if self._final_outer_levels is not None:
             return self._final_outer_levels
-        return 0 if self.model.unet0.precision == "fp16" else 2
+        return 0 if self.model.unet0.kernel_precision == "fp16" else 2
 
     @final_outer_levels.setter
     def final_outer_levels(self, v):
@@ -919,14 +930,23 @@ class ResidualDiffusion(nn.Module):
         """src/DADiff.py:1368-1380: x_input = [ldct (B,1,H,W) in [0,1]] -> list of images in ~[0,1].
         `slice_seeds` (B int64): per-slice keys of the ancestral sampler's step noise (and of x_T when `noise` is not
         given) -- see p_sample_loop; founddiff_amd.parallel.sample_volume passes seed + GLOBAL slice index."""
+        x_input = list(x_input)
         res = self._sample(x_input, batch_size, last, noise, step_noise, slice_seeds)
-        if self.model.unet0.precision == "fp16" and self.check_fp16_range:
+        if self.model.unet0.kernel_precision == "fp16" and self.check_fp16_range:
             # binary16 ends at 65504: an activation beyond it is stored as infinity and reaches the image as NaN (the clamps of
             # the scheduler kernels propagate NaN like torch.clamp).  One reduction + one host read per sample() call.
             if not bool(torch.isfinite(res[-1]).all()):
-                raise L.FoundDiffHipError(
-                    "precision='fp16': the sampled image is not finite -- an activation of this checkpoint left IEEE binary16's "
-                    "range (65504).  Use precision='bf16' (same speed, fp32's range, 8 significand bits) or 'fp32s'.")
+                if self.model.unet0.precision != "auto":
+                    raise L.FoundDiffHipError(
+                        "precision='fp16': the sampled image is not finite -- an activation of this checkpoint left IEEE binary16's "
+                        "range (65504).  Use precision='bf16' (same speed, fp32's range, 8 significand bits), 'auto' or 'fp32s'.")
+                import warnings
+                warnings.warn("founddiff_amd: precision='auto': this checkpoint's activations leave IEEE binary16's range; "
+                              "this and every later sample() of the model run on the bfloat16 kernels")
+                for u in (getattr(self.model, "unet0", None), getattr(self.model, "unet1", None)):
+                    if u is not None:
+                        u._auto_bf16 = True
+                res = self._sample(x_input, batch_size, last, noise, step_noise, slice_seeds)
         return res
 
     def _sample(self, x_input, batch_size, last, noise, step_noise, slice_seeds):

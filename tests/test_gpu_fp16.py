@@ -33,6 +33,12 @@ def test_engine_binds_the_binary16_build(golden):
     dif.sample([g["x_input"].cuda()], batch_size=2, noise=g["ddim.noise0"].cuda())
     e32 = dif.model.unet0._engine[("fp32s", 0)]
     assert e32.mode == "fp32s" and e32.hip is L.BF16                          # the tail engine: fp32 storage, split-bf16, default build
+    # precision='auto' on a model whose activations stay in range IS the fp16 mode
+    out16 = dif.sample([g["x_input"].cuda()], batch_size=2, noise=g["ddim.noise0"].cuda())[-1]
+    g2, auto = _tiny_model(golden, "auto")
+    assert auto.model.unet0.kernel_precision == "fp16" and auto.final_outer_levels == 0
+    assert torch.equal(auto.sample([g["x_input"].cuda()], batch_size=2, noise=g["ddim.noise0"].cuda())[-1], out16)
+    assert auto.model.unet0.kernel_precision == "fp16"
 
 
 def test_ddim_tiny_fp16_vs_reference(golden):
@@ -189,7 +195,7 @@ def test_fp16_odd_sizes_and_one_slice_kernel_set(cfg):
 
 
 def test_fp16_out_of_range_checkpoint_is_reported(golden):
-    """binary16 stops at 65504.  A checkpoint whose activations leave that range must not come back as an image of NaNs: sample()
+    """(and precision='auto' falls back to the bfloat16 kernels.)  binary16 stops at 65504.  A checkpoint whose activations leave that range must not come back as an image of NaNs: sample()
     checks its result in the fp16 mode and raises, naming the mode that has the range (bf16).  Here: the tiny model with its first
     residual block's convolution scaled by 1e6 (the 3x3 output under the GroupNorm is stored in 16 bits)."""
     from founddiff_amd import _lib as L
@@ -198,7 +204,7 @@ def test_fp16_out_of_range_checkpoint_is_reported(golden):
     w = {k: v.clone() for k, v in g.weights("model.").items()}
     w["model.unet0.downs.0.0.block1.proj.bias"] += 3e5        # (the weight itself is standardised: scale the bias, which is not)
     outs = {}
-    for prec in ("fp16", "bf16"):
+    for prec in ("fp16", "bf16", "auto"):
         net = UnetRes(dim=32, dim_mults=(1, 2), num_unet=1, condition=True, objective="pred_res", test_res_or_noise="res",
                       precision=prec, clip_cfg=TINY_CLIP)
         dif = ResidualDiffusion(net, image_size=64, timesteps=1000, sampling_timesteps=4, objective="pred_res", loss_type="l2",
@@ -209,6 +215,14 @@ def test_fp16_out_of_range_checkpoint_is_reported(golden):
         if prec == "fp16":
             with pytest.raises(L.FoundDiffHipError, match="binary16"):
                 dif.sample([g["x_input"].cuda()], batch_size=2, noise=g["ddim.noise0"].cuda())
+        elif prec == "auto":
+            # 'auto' = fp16 until a sample() leaves the range, bf16 from then on: warns once, returns the bf16 engine's image
+            assert net.unet0.kernel_precision == "fp16"
+            with pytest.warns(UserWarning, match="binary16"):
+                outs[prec] = dif.sample([g["x_input"].cuda()], batch_size=2, noise=g["ddim.noise0"].cuda())[-1]
+            assert net.unet0.kernel_precision == "bf16" and torch.equal(outs["auto"], outs["bf16"])
+            again = dif.sample([g["x_input"].cuda()], batch_size=2, noise=g["ddim.noise0"].cuda())[-1]
+            assert torch.equal(again, outs["bf16"])
         else:
             outs[prec] = dif.sample([g["x_input"].cuda()], batch_size=2, noise=g["ddim.noise0"].cuda())[-1]
             assert torch.isfinite(outs[prec]).all()
