@@ -97,13 +97,13 @@ def _build(force, verbose, LIB, objname, extra):
     return LIB
 
 
-def resources():
-    """{source file: {mangled kernel name: {"vgpr", "agpr", "scratch", "occupancy", "lds"}}} of the objects build() compiled
+def resources(half="bf16"):
+    """{source file: {mangled kernel name: {"vgpr", "agpr", "scratch", "occupancy", "lds"}}} of the objects build(half=...) compiled
     (hipcc's kernel-resource-usage remarks): tests/test_host_cpu.py holds the hot kernels to a scratch ledger, so that a
     register-allocation accident (round 5: an early return in fd_softplus_fast cost the fp32 scans 450-820 bytes of scratch and a
     factor 3-5) fails a test instead of waiting for a profile."""
     out = {}
-    for f in sorted(glob.glob(os.path.join(LIBDIR, "obj", "*.resources.txt"))):
+    for f in sorted(glob.glob(os.path.join(LIBDIR, "obj_f16" if half == "fp16" else "obj", "*.resources.txt"))):
         cur, tab = None, {}
         for ln in open(f):
             m = re.search(r"Function Name: (\S+)", ln)

@@ -256,8 +256,13 @@ def test_kernel_scratch_ledger():
     if not shutil.which("/opt/rocm/bin/hipcc"):
         pytest.skip("no hipcc")
     from founddiff_amd import build
-    build.build()
-    res = build.resources()
+    for half in ("bf16", "fp16"):              # both builds of the library: the same ledger
+        build.build(half=half)
+        _check_ledger(build.resources(half), half)
+
+
+def _check_ledger(res, half):
+    import re
     assert res.get("fd_scan.hip") and res.get("fd_conv3x3.hip"), "no resource remarks beside the objects: rebuild with build(force=True)"
     model_nr = {(4, 4), (8, 4), (16, 8), (32, 16), (32, 32), (16, 16), (8, 8)}     # (d_state, dt_rank) of the shipped architecture
     ledger = [          # (file, pattern of the mangled name, bytes of scratch per lane it may use)
@@ -269,7 +274,7 @@ def test_kernel_scratch_ledger():
     for f, tab in res.items():
         for name, r in tab.items():
             limit = 0
-            m = re.search(r"scan_chunk_kernelI(DF16b|f)Li(\d+)ELi(\d+)E", name)
+            m = re.search(r"scan_chunk_kernelI(DF16b|DF16_|f)Li(\d+)ELi(\d+)E", name)
             if f == "fd_scan.hip" and m:
                 # combinations the architecture uses: a few spilled values at the 96-register occupancy step; the others
                 # (dt_rank 32 at d_state 8 / 16) only have to build
@@ -278,7 +283,7 @@ def test_kernel_scratch_ledger():
                 if lf == f and re.search(pat, name):
                     limit = lim
             if r.get("scratch", 0) > limit:
-                bad.append((f, name, r["scratch"], limit))
+                bad.append((half, f, name, r["scratch"], limit))
     assert not bad, bad
     # conv3x3_halo_kernel's halo registers are written by inline-asm loads (hidden from the compiler's waitcnt pass).
     # A register parked in an AGPR or in scratch before its load has landed would park garbage: every instantiation that uses
@@ -289,4 +294,4 @@ def test_kernel_scratch_ledger():
         plain = re.search(r"conv3x3_halo_kernelILi128ELi8ELb0ELb0ELb1E", name) is not None     # <128, 8, F8 = 0, UP = 0, SPL = 1>
         if plain:
             continue
-        assert r.get("agpr", 0) == 0 and r.get("scratch", 0) == 0, (name, r)
+        assert r.get("agpr", 0) == 0 and r.get("scratch", 0) == 0, (half, name, r)
