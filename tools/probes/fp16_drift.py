@@ -20,18 +20,21 @@ ap.add_argument("--size", type=int, default=256)
 ap.add_argument("--steps", type=int, default=50)
 ap.add_argument("--modes", default="bf16,fp16")
 ap.add_argument("--time-batch", type=int, default=8)
+ap.add_argument("--weight-seed", type=int, default=0)
+ap.add_argument("--phantom-seed", type=int, default=10)
+ap.add_argument("--noise-seed", type=int, default=7)
 ap.add_argument("--tails", default="1:2,0:2", help="tail steps : outer levels on the tail engine, comma separated")
 a = ap.parse_args()
 S, N = a.steps, a.size
 spec = arch.da_unet_spec(64, (1, 2, 4, 8), prefix="model.unet0.")
-w = synth.synth_state_dict(spec, seed=0)
-_, ld = synth.ct_phantom(1, N, seed=10)
+w = synth.synth_state_dict(spec, seed=a.weight_seed)
+_, ld = synth.ct_phantom(1, N, seed=a.phantom_seed)
 x_in = torch.from_numpy(ld)
-noise = torch.randn(1, 1, N, N, generator=torch.Generator().manual_seed(7))
+noise = torch.randn(1, 1, N, N, generator=torch.Generator().manual_seed(a.noise_seed))
 torch.set_num_threads(min(32, os.cpu_count()))
 t0 = time.time()
 ref = sampler.ResidualOracle(w, prefix="model.unet0.", sampling_timesteps=S).sample(x_in, noise)[-1]
-print(f"oracle: {time.time() - t0:.0f} s", flush=True)
+print(f"weights seed {a.weight_seed}, phantom seed {a.phantom_seed}, x_T seed {a.noise_seed}; oracle: {time.time() - t0:.0f} s", flush=True)
 
 
 def model(prec, tail, levels):
