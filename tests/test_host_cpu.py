@@ -295,3 +295,25 @@ def _check_ledger(res, half):
         if plain:
             continue
         assert r.get("agpr", 0) == 0 and r.get("scratch", 0) == 0, (half, name, r)
+
+
+def test_traffic_json_serves_the_bench_rooflines():
+    """profiles/traffic.json (PMC passes of tools/profile_round*.sh, summarised by tools/traffic.py) is where bench.py's roofline
+    entries take `traffic` from.  The dominant entry is a scan GROUP: its lookup key is formed in bench.roofline_leg from the group's
+    name -- a renamed group or a traffic.json written by an older traffic.py gives `traffic: null` in the driver's bench line without
+    any error (round 6 shipped one such record).  Hold the keys together here."""
+    import json
+    t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    groups = t.get("scan_hbm_bytes_per_launch")
+    assert isinstance(groups, dict), "traffic.json has no scan groups: python tools/traffic.py --resummarize profiles/traffic.json"
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for name, suffix in (("scan_seq_kernel (single pass, N >= 16, L <= 1024)", ""),
+                         ("scan_chunk_kernel x2 + scan_carry_kernel, level 0 (d_inner 128, N 4, two channels per lane)", "|l0"),
+                         ("scan_chunk_kernel x2 + scan_carry_kernel, levels 1-2 (N 8..16)", "|l12")):
+        assert f'"{name}"' in src, name                       # the group names bench.py uses
+        key = name.split(",")[0] + suffix                      # ... and the key it derives from them
+        assert groups.get(key), (key, sorted(groups))
+        assert 5e7 < groups[key] < 5e9
+    for k in ("total_hbm_bytes_per_forward", "conv3x3_halo128_hbm_bytes_per_launch", "pwdw_gram_hbm_bytes_per_launch",
+              "gemm_rows_zre_hbm_bytes_per_launch", "conv3x3_up_hbm_bytes_per_launch", "csrc_sha"):
+        assert t.get(k), k
