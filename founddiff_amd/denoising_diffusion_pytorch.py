@@ -237,11 +237,14 @@ class Unet(_ParamTree):
         return super()._load_from_state_dict(*a, **k)
 
     def engine(self):
-        if self._engine is None or self._engine.mode != self.precision:
+        # ('auto' -- fp16 with a bf16 fallback -- belongs to ResidualDiffusion.sample of the DA path; this plumbing model, BASELINE
+        #  configs[0], runs it as 'bf16'.  'fp16' itself works here too: the same kernels on the binary16 build.)
+        mode = "bf16" if self.precision == "auto" else self.precision
+        if self._engine is None or self._engine.mode != mode:
             dev = next(self.parameters()).device
             if dev.type != "cuda":
                 raise L.FoundDiffHipError("founddiff_amd runs on MI355X only; there is no CPU path")
-            self._engine = VanillaEngine(self.state_dict(), "", dev, self.precision)
+            self._engine = VanillaEngine(self.state_dict(), "", dev, mode)
         return self._engine
 
     @torch.no_grad()

@@ -106,6 +106,14 @@ def test_vanilla_bf16_runs(golden):
     g, dif = _model(golden, "pred_noise", 10, precision="bf16")
     res = dif.sample(batch_size=2, noise=g["ddim.pred_noise.xT"].cuda())
     assert torch.isfinite(res[0]).all()
+    # ... and on the library's binary16 build (precision='fp16': the same kernels, three more significand bits in every stored
+    # tensor): the one-UNet forward against the reference, closer than the bf16 engine's
+    outs = {}
+    for prec in ("bf16", "fp16"):
+        g, d = _model(golden, "pred_noise", 10, precision=prec)
+        outs[prec] = rel_err(d.model(g["unet.x"].cuda(), g["unet.t"].cuda()).cpu(), g["unet.out"])
+    print(f"vanilla UNet forward vs the reference: bf16 {outs['bf16']:.2e}, fp16 {outs['fp16']:.2e} max-rel")
+    assert outs["fp16"] < 0.4 * outs["bf16"] and outs["fp16"] < 5e-3, outs
 
 
 @pytest.mark.parametrize("mode,tol", [("fp32", 2e-5), ("bf16", 1.5e-2)])
