@@ -669,6 +669,9 @@ def main():
             res["metric"] = "denoised CT slices/sec (512x512, 1000-step ancestral p_sample_loop)"
             res["config"]["workload"] = ("BASELINE configs[3] sampler: 512x512 slices, 1000-step ancestral p_sample, step noise "
                                          "keyed per slice, full FoundDiff UNet + DA-CLIP RN50 cond, bf16")
+        elif a.precision == "fp16" and a.ddim_steps == S_DDIM:
+            res["config"]["workload"] = ("BASELINE configs[2] geometry: 512x512 slice, 50-step DDIM, full FoundDiff UNet + DA-CLIP RN50 "
+                                         "cond, on the library's IEEE-binary16 build (precision fp16; a variant, not the headline)")
         elif a.precision != "bf16" or a.ddim_steps != S_DDIM:
             res["config"]["workload"] = (f"BASELINE configs[4] geometry: 512x512 slice, {a.ddim_steps}-step DDIM, full FoundDiff "
                                          f"UNet + DA-CLIP RN50 cond, precision {a.precision}")
